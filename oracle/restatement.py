@@ -1,0 +1,412 @@
+"""CPU restatement of the doc2tex recognizer forward pass -- TEST INFRASTRUCTURE.
+
+This file is the parity oracle for the HIP engine.  It is NOT part of the
+product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it.  It restates, in plain functional fp32 PyTorch on the CPU, what
+the reference computes on the hot path named by BASELINE.json,
+operating directly on a state_dict with the reference's key names.
+
+Pinning: the reference ships no tests or golden vectors for this path
+(SURVEY.md 4 / 8c), so this restatement is pinned against the reference itself,
+imported in the authoring container by tools/make_golden.py, which (1) checks
+every stage of this file against the reference modules on the same seeded
+weights/inputs and (2) writes tests/golden/*.npz from the REFERENCE's outputs.
+tests/test_oracle_golden.py re-checks this file against those fixtures
+anywhere (no reference needed).
+
+Two modes where the reference's algorithm is wasteful:
+  faithful=True   op-for-op what the reference does: unfused conv+BN+ReLU
+                  (resnet.py:205-245), full-prefix re-decode every step with no
+                  KV cache (tfm.py:125-140).  Used for the CPU baseline timing.
+  faithful=False  same arithmetic, BN folded into the conv and a KV cache /
+                  one-time cross-attention K,V projection (what the engine does).
+
+All file:line citations are relative to /root/reference/doc2tex/.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+PAD, GO, END, UNK = 0, 1, 2, 3  # modules/converter/tfm_converter.py:8,20-34
+RESNET_LAYERS = (1, 2, 5, 3)  # feature_extractor/resnet.py:262
+
+
+# ---------------------------------------------------------------------------
+# ResNet backbone  (modules/component/feature_extractor/resnet.py)
+# ---------------------------------------------------------------------------
+def _bn(x, sd, p, eps=1e-5):
+    # nn.BatchNorm2d in eval mode: running statistics
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+
+
+def fold_bn(w, sd, p, eps=1e-5):
+    """conv weight/bias with eval BatchNorm folded in: y = conv(x, w*s) + (b - m*s)."""
+    s = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + eps)
+    return w * s.view(-1, 1, 1, 1), sd[p + ".bias"] - sd[p + ".running_mean"] * s
+
+
+def _conv_bn(x, sd, conv, bn, stride=1, padding=0, faithful=True):
+    w = sd[conv + ".weight"]
+    if faithful:
+        return _bn(F.conv2d(x, w, None, stride, padding), sd, bn)
+    wf, bf = fold_bn(w, sd, bn)
+    return F.conv2d(x, wf, bf, stride, padding)
+
+
+def _basic_block(x, sd, p, faithful):
+    # BasicBlock.forward, resnet.py:32-48 (ReLU after the residual add, :45-46)
+    out = F.relu(_conv_bn(x, sd, p + ".conv1", p + ".bn1", 1, 1, faithful))
+    out = _conv_bn(out, sd, p + ".conv2", p + ".bn2", 1, 1, faithful)
+    if (p + ".downsample.0.weight") in sd:  # 1x1 conv + BN, resnet.py:181-192
+        x = _conv_bn(x, sd, p + ".downsample.0", p + ".downsample.1", 1, 0, faithful)
+    return F.relu(out + x)
+
+
+def resnet(x, sd, p, faithful=True):
+    """ResNet.forward, resnet.py:205-245.  x [B,1,H,W] -> [B,512,H',W'] (NCHW)."""
+    cb = lambda x, c, b, s=1, pd=1: F.relu(_conv_bn(x, sd, p + c, p + b, s, pd, faithful))
+    x = cb(x, "conv0_1", "bn0_1")
+    x = cb(x, "conv0_2", "bn0_2")
+    x = F.max_pool2d(x, 2, 2, 0)  # :94
+    for i in range(RESNET_LAYERS[0]):
+        x = _basic_block(x, sd, f"{p}layer1.{i}", faithful)
+    x = cb(x, "conv1", "bn1")
+    x = F.max_pool2d(x, 2, 2, 0)  # :106
+    for i in range(RESNET_LAYERS[1]):
+        x = _basic_block(x, sd, f"{p}layer2.{i}", faithful)
+    x = cb(x, "conv2", "bn2")
+    x = F.max_pool2d(x, 2, (2, 1), (0, 1))  # :120, implicit -inf padding
+    for i in range(RESNET_LAYERS[2]):
+        x = _basic_block(x, sd, f"{p}layer3.{i}", faithful)
+    x = cb(x, "conv3", "bn3")
+    for i in range(RESNET_LAYERS[3]):
+        x = _basic_block(x, sd, f"{p}layer4.{i}", faithful)
+    x = cb(x, "conv4_1", "bn4_1", (2, 1), (0, 1))  # :139-147
+    x = cb(x, "conv4_2", "bn4_2", 1, 0)  # :149-157
+    return x
+
+
+def resnet_out_hw(h, w):
+    """Spatial size of resnet() output for an h x w crop."""
+    h, w = h // 2, w // 2
+    h, w = h // 2, w // 2
+    h, w = (h - 2) // 2 + 1, (w + 2 - 2) // 1 + 1  # maxpool3 k2 s(2,1) p(0,1)
+    h, w = (h - 2) // 2 + 1, (w + 2 - 2) // 1 + 1  # conv4_1 k2 s(2,1) p(0,1)
+    return h - 1, w - 1  # conv4_2 k2 s1 p0
+
+
+# ---------------------------------------------------------------------------
+# Position tables
+# ---------------------------------------------------------------------------
+def sincos_2d_table(dim, grid_h, grid_w):
+    """get_2d_sincos_pos_embed(cls_token=True), common/mae_posembed.py:20-70.
+
+    meshgrid(grid_w, grid_h) puts w first (:28): channels [0, D/2) encode the
+    COLUMN index, [D/2, D) the ROW index; each half is [sin | cos] concatenated;
+    row 0 is the zero cls row.  float32 numpy like the reference.
+    """
+    gh = np.arange(grid_h, dtype=np.float32)
+    gw = np.arange(grid_w, dtype=np.float32)
+    col, row = np.meshgrid(gw, gh)  # each [grid_h, grid_w]
+
+    def one(d, pos):
+        omega = np.arange(d // 2, dtype=np.float32)
+        omega /= d / 2.0
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([one(dim // 2, col), one(dim // 2, row)], axis=1)
+    emb = np.concatenate([np.zeros([1, dim]), emb], axis=0)
+    return torch.from_numpy(emb).float().unsqueeze(0)  # [1, 1+gh*gw, dim]
+
+
+def word_pos_table(d_model, max_len=500, temperature=10000.0):
+    """WordPosEnc, prediction_head/addon_module/position_encoding.py:7-22."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float)
+    dim_t = torch.arange(0, d_model, 2, dtype=torch.float)
+    div_term = 1.0 / (temperature ** (dim_t / d_model))
+    ang = position[:, None] * div_term[None, :]
+    pe[:, 0::2] = ang.sin()
+    pe[:, 1::2] = ang.cos()
+    return pe
+
+
+def posenc2d_crop(d_model, h, w):
+    """PositionalEncoding2D.pe[:, :h, :w], common/postional_encoding.py:105-134,146-157.
+
+    First d/2 channels encode the row, last d/2 the column, sin/cos interleaved.
+    Built directly at [d,h,w] instead of the reference's 2000x2000 table."""
+    def pe1d(n, d):
+        pe = torch.zeros(n, d)
+        position = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+        pe[:, 0::2] = torch.sin(position * div)
+        pe[:, 1::2] = torch.cos(position * div)
+        return pe
+    half = d_model // 2
+    pe_h = pe1d(h, half).t()[:, :, None].expand(half, h, w)
+    pe_w = pe1d(w, half).t()[:, None, :].expand(half, h, w)
+    return torch.cat([pe_h, pe_w], dim=0).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# HybridViT encoder
+# ---------------------------------------------------------------------------
+def hybrid_embed(x, sd, p, patch=(2, 2), faithful=True):
+    """HybridEmbed.forward, seq_modeling/addon_module/patchembed.py:115-141."""
+    x = resnet(x, sd, p + "backbone.ConvNet.", faithful)
+    fh, fw = x.shape[2:]
+    pad_h = (-fh) % patch[0]
+    pad_w = (-fw) % patch[1]
+    x = F.pad(x, (0, pad_w, 0, pad_h))  # zeros right/bottom, :121-126
+    y = F.conv2d(x, sd[p + "proj.weight"], sd[p + "proj.bias"], stride=patch)
+    return y.flatten(2).transpose(1, 2), (pad_w, pad_h), {"height": x.shape[2], "width": x.shape[3]}
+
+
+def _vit_block(x, sd, p, heads):
+    """Block.forward vision_transformer.py:119-122; Attention :61-81; Mlp :26-32."""
+    B, N, C = x.shape
+    hd = C // heads
+    h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)  # eps :175
+    qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    h = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    x = x + F.linear(h, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+    h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))  # exact erf
+    return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None):
+    """ViTEncoderV3.forward, seq_modeling/vit_encoder.py:249-268."""
+    x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful)
+    if taps is not None:
+        taps["patch"] = x
+    B, n, C = x.shape
+    x = torch.cat((sd[p + "cls_token"].expand(B, -1, -1), x), dim=1)
+    x = x + sd[p + "pos_embed"][:, : n + 1]  # flat prefix slice, :260
+    for i in range(depth):
+        x = _vit_block(x, sd, f"{p}blocks.{i}.", heads)
+        if taps is not None:
+            taps[f"block{i}"] = x
+    x = F.layer_norm(x, (C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    return x, pad_info, size
+
+
+# ---------------------------------------------------------------------------
+# Transformer decoder (nn.TransformerDecoder, post-norm, ReLU, no final norm)
+# prediction_head/tfm.py:12-32
+# ---------------------------------------------------------------------------
+def _split_heads(x, heads):  # [B,L,d] -> [B,H,L,hd]
+    B, L, d = x.shape
+    return x.view(B, L, heads, d // heads).transpose(1, 2)
+
+
+def _attend(q, k, v, mask=None):
+    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], additive mask broadcastable to [B,H,Lq,Lk]."""
+    s = (q @ k.transpose(-2, -1)) * (q.shape[-1] ** -0.5)
+    if mask is not None:
+        s = s + mask
+    o = s.softmax(dim=-1) @ v
+    B, H, L, hd = o.shape
+    return o.transpose(1, 2).reshape(B, L, H * hd)
+
+
+def _ln(x, sd, p, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def cross_kv(mem, sd, p, heads):
+    """K,V of the memory for one layer's multihead_attn (in_proj rows d:2d, 2d:3d)."""
+    d = mem.shape[-1]
+    w, b = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
+    k = F.linear(mem, w[d:2 * d], b[d:2 * d])
+    v = F.linear(mem, w[2 * d:], b[2 * d:])
+    return _split_heads(k, heads), _split_heads(v, heads)
+
+
+def _decoder_layer(x, sd, p, heads, self_k, self_v, ck, cv, mask):
+    """One nn.TransformerDecoderLayer (norm_first=False) on queries x [B,Lq,d].
+
+    self_k/self_v [B,H,Lk,hd] are the self-attention keys/values (already
+    including x's own positions); ck/cv the cross-attention K,V of the memory."""
+    d = x.shape[-1]
+    w, b = sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]
+    q = _split_heads(F.linear(x, w[:d], b[:d]), heads)
+    a = _attend(q, self_k, self_v, mask)
+    x = _ln(x + F.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"]), sd, p + "norm1")
+    w, b = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
+    q = _split_heads(F.linear(x, w[:d], b[:d]), heads)
+    a = _attend(q, ck, cv)
+    x = _ln(x + F.linear(a, sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"]), sd, p + "norm2")
+    h = F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"]))
+    return _ln(x + F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"]), sd, p + "norm3")
+
+
+def _self_kv(x, sd, p, heads):
+    d = x.shape[-1]
+    w, b = sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]
+    return (_split_heads(F.linear(x, w[d:2 * d], b[d:2 * d]), heads),
+            _split_heads(F.linear(x, w[2 * d:], b[2 * d:]), heads))
+
+
+def _causal_mask(L):
+    # _build_attention_mask, tfm.py:74-84: 0 on/below the diagonal, -inf above
+    return torch.full((L, L), float("-inf")).triu(1)
+
+
+def _embed(tgt, sd, p, pos0=0):
+    # _embedd_tgt tfm.py:86-94: Embedding * sqrt(d) + WordPosEnc (position_encoding.py:24-28)
+    d = sd[p + "word_embed.weight"].shape[1]
+    e = F.embedding(tgt, sd[p + "word_embed.weight"]) * math.sqrt(d)
+    return e + sd[p + "pos_enc.pe"][pos0:pos0 + tgt.shape[1]][None]
+
+
+def tfm_full_pass(tgt, mem, sd, p, layers, heads, key_padding=False):
+    """Decoder over a whole token prefix tgt [B,L] (what the reference runs at
+    every greedy step, and the teacher-forced training pass tfm.py:103-118)."""
+    B, L = tgt.shape
+    x = _embed(tgt, sd, p)
+    mask = _causal_mask(L)[None, None]
+    if key_padding:  # tgt_key_padding_mask = (tgt == PAD), training only (tfm.py:88-91)
+        mask = mask + torch.zeros(B, 1, 1, L).masked_fill((tgt == PAD)[:, None, None, :], float("-inf"))
+    for i in range(layers):
+        lp = f"{p}model.layers.{i}."
+        sk, sv = _self_kv(x, sd, lp, heads)
+        ck, cv = cross_kv(mem, sd, lp, heads)
+        x = _decoder_layer(x, sd, lp, heads, sk, sv, ck, cv, mask)
+    return F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def tfm_greedy(mem, sd, p, layers, heads, max_seq_len, is_test=False, faithful=False, tgt=None):
+    """TransformerPrediction.forward_greedy eval branch, tfm.py:119-143.
+
+    Returns (preds_index [B,S], logits [B,S,V]).  faithful=True re-decodes the
+    whole prefix each step and returns the final pass's logits, as the
+    reference does; faithful=False keeps a KV cache and records each step's
+    last-position logits (equal up to fp32 accumulation noise)."""
+    B = mem.shape[0]
+    if tgt is None:
+        tgt = torch.full((B, 1), GO, dtype=torch.long)
+    end = torch.zeros(B, dtype=torch.bool)
+    if faithful:
+        out = None
+        for _ in range(max_seq_len + 1):
+            out = tfm_full_pass(tgt, mem, sd, p, layers, heads)
+            nxt = out[:, -1:].softmax(-1).argmax(-1)
+            tgt = torch.cat([tgt, nxt], dim=-1)
+            end |= nxt[:, 0] == END
+            if end.all() and is_test:
+                break
+        return out.argmax(dim=2), out
+    ckv = [cross_kv(mem, sd, f"{p}model.layers.{i}.", heads) for i in range(layers)]
+    sk = [None] * layers
+    sv = [None] * layers
+    logits = []
+    tok = tgt[:, -1:]
+    for step in range(max_seq_len + 1):
+        x = _embed(tok, sd, p, pos0=step)
+        for i in range(layers):
+            lp = f"{p}model.layers.{i}."
+            k, v = _self_kv(x, sd, lp, heads)
+            sk[i] = k if sk[i] is None else torch.cat([sk[i], k], dim=2)
+            sv[i] = v if sv[i] is None else torch.cat([sv[i], v], dim=2)
+            x = _decoder_layer(x, sd, lp, heads, sk[i], sv[i], ckv[i][0], ckv[i][1], None)
+        lg = F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+        logits.append(lg)
+        tok = lg.argmax(-1)
+        end |= tok[:, 0] == END
+        if end.all() and is_test:
+            break
+    out = torch.cat(logits, dim=1)
+    return out.argmax(dim=2), out
+
+
+def tfm_beam(mem, sd, p, layers, heads, max_seq_len, beam_size):
+    """TransformerPrediction.forward_beam (tfm.py:145-186) + Beam (tools/beam.py:38-140)
+    for ONE sample (mem [1,T,d]) with a fresh Beam (demo reset_beam semantics).
+
+    Full-length re-decode of every live hypothesis, log_softmax at `step`,
+    flat top-k over (hyp x V) with k = beam - completed.  Returns
+    (LongTensor [1,len], score float)."""
+    assert mem.shape[0] == 1
+    hyps = torch.full((1, max_seq_len + 2), PAD, dtype=torch.long)
+    hyps[:, 0] = GO
+    scores = torch.zeros(1)
+    completed = []  # (seq list, score)
+    for step in range(max_seq_len + 1):
+        n = hyps.shape[0]
+        out = tfm_full_pass(hyps, mem.expand(n, -1, -1), sd, p, layers, heads)
+        logp = F.log_softmax(out[:, step, :], dim=-1)
+        V = logp.shape[1]
+        live = beam_size - len(completed)
+        top_s, top_i = torch.topk((scores[:, None] + logp).reshape(-1), k=live)
+        prev, word = top_i // V, top_i % V
+        new_h, new_s = [], []
+        for pi, wi, sc in zip(prev.tolist(), word.tolist(), top_s.tolist()):
+            hyps[pi, step + 1] = wi  # in-place write before clone, beam.py:90
+            if wi == END:
+                completed.append((hyps[pi, 1:step + 2].tolist(), sc))
+            else:
+                new_h.append(hyps[pi].clone())
+                new_s.append(sc)
+        if len(completed) == beam_size:
+            break
+        hyps = torch.stack(new_h, dim=0)
+        scores = torch.tensor(new_s, dtype=torch.float)
+    if not completed:  # set_hypothesis, beam.py:132-140
+        completed.append((hyps[0, 1:].tolist(), float(scores[0])))
+    best = max(completed, key=lambda h: h[1] / max(len(h[0]), 1))
+    return torch.LongTensor(best[0]).unsqueeze(0), best[1]
+
+
+# ---------------------------------------------------------------------------
+# Model.forward  (modules/build_model.py:36-79)
+# ---------------------------------------------------------------------------
+def forward_encoder(cfg, sd, image, faithful=True, taps=None):
+    """Model.forward_encoder: returns (contextual_feature [B,T,d], output_shape, feat_pad)."""
+    seq = cfg["SequenceModeling"]
+    if seq["name"] == "ViT":
+        sp = seq["params"]
+        x, pad_info, size = vit_encoder_v3(image, sd, "seqmodeler.SequenceModeling.", sp["depth"],
+                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps)
+        shape = (size["height"] // sp["patch_size"][0], size["width"] // sp["patch_size"][1])
+        return x, shape, pad_info
+    # Feat=ResNet, Seq=None, Pred=TFM: PositionalEncoding2D add then B,C,H,W -> B,HW,C
+    # (recognizers/build_seq.py:69-76)
+    f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful)
+    if taps is not None:
+        taps["backbone"] = f
+    f = f + posenc2d_crop(f.shape[1], f.shape[2], f.shape[3])
+    return f.flatten(2).transpose(1, 2).contiguous(), None, None
+
+
+def forward(cfg, sd, image, text, is_train=True, is_test=False, faithful=False, training=False):
+    """Model.forward.  `training` mirrors module.training (teacher forcing vs
+    autoregressive, tfm.py:103,189); is_train is the (unused by TFM) call flag."""
+    pp = cfg["Prediction"]["params"]
+    mem, shape, pad = forward_encoder(cfg, sd, image, faithful)
+    p = "predicter.Prediction."
+    if training:
+        logits = tfm_full_pass(text, mem, sd, p, pp["num_decoder_layers"], pp["nhead"], key_padding=True)
+        return logits.argmax(2), logits, {}
+    if cfg.get("beam_size", 1) > 1:
+        seq, score = tfm_beam(mem, sd, p, pp["num_decoder_layers"], pp["nhead"], pp["max_seq_len"], cfg["beam_size"])
+        return seq, score, {}
+    preds, logits = tfm_greedy(mem, sd, p, pp["num_decoder_layers"], pp["nhead"], pp["max_seq_len"],
+                               is_test=is_test, faithful=faithful, tgt=text)
+    return preds, logits, {}
+
+
+def ce_loss(logits, target):
+    """forward_step + train_one_step loss (engine/training.py:83,126):
+    CrossEntropyLoss(ignore_index=PAD, reduction='none') then .mean() over ALL B*L."""
+    V = logits.shape[-1]
+    return F.cross_entropy(logits.reshape(-1, V), target.reshape(-1), ignore_index=PAD, reduction="none").mean()

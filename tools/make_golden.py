@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE and validate oracle/restatement.py.
+
+Authoring-container only: imports /root/reference (never shipped, never read at
+test/bench time).  For each case it
+  1. builds the reference Model(opt) and loads the seeded synthetic state_dict
+     (doc2tex_amd/synth.py),
+  2. runs the reference forward on seeded crops,
+  3. runs oracle/restatement.py (faithful and KV-cached modes) on the same
+     tensors and asserts agreement (tokens exact, floats <= TOL),
+  4. writes the reference's outputs as small fixtures (npz + json).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+from doc2tex_amd import synth
+from oracle import restatement as R
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from doc2tex.modules.build_model import Model as RefModel
+    from doc2tex.tools.beam import Beam as RefBeam
+    from doc2tex.modules.converter.tfm_converter import TFMLabelConverter as RefTFM
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 2e-5  # restatement vs reference, fp32 CPU both
+
+# name, config, B, H, W, max_seq_len, weight seed, input seed, end_bias, is_test
+GREEDY_CASES = [
+    ("t2_greedy", "T2", 2, 48, 64, 12, 1234, 1000, 0.0, False),
+    ("t2_greedy_early", "T2", 3, 48, 64, 40, 1234, 1001, 1.81, True),
+    ("t2_greedy_late", "T2", 3, 48, 64, 40, 1234, 1001, 1.8, True),
+    ("t1_greedy", "T1", 2, 32, 64, 12, 1234, 1002, 0.0, False),
+    ("c2_greedy", "C2", 2, 128, 512, 150, 1234, 1003, 0.0, False),
+    ("c2_small_crop", "C2", 1, 96, 384, 10, 1234, 1004, 0.0, False),
+    ("c1_greedy", "C1", 2, 64, 256, 30, 1234, 1005, 0.0, False),
+]
+BEAM_CASES = [
+    ("t2_beam5", "T2", 48, 64, 16, 1234, 1010, 1.8, 5),
+    ("c2_beam5", "C2", 96, 384, 12, 1234, 1011, 1.8, 5),
+    ("t2_beam3_nofinish", "T2", 48, 64, 6, 1234, 1012, 0.0, 3),
+]
+TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
+
+
+def build_ref(cfg_name, max_seq_len, beam_size=None, wseed=1234, end_bias=0.0):
+    cfg = synth.make_config(cfg_name, max_seq_len=max_seq_len, beam_size=beam_size)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = RefModel(cfg)
+    tmpl = m.state_dict()
+    # the C1 table is (512,2000,2000) fp32 = 8 GB: never copy it
+    sd = {}
+    for k, v in tmpl.items():
+        t = synth.synth_tensor(k, v.shape, v.dtype, seed=wseed, end_bias=end_bias)
+        sd[k] = v if t is None else t
+    m.load_state_dict(sd)
+    m.eval()
+    return cfg, m, sd
+
+
+def manifest(sd):
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
+def maxdiff(a, b):
+    """max |a-b| relative to max(1, max|b|) (backbone features are O(10-100))."""
+    return float((a.double() - b.double()).abs().max() / max(1.0, float(b.double().abs().max())))
+
+
+def slim_sd(sd):
+    """state_dict view for the restatement (drops nothing; the 8 GB C1 table is
+    only referenced, the restatement builds its own crop)."""
+    return sd
+
+
+def check_tables(cfg, sd, report):
+    p = "seqmodeler.SequenceModeling."
+    if p + "pos_embed" in sd:
+        gh, gw = R.resnet_out_hw(*cfg["max_dimension"])
+        gh, gw = -(-gh // 2), -(-gw // 2)
+        t = R.sincos_2d_table(sd[p + "pos_embed"].shape[-1], gh, gw)
+        d = maxdiff(t, sd[p + "pos_embed"])
+        assert d == 0.0, f"sincos table differs {d}"
+        report["pos_embed_sum"] = float(sd[p + "pos_embed"].double().sum())
+        report["pos_embed_abs"] = float(sd[p + "pos_embed"].double().abs().sum())
+    pe = sd["predicter.Prediction.pos_enc.pe"]
+    d = maxdiff(R.word_pos_table(pe.shape[1], pe.shape[0]), pe)
+    assert d == 0.0, f"word pos table differs {d}"
+    report["pe_sum"] = float(pe.double().sum())
+    if "seqmodeler.image_positional_encoder.pe" in sd:
+        big = sd["seqmodeler.image_positional_encoder.pe"]
+        crop = big[:, :9, :80]
+        d = maxdiff(R.posenc2d_crop(big.shape[0], 9, 80), crop)
+        assert d == 0.0, f"posenc2d differs {d}"
+        report["pe2d_crop_sum"] = float(crop.double().sum())
+
+
+def run_greedy(case):
+    name, cname, B, H, W, L, wseed, iseed, end_bias, is_test = case
+    t0 = time.time()
+    cfg, m, sd = build_ref(cname, L, wseed=wseed, end_bias=end_bias)
+    img = synth.synth_images(B, H, W, seed=iseed)
+    text = torch.full((B, 1), R.GO, dtype=torch.long)
+    rep = {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed,
+           "iseed": iseed, "end_bias": end_bias, "is_test": is_test, "torch": torch.__version__}
+    check_tables(cfg, sd, rep)
+    with torch.no_grad():
+        mem, shape, pad = m.forward_encoder(img)
+        preds, logits, _ = m(img, text, is_train=False, is_test=is_test)
+        # restatement, both modes
+        taps = {}
+        mem_f, shape_f, pad_f = R.forward_encoder(cfg, sd, img, faithful=True, taps=taps)
+        mem_a, _, _ = R.forward_encoder(cfg, sd, img, faithful=False)
+        pf, lf, _ = R.forward(cfg, sd, img, text, is_test=is_test, faithful=True)
+        pa, la, _ = R.forward(cfg, sd, img, text, is_test=is_test, faithful=False)
+    assert (shape_f, pad_f) == (shape, pad), (shape_f, pad_f, shape, pad)
+    rep["diff_mem_faithful"] = maxdiff(mem_f, mem)
+    rep["diff_mem_folded"] = maxdiff(mem_a, mem)
+    assert rep["diff_mem_faithful"] <= TOL and rep["diff_mem_folded"] <= TOL, rep
+    assert pf.shape == preds.shape == pa.shape, (pf.shape, preds.shape, pa.shape)
+    assert torch.equal(pf, preds), "faithful restatement tokens differ"
+    assert torch.equal(pa, preds), "cached restatement tokens differ"
+    rep["diff_logits_faithful"] = maxdiff(lf, logits)
+    rep["diff_logits_cached"] = maxdiff(la, logits)
+    assert rep["diff_logits_faithful"] <= TOL and rep["diff_logits_cached"] <= 10 * TOL, rep
+    top2 = logits.topk(2, dim=-1).values
+    rep["min_top2_gap"] = float((top2[..., 0] - top2[..., 1]).min())
+    rep["steps"] = int(preds.shape[1])
+    rep["output_shape"] = list(shape) if shape is not None else None
+    rep["feat_pad"] = list(pad) if pad is not None else None
+    rep["mem_shape"] = list(mem.shape)
+    rep["mem_sum"] = float(mem.double().sum())
+    rep["mem_abs"] = float(mem.double().abs().sum())
+    rep["mem_absmax"] = float(mem.abs().max())
+    rep["logits_sum"] = float(logits.double().sum())
+    rep["logits_absmax"] = float(logits.abs().max())
+    rows = sorted(set([0, 1, mem.shape[1] // 2, mem.shape[1] - 1]))
+    steps = sorted(set(min(i, preds.shape[1] - 1) for i in [0, 1, preds.shape[1] // 2, preds.shape[1] - 1]))
+    arrays = {
+        "tokens": preds.numpy().astype(np.int32),
+        "mem_rows": np.array(rows, dtype=np.int32),
+        "mem_sample": mem[:, rows].numpy(),
+        "logit_steps": np.array(steps, dtype=np.int32),
+        "logits_sample": logits[:, steps].numpy(),
+        "top2_gap": (top2[..., 0] - top2[..., 1]).numpy(),
+    }
+    if mem.numel() <= 64 * 1024:
+        arrays["mem_full"] = mem.numpy()
+    if "patch" in taps:  # per-stage checksums for bisecting engine mismatches
+        rep["patch_sum"] = float(taps["patch"].double().sum())
+        for k in sorted(k for k in taps if k.startswith("block")):
+            rep[k + "_sum"] = float(taps[k].double().sum())
+    if "backbone" in taps:
+        rep["backbone_sum"] = float(taps["backbone"].double().sum())
+        rep["backbone_shape"] = list(taps["backbone"].shape)
+    rep["seconds"] = round(time.time() - t0, 1)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
+    return rep, manifest(sd), cname
+
+
+def run_beam(case):
+    name, cname, H, W, L, wseed, iseed, end_bias, beam = case
+    cfg, m, sd = build_ref(cname, L, beam_size=beam, wseed=wseed, end_bias=end_bias)
+    img = synth.synth_images(1, H, W, seed=iseed)
+    text = torch.full((1, 1), R.GO, dtype=torch.long)
+    pred = m.predicter.Prediction
+    # fresh Beam per sample (demo reset_beam semantics)
+    pred.beam = RefBeam(ignore_w=RefTFM.PAD(), start_w=RefTFM.START(), stop_w=RefTFM.END(),
+                        max_len=pred.max_seq_len, device="cpu")
+    with torch.no_grad():
+        seq, score, _ = m(img, text, is_train=False, is_test=True)
+        n_completed = len(pred.beam.completed_hypotheses)
+        rseq, rscore, _ = R.forward(cfg, sd, img, text, is_test=True)
+    assert torch.equal(seq, rseq), (seq, rseq)
+    assert abs(score - rscore) <= 1e-4, (score, rscore)
+    rep = {"case": name, "config": cname, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
+           "end_bias": end_bias, "beam_size": beam, "seq": seq[0].tolist(), "score": float(score),
+           "completed": n_completed, "torch": torch.__version__}
+    return rep
+
+
+def run_train(case):
+    name, cname, B, H, W, L, wseed, iseed = case
+    cfg, m, sd = build_ref(cname, L, wseed=wseed)
+    m.train()  # teacher forcing (tfm.py:103); BN switches to batch statistics
+    img = synth.synth_images(B, H, W, seed=iseed)
+    text = synth.synth_labels(B, max_len=L, seed=iseed)
+    text[:, 8:] = 0
+    text[:, 7] = R.END  # short labels so PAD masking is exercised
+    # The reference train path uses BN batch statistics; the engine/oracle
+    # parity target for the teacher-forced pass is the eval-BN encoder +
+    # training-mode decoder.  Golden: decoder pass on the eval encoder memory.
+    m.eval()
+    with torch.no_grad():
+        mem, _, _ = m.forward_encoder(img)
+    m.predicter.train()
+    logits = m.predicter(mem, text[:, :-1], True, False)[1]
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), text[:, 1:].reshape(-1),
+                                             ignore_index=0, reduction="none").mean()
+    with torch.no_grad():
+        rl = R.tfm_full_pass(text[:, :-1], mem, sd, "predicter.Prediction.",
+                             cfg["Prediction"]["params"]["num_decoder_layers"],
+                             cfg["Prediction"]["params"]["nhead"], key_padding=True)
+    d = maxdiff(rl, logits.detach())
+    assert d <= TOL, d
+    rep = {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed,
+           "iseed": iseed, "loss": float(loss), "diff_logits": d, "logits_sum": float(logits.double().sum()),
+           "text": text.tolist()}
+    return rep
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    summary = {"greedy": [], "beam": [], "train": []}
+    manifests = {}
+    for case in GREEDY_CASES:
+        rep, man, cname = run_greedy(case)
+        manifests[cname] = man
+        summary["greedy"].append(rep)
+        print("greedy", rep["case"], "steps", rep["steps"], "dmem", rep["diff_mem_folded"],
+              "dlogit", rep["diff_logits_cached"], "gap", rep["min_top2_gap"], f'{rep["seconds"]}s', flush=True)
+    for case in BEAM_CASES:
+        rep = run_beam(case)
+        summary["beam"].append(rep)
+        print("beam", rep["case"], rep["seq"], rep["score"], "completed", rep["completed"], flush=True)
+    for case in TRAIN_CASES:
+        rep = run_train(case)
+        summary["train"].append(rep)
+        print("train", rep["case"], rep["loss"], rep["diff_logits"], flush=True)
+    with open(os.path.join(GOLD, "cases.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+        json.dump(manifests, f)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
