@@ -1,0 +1,87 @@
+"""ctypes binding of libd2t.so (include/d2t.h).
+
+The shared library is built in-tree by doc2tex_amd/csrc/build.sh (see
+__graft_entry__.build).  There is no CPU or PyTorch fallback: if the library is
+missing or no HIP device is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libd2t.so")
+
+D2T_OK = 0
+ENC_RESNET, ENC_HYBRID_VIT = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class D2TConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "encoder", "in_channels", "backbone_out", "vit_depth", "vit_heads", "vit_dim", "patch_h", "patch_w",
+        "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len")]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+# name -> (restype, argtypes); must list every symbol include/d2t.h declares
+SIGNATURES = {
+    "d2t_create": (_I, [C.POINTER(D2TConfig), C.POINTER(_P)]),
+    "d2t_destroy": (None, [_P]),
+    "d2t_last_error": (C.c_char_p, [_P]),
+    "d2t_device_available": (_I, []),
+    "d2t_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _P]),
+    "d2t_finalize_weights": (_I, [_P, _P]),
+    "d2t_encoder_shape": (_I, [_P, _I, _I] + [C.POINTER(_I)] * 6),
+    "d2t_encode": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "d2t_decode_greedy": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, C.POINTER(_I), _P]),
+    "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
+    "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),
+    "d2t_op_linear": (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    "d2t_op_maxpool2x2": (_I, [_P, _P] + [_I] * 8 + [_P]),
+    "d2t_op_layernorm": (_I, [_P] * 4 + [_I, _I, C.c_float, _P]),
+    "d2t_op_vit_attention": (_I, [_P, _P, _I, _I, _I, _P]),
+    "d2t_op_decode_attention": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libd2t.so (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"doc2tex_amd: {LIB_PATH} is not built (run doc2tex_amd/csrc/build.sh or "
+            "__graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_device():
+    lib = load()
+    if not lib.d2t_device_available():
+        raise RuntimeError("doc2tex_amd: no HIP device visible; the engine has no CPU path")
+    return lib
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def check(rc, ctx=None, what=""):
+    if rc != D2T_OK:
+        msg = load().d2t_last_error(ctx).decode() if ctx else ""
+        raise RuntimeError(f"libd2t {what} failed (code {rc}) {msg}")

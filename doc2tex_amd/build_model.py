@@ -1,0 +1,140 @@
+"""Drop-in `Model(opt)` for doc2tex's recognizer (reference:
+doc2tex/modules/build_model.py:7-79 and doc2tex/modules/recognizers/*).
+
+Same constructor argument (the flat config dict), same attributes
+(.stages/.featextractor/.seqmodeler/.predicter), same forward signatures and
+return tuples, same state_dict key names and shapes -- but every forward runs
+in libd2t (hand-written gfx950 HIP kernels) through ctypes.  There is no CPU or
+eager-PyTorch fallback: on a machine without the built library or without a
+HIP device the forward raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import params as P
+from .engine import Engine
+
+
+class FeatExtractorBuilder(nn.Module):
+    """recognizers/build_feat.py:8-63 (parameter tree; ResNet only)."""
+
+    def __init__(self, flow, config):
+        super().__init__()
+        self.config = config
+        self.flow = flow
+        self.feat_name = flow["Feat"]
+        if self.feat_name != "None":
+            config["FeatureExtraction"]["params"].pop("mean_height", True)  # build_feat.py:16
+            if self.feat_name != "ResNet":
+                raise NotImplementedError(f"FeatureExtraction '{self.feat_name}' is not on the accelerated path")
+            self.FeatureExtraction = P.ResNetFeatureExtractorParams(**config["FeatureExtraction"]["params"])
+            self.FeatureExtraction_output = config["FeatureExtraction"]["params"]["output_channel"]
+        else:
+            if flow["Seq"] != "ViT":
+                raise Exception("No FeatureExtraction module specified")
+            self.FeatureExtraction = nn.Identity()
+
+
+class SeqModelingBuilder(nn.Module):
+    """recognizers/build_seq.py:7-40 (parameter tree; ViT hybrid or None)."""
+
+    def __init__(self, flow, config, FeatureExtraction_output):
+        super().__init__()
+        self.config = config
+        self.flow = flow
+        if flow["Seq"] == "ViT":
+            assert config["max_dimension"] is not None, \
+                "ViT encoder require exact height or max height and max width"
+            sp = config["SequenceModeling"]["params"]
+            bb = sp["backbone"]
+            backbone = P.ResNetFeatureExtractorParams(bb["input_channel"], bb["output_channel"], bb["gcb"])
+            max_dimension = ((config["imgH"], config["max_dimension"][1]) if config["imgH"]
+                             else config["max_dimension"])  # vit_encoder.py:292-294
+            ps = sp["patch_size"]
+            ps = (ps, ps) if isinstance(ps, int) else tuple(ps)
+            self.SequenceModeling = P.ViTEncoderV3Params(
+                img_size=tuple(max_dimension), patch_size=ps, in_chans=sp["input_channel"], depth=sp["depth"],
+                embed_dim=sp["hidden_size"], num_heads=sp["num_heads"], hybrid_backbone=backbone)
+        elif flow["Seq"] == "None":
+            if flow["Pred"] == "TFM":
+                self.image_positional_encoder = P.PositionalEncoding2DParams(FeatureExtraction_output)
+            self.SequenceModeling_output = FeatureExtraction_output
+        else:
+            raise NotImplementedError(f"SequenceModeling '{flow['Seq']}' is not on the accelerated path")
+
+
+class PredictBuilder(nn.Module):
+    """recognizers/build_pred.py:9-26 (parameter tree; TFM only)."""
+
+    def __init__(self, flow, config, SequenceModeling_output):
+        super().__init__()
+        self.flow = flow
+        self.config = config
+        if flow["Pred"] != "TFM":
+            raise NotImplementedError(f"Prediction '{flow['Pred']}' is not on the accelerated path")
+        config["Prediction"]["params"]["num_classes"] = config["num_class"]  # build_pred.py:16-17
+        config["Prediction"]["params"]["device"] = config["device"]
+        self.Prediction = P.TransformerPredictionParams(**config["Prediction"]["params"])
+
+
+class Model(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        stages = {
+            "Feat": opt["FeatureExtraction"]["name"],
+            "Seq": opt["SequenceModeling"]["name"],
+            "Pred": opt["Prediction"]["name"],
+        }
+        self.stages = stages
+        if stages["Seq"].__contains__("Vi"):
+            assert stages["Feat"] == "None"
+        self.featextractor = FeatExtractorBuilder(stages, opt)
+        self.seqmodeler = SeqModelingBuilder(stages, opt, getattr(self.featextractor, "FeatureExtraction_output", None))
+        self.predicter = PredictBuilder(stages, opt, getattr(self.seqmodeler, "SequenceModeling_output", None))
+        self._engine = None
+
+    # -- engine plumbing -----------------------------------------------------
+    def engine(self):
+        """The libd2t context of this model, with the current weights packed."""
+        if self._engine is None:
+            self._engine = Engine(self.opt)
+        self._engine.sync_weights(self)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if self._engine is not None:
+            self._engine._sig = None  # tensors moved: re-upload on next use
+        return out
+
+    # -- reference API -------------------------------------------------------
+    def forward_encoder(self, input, *args, **kwargs):
+        """build_model.py:36-43 -> (contextual_feature [B,T,d], output_shape, feat_pad)."""
+        memory, grid, pad = self.engine().encode(input)
+        if self.stages["Seq"] == "ViT":
+            return memory, grid, pad  # build_seq.py:59-66
+        return memory, None, None  # build_seq.py:69-76
+
+    def forward_decoder(self, contextual_feature, text, is_train=True, is_test=False, rtl_text=None):
+        """build_model.py:45-53 / build_pred.py:28-50 / tfm.py:188-195."""
+        beam_size = self.opt.get("beam_size", 1)  # read on every call, build_pred.py:31
+        eng = self.engine()
+        if self.training:
+            raise NotImplementedError(
+                "teacher-forced training pass (tfm.py:103-118) is not implemented in the HIP engine yet; "
+                "call model.eval() for greedy / beam decoding")
+        if beam_size > 1:
+            prediction, logits = eng.decode_beam(contextual_feature.contiguous(), beam_size)
+        else:
+            if text.dim() != 2 or text.shape[1] != 1:
+                raise ValueError("eval decoding expects text = [B,1] start tokens ([GO])")
+            prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
+        return prediction, logits, None, {}
+
+    def forward(self, input, text, is_train=True, is_test=False, rtl_text=None):
+        contextual_feature, output_shape, feat_pad = self.forward_encoder(input)
+        prediction, logits, decoder_attn, addition_outputs = self.forward_decoder(
+            contextual_feature, text=text, is_train=is_train, is_test=is_test, rtl_text=rtl_text)
+        # decoder_attn is always None for the TFM head (build_pred.py:34,46-49)
+        return prediction, logits, addition_outputs

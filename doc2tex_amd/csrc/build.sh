@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build libd2t.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OPT="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+for f in conv_mfma ops engine; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ kernels.h -nt $f.o ] || [ ../../include/d2t.h -nt $f.o ]; then
+    hipcc $OPT -c $f.hip -o $f.o &
+  fi
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o libd2t.so conv_mfma.o ops.o engine.o
+echo "built $(pwd)/libd2t.so"

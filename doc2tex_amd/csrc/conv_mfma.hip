@@ -1,0 +1,296 @@
+// Implicit-GEMM convolution / linear kernel on the gfx950 fp32 matrix cores.
+//
+// Replaces the reference's nn.Conv2d + BatchNorm2d(eval) + ReLU (+ residual)
+// sequences (feature_extractor/resnet.py:205-245, :32-48), the HybridEmbed patch
+// projection (seq_modeling/addon_module/patchembed.py:135) and the large-M
+// nn.Linear layers of the ViT blocks (seq_modeling/vit/vision_transformer.py:26-32,61-81).
+//
+// GEMM view: M = B*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  Activations are
+// NHWC so that for one filter tap the K-slice of a pixel is Cin contiguous floats;
+// weights are OHWI ([Cout][K], BN folded), so a K-step of both operands is one
+// 128-byte run per row.  v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD):
+// lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  The k order
+// inside a 8-wide chunk is permuted identically for A and B (lane half h takes
+// k = 4h..4h+3) so each lane fetches its four k values with one ds_read_b128.
+//
+// Block = 256 threads = 2x2 waves; block tile BM x BN x 32, register-prefetched
+// double-buffered LDS (rows padded to 36 floats: conflict-free b128 reads and
+// writes), one barrier per K-step.  Epilogue fuses bias, residual, ReLU / exact
+// GELU, positional-table add and the output row / head-split remaps.
+#include "kernels.h"
+
+namespace d2t {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;  // padded row length in floats (144 B = 9 x 16 B)
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+  constexpr int MI = WTM / 32, NJ = WTN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;  // rows each thread stages per K-step
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+  float* const As = smem;                     // [2][BM][LDS_LD]
+  float* const Bs = smem + 2 * BM * LDS_LD;   // [2][BN][LDS_LD]
+
+  // XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring
+  // pixels) run on the same XCD so they share its L2 (bijective remap).
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int logical;
+  {
+    const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  const int tid = threadIdx.x;
+  const int kq = tid & 7;     // float4 slot inside the 32-float K-step
+  const int lrow = tid >> 3;  // 0..31
+
+  // per-thread A rows: output pixel -> top-left input coordinate
+  int a_ih0[AR], a_iw0[AR], a_pix[AR];
+  const int ohow = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int b = m / ohow, rem = m - b * ohow;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      a_ih0[i] = oh * p.SH - p.PH;
+      a_iw0[i] = ow * p.SW - p.PW;
+      a_pix[i] = b * p.H * p.W;
+    } else {
+      a_ih0[i] = -0x40000000;  // never in range
+      a_iw0[i] = 0;
+      a_pix[i] = 0;
+    }
+  }
+  const float* b_ptr[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int n = n0 + lrow + 32 * i;
+    b_ok[i] = n < p.Cout;
+    b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.K + kq * 4;
+  }
+
+  float4 ra[AR], rb[BR];
+  int kh = 0, kw = 0, c0 = 0;  // position of the NEXT K-step to fetch
+  const int KT = p.K / BK;
+
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+      if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+        const float* src = p.in + (size_t)(a_pix[i] + ih * p.W + iw) * p.Cin + c0 + kq * 4;
+        ra[i] = *reinterpret_cast<const float4*>(src);
+      } else {
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + (size_t)kt * BK)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    c0 += BK;
+    if (c0 == p.Cin) {
+      c0 = 0;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto stage = [&](int buf) {
+    float* a = As + buf * BM * LDS_LD;
+    float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDS_LD + kq * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDS_LD + kq * 4) = rb[i];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) fetch(kt + 1);  // global loads in flight under the MFMAs
+    const float* a = As + cur * BM * LDS_LD + (wm * WTM + r) * LDS_LD + h * 4;
+    const float* b = Bs + cur * BN * LDS_LD + (wn * WTN + r) * LDS_LD + h * 4;
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      float4 fa[MI], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const float4*>(a + i * 32 * LDS_LD + kc * 8);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + kc * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < KT) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D map: col = lane&31 -> n, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> m
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + r;
+    if (n >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    int slab = 0, head = 0, e = 0;
+    if (p.store_mode == STORE_KV) {
+      const int d = p.kv_heads * p.kv_hd;
+      slab = n / d;
+      const int within = n - slab * d;
+      head = within / p.kv_hd;
+      e = within - head * p.kv_hd;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][reg] + bias;
+        if (p.store_mode == STORE_KV) {
+          const int bb = m / p.kv_T, jj = m - bb * p.kv_T;
+          p.out[((((size_t)slab * p.kv_B + bb) * p.kv_heads + head) * p.kv_T + jj) * p.kv_hd + e] = v;
+          continue;
+        }
+        size_t row = (size_t)m;
+        int in_img = 0;
+        if (p.rows_per_img > 0) {
+          const int img = m / p.rows_per_img;
+          in_img = m - img * p.rows_per_img;
+          row = (size_t)img * p.img_stride + p.row_off + in_img;
+        }
+        const size_t off = row * p.Cout + n;
+        if (p.res) v += p.res[off];
+        v = apply_act(v, p.act);
+        if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
+        p.out[off] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
+  const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN>), dim3(mt * nt), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvP& p, hipStream_t s) {
+  if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
+  if (p.Cin % BK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
+  const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+  if (p.Cout <= 64) {
+    if ((long long)((p.M + 127) / 128) >= 256) return launch_cfg<128, 64>(p, s);
+    return launch_cfg<64, 64>(p, s);
+  }
+  if (tiles128 >= 256) return launch_cfg<128, 128>(p, s);
+  return launch_cfg<64, 64>(p, s);
+}
+
+// ---------------------------------------------------------------------------
+// Skinny GEMM (decode steps, M <= 64 per block row): weights streamed from L2
+// straight into registers, v_mfma_f32_16x16x4_f32, block tile 64 x 16.
+// Replaces the per-step nn.Linear / in_proj calls of nn.TransformerDecoderLayer
+// (prediction_head/tfm.py:130-133).
+// ---------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int m = blockIdx.y * 64 + wave * 16 + r;  // A row this lane loads
+  const int n = blockIdx.x * 16 + r;              // B (weight) row this lane loads
+  const bool mok = m < p.M, nok = n < p.N;
+  const float* xa = p.x + (size_t)(mok ? m : 0) * p.ldx + q * 4;
+  const float* wb = p.w + (size_t)(nok ? n : 0) * p.K + q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int KC = p.K >> 4;
+  int c = 0;
+  for (; c + 4 <= KC; c += 4) {  // 4 chunks (8 x 16-B loads) in flight per lane
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const float4*>(xa + (c + u) * 16);
+      b[u] = *reinterpret_cast<const float4*>(wb + (c + u) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!mok) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!nok) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+  for (; c < KC; ++c) {
+    float4 a = *reinterpret_cast<const float4*>(xa + c * 16);
+    float4 b = *reinterpret_cast<const float4*>(wb + c * 16);
+    if (!mok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  // C/D map: col = lane&15 -> n, row = (lane>>4)*4 + reg -> m
+  const int nn = blockIdx.x * 16 + r;
+  if (nn >= p.N) return;
+  float* y = p.y;
+  if (p.step_ptr) y += (long long)(*p.step_ptr) * p.out_step_stride;
+  const float bias = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int mm = blockIdx.y * 64 + wave * 16 + q * 4 + reg;
+    if (mm >= p.M) continue;
+    float v = acc[reg] + bias;
+    if (p.res) v += p.res[(size_t)mm * p.ldres + nn];
+    y[(size_t)mm * p.ldy + nn] = apply_act(v, p.act);
+  }
+}
+
+hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if (p.K % 16 != 0 || p.ldx % 4 != 0) return hipErrorInvalidValue;
+  dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
+  hipLaunchKernelGGL(skinny_gemm_kernel, grid, dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace d2t

@@ -1,0 +1,839 @@
+// libd2t engine: context, weight packing, encoder / decoder orchestration and
+// the C-ABI declared in include/d2t.h.  Host code only launches the kernels of
+// conv_mfma.hip / ops.hip on the caller's HIP stream; there is no CPU compute
+// path and no fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/d2t.h"
+#include "kernels.h"
+
+using namespace d2t;
+
+namespace {
+
+constexpr int TOK_PAD = 0, TOK_GO = 1, TOK_END = 2;  // converter/tfm_converter.py:8
+const int RESNET_LAYERS[4] = {1, 2, 5, 3};           // feature_extractor/resnet.py:262
+
+struct RawW {
+  float* p = nullptr;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+};
+struct ConvW {
+  float* w = nullptr;
+  float* bias = nullptr;
+  int Cout = 0, Cin = 0, KH = 0, KW = 0;
+};
+struct LinW {
+  const float* w = nullptr;
+  const float* b = nullptr;
+  int N = 0, K = 0;
+};
+struct LNW {
+  const float* g = nullptr;
+  const float* b = nullptr;
+};
+struct VitBlock {
+  LNW n1, n2;
+  LinW qkv, proj, fc1, fc2;
+};
+struct DecLayer {
+  LinW sa_in, sa_out, ca_q, ca_out, l1, l2;
+  LNW n1, n2, n3;
+};
+struct Block {
+  ConvW c1, c2, down;
+  bool has_down = false;
+};
+struct Act {
+  float* p;
+  int B, H, W, C;
+  size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+}  // namespace
+
+struct d2t_ctx {
+  d2t_config cfg;
+  std::string err;
+  std::map<std::string, RawW> raw;
+  std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
+  bool finalized = false;
+
+  // packed weights
+  std::string bb;  // backbone key prefix ("...ConvNet.")
+  ConvW stem, conv0_2, conv1, conv2, conv3, conv4_1, conv4_2, patch;
+  std::vector<Block> layers[4];
+  const float* pos_embed = nullptr;  // [1+gh*gw][dim]
+  int pos_rows = 0;
+  float* cls_row = nullptr;  // cls_token + pos_embed[0]
+  std::vector<VitBlock> vit;
+  LNW vit_norm;
+  const float* word_embed = nullptr;
+  const float* word_pe = nullptr;
+  int word_pe_rows = 0;
+  std::vector<DecLayer> dec;
+  float* ckv_w = nullptr;  // [layers*2*d][d] cross-attention K,V projections of every layer
+  float* ckv_b = nullptr;
+  LinW out_proj;
+
+  // workspace
+  float* act[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t act_cap = 0;
+  std::map<std::pair<int, int>, float*> pe2d;  // PositionalEncoding2D crops [h*w][C]
+  // decoder state
+  float* ckv = nullptr; size_t ckv_cap = 0;
+  float* skv = nullptr; size_t skv_cap = 0;
+  float* dws = nullptr; size_t dws_cap = 0;
+  int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]
+  size_t dstate_cap = 0;
+  int* h_pinned = nullptr;
+  hipStream_t dstream = nullptr;
+  hipEvent_t ev_in = nullptr;
+  hipGraphExec_t graph = nullptr;
+  struct GraphKey { int B, T; const void* tok; const void* logits; const void* start; const void* mem; } gkey{};
+};
+
+namespace {
+
+int fail(d2t_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+int dev_alloc(d2t_ctx* c, void** p, size_t bytes) {
+  if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return fail(c, D2T_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  return D2T_OK;
+}
+// grow-only buffer; growing synchronises the device (never during graph capture)
+template <typename T>
+int ensure(d2t_ctx* c, T** p, size_t* cap, size_t bytes) {
+  if (*cap >= bytes && *p) return D2T_OK;
+  if (*p) { hipDeviceSynchronize(); hipFree(*p); *p = nullptr; }
+  int rc = dev_alloc(c, reinterpret_cast<void**>(p), bytes);
+  if (rc) return rc;
+  *cap = bytes;
+  return D2T_OK;
+}
+
+const RawW* find(d2t_ctx* c, const std::string& k) {
+  auto it = c->raw.find(k);
+  return it == c->raw.end() ? nullptr : &it->second;
+}
+int need(d2t_ctx* c, const std::string& k, const RawW** out, std::vector<int64_t> shape = {}) {
+  const RawW* r = find(c, k);
+  if (!r) return fail(c, D2T_ESTATE, "missing weight '%s'", k.c_str());
+  if (!shape.empty() && r->shape != shape) {
+    std::string s;
+    for (auto v : r->shape) s += std::to_string(v) + ",";
+    return fail(c, D2T_EINVAL, "weight '%s' has shape [%s]", k.c_str(), s.c_str());
+  }
+  *out = r;
+  return D2T_OK;
+}
+
+int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW* out, hipStream_t s) {
+  const RawW *w, *g = nullptr, *b = nullptr, *mu = nullptr, *var = nullptr;
+  int rc = need(c, conv + ".weight", &w);
+  if (rc) return rc;
+  if (w->shape.size() != 4) return fail(c, D2T_EINVAL, "conv weight '%s' is not 4-D", conv.c_str());
+  const RawW* cb = find(c, conv + ".bias");
+  if (!bn.empty()) {
+    if ((rc = need(c, bn + ".weight", &g)) || (rc = need(c, bn + ".bias", &b)) ||
+        (rc = need(c, bn + ".running_mean", &mu)) || (rc = need(c, bn + ".running_var", &var)))
+      return rc;
+  }
+  out->Cout = (int)w->shape[0]; out->Cin = (int)w->shape[1]; out->KH = (int)w->shape[2]; out->KW = (int)w->shape[3];
+  void *pw, *pb;
+  if ((rc = dev_alloc(c, &pw, w->numel * 4)) || (rc = dev_alloc(c, &pb, (size_t)out->Cout * 4))) return rc;
+  c->owned.push_back(pw);
+  c->owned.push_back(pb);
+  out->w = (float*)pw;
+  out->bias = (float*)pb;
+  HIPCHK(c, launch_pack_conv(w->p, cb ? cb->p : nullptr, g ? g->p : nullptr, b ? b->p : nullptr, mu ? mu->p : nullptr,
+                             var ? var->p : nullptr, 1e-5f, out->w, out->bias, out->Cout, out->Cin, out->KH, out->KW,
+                             s));
+  return D2T_OK;
+}
+int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K) {
+  const RawW *w, *b;
+  int rc;
+  if ((rc = need(c, k + ".weight", &w, {N, K})) || (rc = need(c, k + ".bias", &b, {N}))) return rc;
+  *out = LinW{w->p, b->p, N, K};
+  return D2T_OK;
+}
+int get_ln(d2t_ctx* c, const std::string& k, LNW* out, int D) {
+  const RawW *g, *b;
+  int rc;
+  if ((rc = need(c, k + ".weight", &g, {D})) || (rc = need(c, k + ".bias", &b, {D}))) return rc;
+  *out = LNW{g->p, b->p};
+  return D2T_OK;
+}
+
+void free_packed(d2t_ctx* c) {
+  for (void* p : c->owned) hipFree(p);
+  c->owned.clear();
+  for (int i = 0; i < 4; ++i) c->layers[i].clear();
+  c->vit.clear();
+  c->dec.clear();
+  c->finalized = false;
+}
+
+// spatial size after the backbone (resnet.py:205-245) for an H x W crop
+void backbone_hw(int H, int W, int* oh, int* ow) {
+  int h = H / 2, w = W / 2;          // maxpool1
+  h /= 2; w /= 2;                    // maxpool2
+  h = (h - 2) / 2 + 1; w = w + 1;    // maxpool3 k2 s(2,1) p(0,1)
+  h = (h - 2) / 2 + 1; w = w + 1;    // conv4_1  k2 s(2,1) p(0,1)
+  *oh = h - 1; *ow = w - 1;          // conv4_2  k2 s1 p0
+}
+
+Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& w, int sh, int sw, int ph, int pw,
+         int act, const float* res, float* outbuf, const ConvP* extra = nullptr) {
+  Act y{outbuf, x.B, (x.H + 2 * ph - w.KH) / sh + 1, (x.W + 2 * pw - w.KW) / sw + 1, w.Cout};
+  ConvP p{};
+  if (extra) p = *extra;
+  p.in = x.p; p.w = w.w; p.bias = w.bias; p.res = res; p.out = outbuf;
+  p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
+  p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
+  p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
+  hipError_t e = launch_conv(p, s);
+  if (e != hipSuccess && *err == hipSuccess) *err = e;
+  return y;
+}
+
+hipError_t linear_big(hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M, int act) {
+  ConvP p{};
+  p.in = x; p.w = w.w; p.bias = w.b; p.res = res; p.out = y;
+  p.B = 1; p.H = 1; p.W = M; p.Cin = w.K; p.OH = 1; p.OW = M; p.Cout = w.N;
+  p.KH = p.KW = p.SH = p.SW = 1; p.PH = p.PW = 0; p.M = M; p.K = w.K; p.act = act;
+  return launch_conv(p, s);
+}
+
+hipError_t linear_any(hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M, int act) {
+  if (M > 64 && w.K % 32 == 0) return linear_big(s, x, w, res, y, M, act);
+  SkinnyP p{};
+  p.x = x; p.w = w.w; p.bias = w.b; p.res = res; p.y = y;
+  p.M = M; p.K = w.K; p.N = w.N; p.ldx = w.K; p.ldy = w.N; p.ldres = w.N; p.act = act;
+  return launch_skinny(p, s);
+}
+
+// pick a rotating activation buffer that is not in `live`
+float* pick(d2t_ctx* c, std::initializer_list<const float*> live) {
+  for (int i = 0; i < 4; ++i) {
+    bool used = false;
+    for (const float* l : live) used |= (l == c->act[i]);
+    if (!used) return c->act[i];
+  }
+  return nullptr;
+}
+
+int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int W, Act* out, float* final_out,
+                 const ConvP* final_extra) {
+  hipError_t err = hipSuccess;
+  Act x{pick(c, {}), B, H, W, c->stem.Cout};
+  HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
+  x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
+    Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
+    hipError_t e = launch_maxpool(a.p, y.p, a.B, a.H, a.W, a.C, sh, sw, ph, pw, s);
+    if (e != hipSuccess && err == hipSuccess) err = e;
+    return y;
+  };
+  auto stage = [&](int li) {
+    for (const Block& b : c->layers[li]) {
+      Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      const float* res = x.p;
+      if (b.has_down) {
+        Act r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}));
+        res = r.p;
+      }
+      x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, res, pick(c, {x.p, t.p, res}));
+    }
+  };
+  x = pool(x, 2, 2, 0, 0);
+  stage(0);
+  x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = pool(x, 2, 2, 0, 0);
+  stage(1);
+  x = conv(c, s, &err, x, c->conv2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = pool(x, 2, 1, 0, 1);
+  stage(2);
+  x = conv(c, s, &err, x, c->conv3, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  stage(3);
+  x = conv(c, s, &err, x, c->conv4_1, 2, 1, 0, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = conv(c, s, &err, x, c->conv4_2, 1, 1, 0, 0, ACT_RELU, nullptr, final_out ? final_out : pick(c, {x.p}),
+           final_extra);
+  if (err != hipSuccess) return fail(c, D2T_EHIP, "backbone launch: %s", hipGetErrorString(err));
+  *out = x;
+  return D2T_OK;
+}
+
+// PositionalEncoding2D crop [h][w][C] (common/postional_encoding.py:105-134,146-157)
+int get_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) {
+  auto key = std::make_pair(h, w);
+  auto it = c->pe2d.find(key);
+  if (it != c->pe2d.end()) { *out = it->second; return D2T_OK; }
+  const int half = C / 2;
+  std::vector<float> div(half / 2);
+  for (int i = 0; i < half / 2; ++i) div[i] = expf((float)(2 * i) * (float)(-std::log(10000.0) / (double)half));
+  std::vector<float> host((size_t)h * w * C);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      float* o = host.data() + ((size_t)y * w + x) * C;
+      for (int i = 0; i < half / 2; ++i) {
+        o[2 * i] = sinf((float)y * div[i]);
+        o[2 * i + 1] = cosf((float)y * div[i]);
+        o[half + 2 * i] = sinf((float)x * div[i]);
+        o[half + 2 * i + 1] = cosf((float)x * div[i]);
+      }
+    }
+  void* d;
+  int rc = dev_alloc(c, &d, host.size() * 4);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(d, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+  c->pe2d[key] = (float*)d;
+  *out = (float*)d;
+  return D2T_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+extern "C" {
+
+int d2t_device_available(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
+  if (!cfg || !out) return D2T_EINVAL;
+  *out = nullptr;
+  d2t_ctx* c = new d2t_ctx();
+  c->cfg = *cfg;
+  *out = c;  // returned even on error so that d2t_last_error works; caller destroys it
+  if (cfg->in_channels != 1) return fail(c, D2T_EINVAL, "in_channels must be 1 (grey crops)");
+  if (cfg->backbone_out != 512) return fail(c, D2T_EINVAL, "backbone output_channel must be 512");
+  if (cfg->encoder == D2T_ENC_HYBRID_VIT) {
+    if (cfg->vit_dim != 256 && cfg->vit_dim != 512) return fail(c, D2T_EINVAL, "ViT hidden_size must be 256 or 512");
+    if (cfg->vit_dim / cfg->vit_heads != 32) return fail(c, D2T_EINVAL, "ViT head_dim must be 32");
+    if (cfg->patch_h < 1 || cfg->patch_w < 1) return fail(c, D2T_EINVAL, "bad patch size");
+  } else if (cfg->encoder != D2T_ENC_RESNET) {
+    return fail(c, D2T_EINVAL, "unknown encoder %d", cfg->encoder);
+  }
+  const int hd = cfg->dec_heads > 0 ? cfg->dec_dim / cfg->dec_heads : 0;
+  if (cfg->dec_dim != 256 && cfg->dec_dim != 512) return fail(c, D2T_EINVAL, "decoder d_model must be 256 or 512");
+  if (hd != 32 && hd != 64) return fail(c, D2T_EINVAL, "decoder head_dim must be 32 or 64");
+  if (cfg->dec_ff % 64) return fail(c, D2T_EINVAL, "dim_feedforward must be a multiple of 64");
+  if (cfg->max_seq_len + 2 > 512) return fail(c, D2T_EINVAL, "max_seq_len must be <= 510");
+  if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
+  HIPCHK(c, hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault));
+  return D2T_OK;
+}
+
+void d2t_destroy(d2t_ctx* c) {
+  if (!c) return;
+  hipDeviceSynchronize();
+  if (c->graph) hipGraphExecDestroy(c->graph);
+  free_packed(c);
+  for (auto& kv : c->raw) hipFree(kv.second.p);
+  for (auto& kv : c->pe2d) hipFree(kv.second);
+  for (int i = 0; i < 4; ++i) if (c->act[i]) hipFree(c->act[i]);
+  if (c->ckv) hipFree(c->ckv);
+  if (c->skv) hipFree(c->skv);
+  if (c->dws) hipFree(c->dws);
+  if (c->dstate) hipFree(c->dstate);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->ev_in) hipEventDestroy(c->ev_in);
+  if (c->dstream) hipStreamDestroy(c->dstream);
+  delete c;
+}
+
+const char* d2t_last_error(const d2t_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int d2t_load_weight(d2t_ctx* c, const char* name, const float* dev, const int64_t* shape, int32_t ndim,
+                    d2t_stream stream) {
+  if (!c || !name || !dev || ndim < 0 || (ndim > 0 && !shape)) return fail(c, D2T_EINVAL, "bad argument");
+  size_t n = 1;
+  std::vector<int64_t> shp(shape, shape + ndim);
+  for (auto v : shp) n *= (size_t)v;
+  RawW& r = c->raw[name];
+  if (r.p && r.numel != n) { hipDeviceSynchronize(); hipFree(r.p); r.p = nullptr; }
+  if (!r.p) {
+    void* p;
+    int rc = dev_alloc(c, &p, n * 4);
+    if (rc) return rc;
+    r.p = (float*)p;
+  }
+  r.shape = shp;
+  r.numel = n;
+  HIPCHK(c, hipMemcpyAsync(r.p, dev, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return D2T_OK;
+}
+
+int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
+  if (!c) return D2T_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipDeviceSynchronize();
+  if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+  free_packed(c);
+  const d2t_config& g = c->cfg;
+  int rc;
+  const bool vit = g.encoder == D2T_ENC_HYBRID_VIT;
+  const std::string sm = "seqmodeler.SequenceModeling.";
+  c->bb = vit ? sm + "patch_embed.backbone.ConvNet." : "featextractor.FeatureExtraction.ConvNet.";
+  const std::string& bb = c->bb;
+  if ((rc = pack_conv(c, bb + "conv0_1", bb + "bn0_1", &c->stem, s))) return rc;
+  if (c->stem.Cin != 1 || c->stem.KH != 3 || c->stem.KW != 3)
+    return fail(c, D2T_EINVAL, "conv0_1 must be 1-channel 3x3");
+  if ((rc = pack_conv(c, bb + "conv0_2", bb + "bn0_2", &c->conv0_2, s))) return rc;
+  for (int li = 0; li < 4; ++li) {
+    for (int bi = 0; bi < RESNET_LAYERS[li]; ++bi) {
+      const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      Block b;
+      if ((rc = pack_conv(c, p + ".conv1", p + ".bn1", &b.c1, s))) return rc;
+      if ((rc = pack_conv(c, p + ".conv2", p + ".bn2", &b.c2, s))) return rc;
+      if (find(c, p + ".downsample.0.weight")) {
+        b.has_down = true;
+        if ((rc = pack_conv(c, p + ".downsample.0", p + ".downsample.1", &b.down, s))) return rc;
+      }
+      c->layers[li].push_back(b);
+    }
+  }
+  if ((rc = pack_conv(c, bb + "conv1", bb + "bn1", &c->conv1, s))) return rc;
+  if ((rc = pack_conv(c, bb + "conv2", bb + "bn2", &c->conv2, s))) return rc;
+  if ((rc = pack_conv(c, bb + "conv3", bb + "bn3", &c->conv3, s))) return rc;
+  if ((rc = pack_conv(c, bb + "conv4_1", bb + "bn4_1", &c->conv4_1, s))) return rc;
+  if ((rc = pack_conv(c, bb + "conv4_2", bb + "bn4_2", &c->conv4_2, s))) return rc;
+
+  if (vit) {
+    const int D = g.vit_dim;
+    if ((rc = pack_conv(c, sm + "patch_embed.proj", "", &c->patch, s))) return rc;
+    if (c->patch.Cout != D || c->patch.KH != g.patch_h || c->patch.KW != g.patch_w)
+      return fail(c, D2T_EINVAL, "patch_embed.proj shape does not match the config");
+    const RawW *pos, *cls;
+    if ((rc = need(c, sm + "pos_embed", &pos)) || (rc = need(c, sm + "cls_token", &cls, {1, 1, D}))) return rc;
+    if (pos->shape.size() != 3 || pos->shape[2] != D) return fail(c, D2T_EINVAL, "pos_embed must be [1,N,%d]", D);
+    c->pos_embed = pos->p;
+    c->pos_rows = (int)pos->shape[1];
+    void* p;
+    if ((rc = dev_alloc(c, &p, (size_t)D * 4))) return rc;
+    c->owned.push_back(p);
+    c->cls_row = (float*)p;
+    HIPCHK(c, launch_add_rows(cls->p, pos->p, c->cls_row, D, s));
+    for (int i = 0; i < g.vit_depth; ++i) {
+      const std::string b = sm + "blocks." + std::to_string(i) + ".";
+      VitBlock vb;
+      if ((rc = get_ln(c, b + "norm1", &vb.n1, D)) || (rc = get_ln(c, b + "norm2", &vb.n2, D)) ||
+          (rc = get_lin(c, b + "attn.qkv", &vb.qkv, 3 * D, D)) || (rc = get_lin(c, b + "attn.proj", &vb.proj, D, D)))
+        return rc;
+      const RawW* f1;
+      if ((rc = need(c, b + "mlp.fc1.weight", &f1))) return rc;
+      const int hid = (int)f1->shape[0];
+      if ((rc = get_lin(c, b + "mlp.fc1", &vb.fc1, hid, D)) || (rc = get_lin(c, b + "mlp.fc2", &vb.fc2, D, hid)))
+        return rc;
+      c->vit.push_back(vb);
+    }
+    if ((rc = get_ln(c, sm + "norm", &c->vit_norm, D))) return rc;
+    if (g.dec_dim != D) return fail(c, D2T_EINVAL, "decoder d_model must equal the ViT hidden_size");
+  } else if (g.dec_dim != c->conv4_2.Cout) {
+    return fail(c, D2T_EINVAL, "decoder d_model must equal the backbone output_channel");
+  }
+
+  // decoder (prediction_head/tfm.py:36-72)
+  const std::string pp = "predicter.Prediction.";
+  const int d = g.dec_dim, V = g.vocab;
+  const RawW *we, *pe;
+  if ((rc = need(c, pp + "word_embed.weight", &we, {V, d})) || (rc = need(c, pp + "pos_enc.pe", &pe))) return rc;
+  if (pe->shape.size() != 2 || pe->shape[1] != d || pe->shape[0] < g.max_seq_len + 2)
+    return fail(c, D2T_EINVAL, "pos_enc.pe must be [>=%d,%d]", g.max_seq_len + 2, d);
+  c->word_embed = we->p;
+  c->word_pe = pe->p;
+  c->word_pe_rows = (int)pe->shape[0];
+  void *kw, *kb;
+  if ((rc = dev_alloc(c, &kw, (size_t)g.dec_layers * 2 * d * d * 4)) ||
+      (rc = dev_alloc(c, &kb, (size_t)g.dec_layers * 2 * d * 4)))
+    return rc;
+  c->owned.push_back(kw);
+  c->owned.push_back(kb);
+  c->ckv_w = (float*)kw;
+  c->ckv_b = (float*)kb;
+  for (int i = 0; i < g.dec_layers; ++i) {
+    const std::string l = pp + "model.layers." + std::to_string(i) + ".";
+    DecLayer dl;
+    const RawW *siw, *sib, *ciw, *cib;
+    if ((rc = need(c, l + "self_attn.in_proj_weight", &siw, {3 * d, d})) ||
+        (rc = need(c, l + "self_attn.in_proj_bias", &sib, {3 * d})) ||
+        (rc = need(c, l + "multihead_attn.in_proj_weight", &ciw, {3 * d, d})) ||
+        (rc = need(c, l + "multihead_attn.in_proj_bias", &cib, {3 * d})))
+      return rc;
+    dl.sa_in = LinW{siw->p, sib->p, 3 * d, d};
+    dl.ca_q = LinW{ciw->p, cib->p, d, d};
+    HIPCHK(c, launch_copy(ciw->p + (size_t)d * d, c->ckv_w + (size_t)i * 2 * d * d, (size_t)2 * d * d, s));
+    HIPCHK(c, launch_copy(cib->p + d, c->ckv_b + (size_t)i * 2 * d, (size_t)2 * d, s));
+    if ((rc = get_lin(c, l + "self_attn.out_proj", &dl.sa_out, d, d)) ||
+        (rc = get_lin(c, l + "multihead_attn.out_proj", &dl.ca_out, d, d)) ||
+        (rc = get_lin(c, l + "linear1", &dl.l1, g.dec_ff, d)) || (rc = get_lin(c, l + "linear2", &dl.l2, d, g.dec_ff)) ||
+        (rc = get_ln(c, l + "norm1", &dl.n1, d)) || (rc = get_ln(c, l + "norm2", &dl.n2, d)) ||
+        (rc = get_ln(c, l + "norm3", &dl.n3, d)))
+      return rc;
+    c->dec.push_back(dl);
+  }
+  if ((rc = get_lin(c, pp + "proj", &c->out_proj, V, d))) return rc;
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->finalized = true;
+  return D2T_OK;
+}
+
+int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_t* d, int32_t* grid_h,
+                      int32_t* grid_w, int32_t* pad_w, int32_t* pad_h) {
+  if (!c) return D2T_EINVAL;
+  if (H < 4 || W < 4) return D2T_EINVAL;
+  int fh, fw;
+  backbone_hw(H, W, &fh, &fw);
+  if (fh < 1 || fw < 1) return D2T_EINVAL;
+  int gh = fh, gw = fw, pw = 0, ph = 0, t, dim = c->cfg.backbone_out;
+  if (c->cfg.encoder == D2T_ENC_HYBRID_VIT) {
+    ph = (c->cfg.patch_h - fh % c->cfg.patch_h) % c->cfg.patch_h;
+    pw = (c->cfg.patch_w - fw % c->cfg.patch_w) % c->cfg.patch_w;
+    gh = (fh + ph) / c->cfg.patch_h;
+    gw = (fw + pw) / c->cfg.patch_w;
+    t = gh * gw + 1;
+    dim = c->cfg.vit_dim;
+  } else {
+    t = fh * fw;
+  }
+  if (T) *T = t;
+  if (d) *d = dim;
+  if (grid_h) *grid_h = gh;
+  if (grid_w) *grid_w = gw;
+  if (pad_w) *pad_w = pw;
+  if (pad_h) *pad_h = ph;
+  return D2T_OK;
+}
+
+int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, float* memory, d2t_stream stream) {
+  if (!c || !image || !memory || B < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  hipStream_t s = (hipStream_t)stream;
+  const d2t_config& g = c->cfg;
+  int T, dim, gh, gw, pw, ph;
+  if (d2t_encoder_shape(c, H, W, &T, &dim, &gh, &gw, &pw, &ph))
+    return fail(c, D2T_EINVAL, "unsupported crop %dx%d (backbone output would be empty)", H, W);
+  const bool vit = g.encoder == D2T_ENC_HYBRID_VIT;
+  if (vit && T > c->pos_rows) return fail(c, D2T_EINVAL, "crop %dx%d exceeds max_dimension (pos_embed rows %d)", H, W, c->pos_rows);
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  // largest activation: conv0_2 output B*H*W*64 floats; ViT needs B*T*max(3*dim, hidden)
+  size_t need_floats = (size_t)B * H * W * 64;
+  if (vit) {
+    size_t hid = c->vit.empty() ? 0 : (size_t)c->vit[0].fc1.N;
+    size_t v = (size_t)B * T * (hid > 3 * (size_t)dim ? hid : 3 * (size_t)dim);
+    if (v > need_floats) need_floats = v;
+  }
+  if (c->act_cap < need_floats * 4) {
+    hipDeviceSynchronize();
+    for (int i = 0; i < 4; ++i) {
+      if (c->act[i]) hipFree(c->act[i]);
+      c->act[i] = nullptr;
+      void* p;
+      int rc = dev_alloc(c, &p, need_floats * 4);
+      if (rc) { c->act_cap = 0; return rc; }
+      c->act[i] = (float*)p;
+    }
+    c->act_cap = need_floats * 4;
+  }
+  Act f{};
+  int rc;
+  if (!vit) {
+    // Feat=ResNet, Seq=None: PositionalEncoding2D add, [B,C,H,W] -> [B,HW,C] (build_seq.py:69-76)
+    int fh, fw;
+    backbone_hw(H, W, &fh, &fw);
+    const float* pe;
+    if ((rc = get_pe2d(c, fh, fw, g.backbone_out, s, &pe))) return rc;
+    ConvP ex{};
+    ex.row_add = pe; ex.rows_per_img = fh * fw; ex.img_stride = fh * fw; ex.row_off = 0; ex.row_add_off = 0;
+    return run_backbone(c, s, image, B, H, W, &f, memory, &ex);
+  }
+  if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr))) return rc;
+  // HybridEmbed.forward (patchembed.py:115-141): zero-pad right/bottom + Conv2d(k=s=patch) as one
+  // implicit GEMM whose out-of-range taps read zero; epilogue adds pos_embed[1+i] (flat prefix
+  // slice, vit_encoder.py:260) and leaves row 0 of every image for the cls token.
+  hipError_t err = hipSuccess;
+  float* X = pick(c, {f.p});
+  {
+    Act y{X, f.B, gh, gw, dim};
+    ConvP p{};
+    p.in = f.p; p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
+    p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
+    p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
+    p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
+    p.row_add = c->pos_embed; p.rows_per_img = gh * gw; p.img_stride = T; p.row_off = 1; p.row_add_off = 1;
+    HIPCHK(c, launch_conv(p, s));
+    HIPCHK(c, launch_fill_cls(c->cls_row, X, B, (long long)T * dim, dim, s));
+  }
+  const int M = B * T;
+  float* Hn = pick(c, {X});
+  float* Q = pick(c, {X, Hn});
+  float* X2 = pick(c, {X, Hn, Q});
+  for (const VitBlock& vb : c->vit) {
+    // Block.forward (vision_transformer.py:119-122), LayerNorm eps 1e-6 (:175)
+    HIPCHK(c, launch_layernorm(X, vb.n1.g, vb.n1.b, Hn, M, dim, 1e-6f, s));
+    HIPCHK(c, linear_any(s, Hn, vb.qkv, nullptr, Q, M, ACT_NONE));
+    HIPCHK(c, launch_vit_attention(Q, Hn, B, T, g.vit_heads, s));
+    HIPCHK(c, linear_any(s, Hn, vb.proj, X, X2, M, ACT_NONE));
+    HIPCHK(c, launch_layernorm(X2, vb.n2.g, vb.n2.b, Hn, M, dim, 1e-6f, s));
+    HIPCHK(c, linear_any(s, Hn, vb.fc1, nullptr, Q, M, ACT_GELU));
+    HIPCHK(c, linear_any(s, Q, vb.fc2, X2, X, M, ACT_NONE));
+  }
+  HIPCHK(c, launch_layernorm(X, c->vit_norm.g, c->vit_norm.b, memory, M, dim, 1e-6f, s));
+  (void)err;
+  return D2T_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------
+namespace {
+struct DecBufs {
+  float *x, *y, *x1, *x2, *qkv, *q2, *a, *f;
+};
+
+int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
+  const d2t_config& g = c->cfg;
+  const int d = g.dec_dim, Lmax = g.max_seq_len + 2;
+  int rc;
+  if ((rc = ensure(c, &c->ckv, &c->ckv_cap, (size_t)g.dec_layers * 2 * B * T * d * 4))) return rc;
+  if ((rc = ensure(c, &c->skv, &c->skv_cap, (size_t)g.dec_layers * 2 * B * Lmax * d * 4))) return rc;
+  const size_t per = (size_t)B * (5 * d + 3 * d + d + g.dec_ff);
+  if ((rc = ensure(c, &c->dws, &c->dws_cap, per * 4))) return rc;
+  if ((rc = ensure(c, &c->dstate, &c->dstate_cap, (size_t)(4 + B) * 4))) return rc;
+  float* p = c->dws;
+  bufs->x = p; p += (size_t)B * d;
+  bufs->y = p; p += (size_t)B * d;
+  bufs->x1 = p; p += (size_t)B * d;
+  bufs->x2 = p; p += (size_t)B * d;
+  bufs->q2 = p; p += (size_t)B * d;
+  bufs->qkv = p; p += (size_t)B * 3 * d;
+  bufs->a = p; p += (size_t)B * d;
+  bufs->f = p;
+  return D2T_OK;
+}
+
+hipError_t skinny(hipStream_t s, const float* x, int ldx, const LinW& w, const float* res, float* y, int ldy, int M,
+                  int act, const int* step_ptr = nullptr, long long step_stride = 0) {
+  SkinnyP p{};
+  p.x = x; p.w = w.w; p.bias = w.b; p.res = res; p.y = y;
+  p.M = M; p.K = w.K; p.N = w.N; p.ldx = ldx; p.ldy = ldy; p.ldres = w.N; p.act = act;
+  p.step_ptr = step_ptr; p.out_step_stride = step_stride;
+  return launch_skinny(p, s);
+}
+
+// cross-attention K,V of every layer, once per batch: [layers*2][B][heads][T][hd]
+hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T) {
+  const d2t_config& g = c->cfg;
+  const int d = g.dec_dim;
+  ConvP p{};
+  p.in = memory; p.w = c->ckv_w; p.bias = c->ckv_b; p.out = c->ckv;
+  p.B = 1; p.H = 1; p.W = B * T; p.Cin = d; p.OH = 1; p.OW = B * T; p.Cout = g.dec_layers * 2 * d;
+  p.KH = p.KW = p.SH = p.SW = 1; p.M = B * T; p.K = d; p.act = ACT_NONE;
+  p.store_mode = STORE_KV; p.kv_T = T; p.kv_heads = g.dec_heads; p.kv_hd = d / g.dec_heads; p.kv_B = B;
+  return launch_conv(p, s);
+}
+
+// one decode step for M rows (greedy: M = B).  All position-dependent values are
+// read from the device step counter so the launch sequence is graph-replayable.
+// shared_mem: cross K/V of sample 0 shared by every row (beam search, one sample).
+hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
+                       const int64_t* start, int64_t* tokens, int tok_stride, float* logits, long long logit_row_stride,
+                       long long logit_step_stride) {
+  const d2t_config& g = c->cfg;
+  const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
+  const int* step = c->dstate;
+  hipError_t e;
+#define TRY(x) if ((e = (x)) != hipSuccess) return e
+  TRY(launch_embed(c->word_embed, c->word_pe, start, tokens, tok_stride, step, bf.x, M, d, s));
+  const size_t skv_layer = (size_t)kvB * heads * Lmax * hd;
+  const size_t ckv_slab = (size_t)(shared_mem ? 1 : kvB) * heads * T * hd;
+  for (int l = 0; l < g.dec_layers; ++l) {
+    const DecLayer& L = c->dec[l];
+    TRY(skinny(s, bf.x, d, L.sa_in, nullptr, bf.qkv, 3 * d, M, ACT_NONE));
+    DecAttnP a{};
+    a.q = bf.qkv; a.q_stride = 3 * d;
+    a.k = c->skv + (size_t)(2 * l) * skv_layer; a.v = c->skv + (size_t)(2 * l + 1) * skv_layer;
+    a.cur_k = bf.qkv + d; a.cur_v = bf.qkv + 2 * d; a.cur_stride = 3 * d;
+    a.y = bf.a; a.y_stride = d; a.B = M; a.heads = heads; a.hd = hd; a.Lmax = Lmax; a.step_ptr = step;
+    a.kv_batch_stride = (long long)heads * Lmax * hd;
+    TRY(launch_decode_attention(a, s));
+    TRY(skinny(s, bf.a, d, L.sa_out, bf.x, bf.y, d, M, ACT_NONE));
+    TRY(launch_layernorm(bf.y, L.n1.g, L.n1.b, bf.x1, M, d, 1e-5f, s));
+    TRY(skinny(s, bf.x1, d, L.ca_q, nullptr, bf.q2, d, M, ACT_NONE));
+    DecAttnP ca{};
+    ca.q = bf.q2; ca.q_stride = d;
+    ca.k = c->ckv + (size_t)(2 * l) * ckv_slab; ca.v = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
+    ca.y = bf.a; ca.y_stride = d; ca.B = M; ca.heads = heads; ca.hd = hd; ca.Lmax = T; ca.L = T;
+    ca.kv_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
+    TRY(launch_decode_attention(ca, s));
+    TRY(skinny(s, bf.a, d, L.ca_out, bf.x1, bf.y, d, M, ACT_NONE));
+    TRY(launch_layernorm(bf.y, L.n2.g, L.n2.b, bf.x2, M, d, 1e-5f, s));
+    TRY(skinny(s, bf.x2, d, L.l1, nullptr, bf.f, g.dec_ff, M, ACT_RELU));
+    TRY(skinny(s, bf.f, g.dec_ff, L.l2, bf.x2, bf.y, d, M, ACT_NONE));
+    TRY(launch_layernorm(bf.y, L.n3.g, L.n3.b, bf.x, M, d, 1e-5f, s));
+  }
+  TRY(skinny(s, bf.x, d, c->out_proj, nullptr, logits, (int)logit_row_stride, M, ACT_NONE, step, logit_step_stride));
+#undef TRY
+  return hipSuccess;
+}
+}  // namespace
+
+int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
+                      int32_t is_test, int64_t* tokens, float* logits, int32_t* steps_out, d2t_stream stream) {
+  if (!c || !memory || !start_tokens || !tokens || !logits || !steps_out || B < 1 || T < 1)
+    return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  const d2t_config& g = c->cfg;
+  const int S = g.max_seq_len + 1, V = g.vocab;
+  hipStream_t user = (hipStream_t)stream;
+  hipStream_t s = c->dstream;
+  DecBufs bf;
+  int rc = dec_prepare(c, B, T, &bf);
+  if (rc) return rc;
+  // order the internal stream after the caller's work (memory, start tokens)
+  HIPCHK(c, hipEventRecord(c->ev_in, user));
+  HIPCHK(c, hipStreamWaitEvent(s, c->ev_in, 0));
+  HIPCHK(c, hipMemsetAsync(c->dstate, 0, (size_t)(4 + B) * 4, s));
+  HIPCHK(c, cross_kv(c, s, memory, B, T));
+
+  ArgmaxP am{};
+  am.logits = logits; am.row_stride = (long long)S * V; am.step_stride = V;
+  am.tokens = tokens; am.tok_stride = S;
+  am.ended = c->dstate + 4; am.end_count = c->dstate + 1; am.steps_done = c->dstate + 2; am.step_ptr = c->dstate;
+  am.B = B; am.V = V; am.end_token = TOK_END;
+  auto one_step = [&](hipStream_t st) -> hipError_t {
+    hipError_t e = decode_step(c, st, bf, B, T, B, false, start_tokens, tokens, S, logits, (long long)S * V, V);
+    if (e != hipSuccess) return e;
+    if ((e = launch_argmax(am, st)) != hipSuccess) return e;
+    return launch_step_inc(c->dstate, st);
+  };
+
+  const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
+  if (use_graph) {
+    d2t_ctx::GraphKey k{B, T, tokens, logits, start_tokens, memory};
+    if (!c->graph || memcmp(&k, &c->gkey, sizeof k) != 0) {
+      if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+      hipGraph_t gr = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      hipError_t e = one_step(s);
+      hipError_t e2 = hipStreamEndCapture(s, &gr);
+      if (e != hipSuccess || e2 != hipSuccess) {
+        if (gr) hipGraphDestroy(gr);
+        return fail(c, D2T_EHIP, "decode graph capture: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+      }
+      e = hipGraphInstantiate(&c->graph, gr, nullptr, nullptr, 0);
+      hipGraphDestroy(gr);
+      if (e != hipSuccess) { c->graph = nullptr; return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+      c->gkey = k;
+    }
+  }
+  int steps = S;
+  for (int t = 0; t < S; ++t) {
+    if (use_graph) HIPCHK(c, hipGraphLaunch(c->graph, s));
+    else HIPCHK(c, one_step(s));
+    if (is_test && ((t & 7) == 7 || t == S - 1)) {
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->dstate + 2, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (c->h_pinned[0] > 0) { steps = c->h_pinned[0]; break; }
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  *steps_out = steps;
+  return D2T_OK;
+}
+
+int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
+                    float* score_out, d2t_stream stream) {
+  (void)memory; (void)T; (void)beam_size; (void)seq_out; (void)len_out; (void)score_out; (void)stream;
+  return fail(c, D2T_EINVAL, "beam decode is not implemented in this build");
+}
+
+// ---------------------------------------------------------------------------
+// single-kernel entry points
+// ---------------------------------------------------------------------------
+int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
+                  int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW,
+                  int32_t PH, int32_t PW, int32_t act, d2t_stream stream) {
+  if (!x || !w || !y || SH < 1 || SW < 1) return D2T_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1) {
+    if (KH != 3 || KW != 3 || SH != 1 || SW != 1 || PH != 1 || PW != 1 || residual) return D2T_EINVAL;
+    return launch_stem(x, w, bias, y, B, H, W, Cout, act, s) == hipSuccess ? D2T_OK : D2T_EHIP;
+  }
+  if (Cin % 32) return D2T_EINVAL;
+  ConvP p{};
+  p.in = x; p.w = w; p.bias = bias; p.res = residual; p.out = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.OH = (H + 2 * PH - KH) / SH + 1; p.OW = (W + 2 * PW - KW) / SW + 1;
+  p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
+  p.M = B * p.OH * p.OW; p.K = KH * KW * Cin; p.act = act;
+  return launch_conv(p, s) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,
+                  int32_t K, int32_t N, int32_t act, d2t_stream stream) {
+  if (!x || !w || !y || K % 16) return D2T_EINVAL;
+  LinW lw{w, bias, N, K};
+  return linear_any((hipStream_t)stream, x, lw, residual, y, M, act) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_maxpool2x2(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t SH, int32_t SW,
+                      int32_t PH, int32_t PW, d2t_stream stream) {
+  if (!x || !y) return D2T_EINVAL;
+  return launch_maxpool(x, y, B, H, W, C, SH, SW, PH, PW, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t D,
+                     float eps, d2t_stream stream) {
+  if (!x || !gamma || !beta || !y) return D2T_EINVAL;
+  return launch_layernorm(x, gamma, beta, y, rows, D, eps, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_vit_attention(const float* qkv, float* y, int32_t B, int32_t N, int32_t heads, d2t_stream stream) {
+  if (!qkv || !y) return D2T_EINVAL;
+  return launch_vit_attention(qkv, y, B, N, heads, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_decode_attention(const float* q, const float* k, const float* v, float* y, int32_t B, int32_t heads,
+                            int32_t hd, int32_t L, int32_t Lmax, d2t_stream stream) {
+  if (!q || !k || !v || !y || L > Lmax) return D2T_EINVAL;
+  DecAttnP p{};
+  p.q = q; p.q_stride = heads * hd; p.k = const_cast<float*>(k); p.v = const_cast<float*>(v);
+  p.y = y; p.y_stride = heads * hd; p.B = B; p.heads = heads; p.hd = hd; p.Lmax = Lmax; p.L = L;
+  p.kv_batch_stride = (long long)heads * Lmax * hd;
+  return launch_decode_attention(p, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Internal launch interface between the kernel translation units and the engine.
+// gfx950 only; all tensors fp32, activations NHWC / row-major.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d2t {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { STORE_ROWS = 0, STORE_KV = 1 };
+
+// Implicit-GEMM convolution / linear layer:
+//   out[row(m)][n] = act( sum_{kh,kw,c} in[b, oh*SH-PH+kh, ow*SW-PW+kw, c] * w[n][(kh*KW+kw)*Cin+c]
+//                         + bias[n] + res[row(m)][n] ) + row_add[add_row(m)][n]
+// with m = (b*OH + oh)*OW + ow, out-of-range taps reading zero.
+struct ConvP {
+  const float* in;       // [B,H,W,Cin]
+  const float* w;        // [Cout][KH*KW*Cin]  (OHWI, BN folded)
+  const float* bias;     // [Cout] or nullptr
+  const float* res;      // [rows][Cout] or nullptr, indexed like out
+  const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
+  float* out;
+  int B, H, W, Cin, OH, OW, Cout;
+  int KH, KW, SH, SW, PH, PW;
+  int M;    // B*OH*OW
+  int K;    // KH*KW*Cin
+  int act;
+  // output row remap: row(m) = (m / rows_per_img) * img_stride + row_off + m % rows_per_img
+  // (rows_per_img == 0 -> identity).  add_row(m) = row_add_off + m % rows_per_img.
+  int rows_per_img, img_stride, row_off, row_add_off;
+  // STORE_KV: n -> (slab = n / (heads*hd), head, e), m -> (b = m / kv_T, j):
+  //   out[(((slab*kv_B + b)*kv_heads + head)*kv_T + j)*kv_hd + e]
+  int store_mode, kv_T, kv_heads, kv_hd, kv_B;
+};
+hipError_t launch_conv(const ConvP& p, hipStream_t s);
+
+// Skinny GEMM for decode steps: y[M,N] = act(x[M,K] @ w[N,K]^T + bias + res), K % 16 == 0.
+// If step_ptr != nullptr the output base is advanced by (*step_ptr) * out_step_stride floats.
+struct SkinnyP {
+  const float* x; const float* w; const float* bias; const float* res; float* y;
+  int M, K, N;
+  int ldx, ldy, ldres;  // row strides (floats)
+  int act;
+  const int* step_ptr;
+  long long out_step_stride;
+};
+hipError_t launch_skinny(const SkinnyP& p, hipStream_t s);
+
+// conv0_1: Cin = 1, 3x3, stride 1, pad 1, Cout % 4 == 0, fused bias + ReLU.  w [Cout][9].
+hipError_t launch_stem(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
+                       int act, hipStream_t s);
+hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
+                          hipStream_t s);
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps,
+                            hipStream_t s);
+hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s);
+
+// Single-query attention, one wave per (b, head).
+struct DecAttnP {
+  const float* q; int q_stride;      // q[b*q_stride + head*hd + e]
+  float* k; float* v;                // [B][heads][Lmax][hd]; row b starts at b*kv_batch_stride (0 = shared)
+  long long kv_batch_stride;
+  const float* cur_k; const float* cur_v; int cur_stride;  // this step's k,v rows (self-attn) or nullptr
+  float* y; int y_stride;
+  int B, heads, hd, Lmax;
+  int L;                 // number of keys when step_ptr == nullptr
+  const int* step_ptr;   // self-attn: t = *step_ptr, L = t + 1, cur_k/v are written to the cache at t
+};
+hipError_t launch_decode_attention(const DecAttnP& p, hipStream_t s);
+
+// x[b] = emb[tok]*sqrt(d) + pe[t];  tok = (t == 0) ? start[b] : tokens[b*tok_stride + t - 1]
+hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start, const int64_t* tokens,
+                        int tok_stride, const int* step_ptr, float* x, int B, int d, hipStream_t s);
+// greedy argmax over logits[b][t][:V] (first maximum), writes tokens[b][t], updates end bookkeeping.
+struct ArgmaxP {
+  const float* logits; long long row_stride; long long step_stride;
+  int64_t* tokens; int tok_stride;
+  int* ended;       // [B]
+  int* end_count;   // [1]
+  int* steps_done;  // [1]: first t+1 at which all rows have ended (0 = not yet)
+  const int* step_ptr;
+  int B, V, end_token;
+};
+hipError_t launch_argmax(const ArgmaxP& p, hipStream_t s);
+hipError_t launch_step_inc(int* step_ptr, hipStream_t s);
+
+// weight packing
+// OIHW (+ optional eval-BN) -> OHWI with the BN scale folded; bias_out = bn_b - mean*scale (+ conv bias*scale)
+hipError_t launch_pack_conv(const float* w_oihw, const float* conv_bias, const float* bn_w, const float* bn_b,
+                            const float* bn_mean, const float* bn_var, float eps, float* w_out, float* bias_out,
+                            int Cout, int Cin, int KH, int KW, hipStream_t s);
+hipError_t launch_copy(const float* src, float* dst, size_t n, hipStream_t s);
+hipError_t launch_add_rows(const float* a, const float* b, float* out, int n, hipStream_t s);  // out = a + b
+// out[b*img_stride*D + i] = row[i] for i < D  (cls-token row of every image)
+hipError_t launch_fill_cls(const float* row, float* out, int B, long long img_stride_floats, int D, hipStream_t s);
+
+}  // namespace d2t

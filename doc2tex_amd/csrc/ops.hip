@@ -1,0 +1,466 @@
+// Non-GEMM kernels of the recognizer path (gfx950, 64-wide wavefronts, fp32).
+// Each kernel names the reference op sequence it replaces (paths relative to
+// /root/reference/doc2tex/modules/component/).
+#include "kernels.h"
+
+namespace d2t {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// conv0_1 + bn0_1 + ReLU (feature_extractor/resnet.py:206-208): Cin = 1, 3x3 pad 1.
+// HBM-write-bound: one thread = one pixel x 4 output channels, 16-B coalesced stores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                   int H, int W, int Cout, int act) {
+  const int cq = Cout >> 2;
+  const long long total = (long long)B * H * W * cq;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq);
+    const long long pix = idx / cq;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    const float* im = img + b * H * W;
+    float v[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + kh - 1, xx = x + kw - 1;
+        v[kh * 3 + kw] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? im[(long long)yy * W + xx] : 0.f;
+      }
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int oc = c4 * 4 + c;
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(v[t], w[oc * 9 + t], a);
+      a += bias ? bias[oc] : 0.f;
+      o[c] = act == ACT_RELU ? fmaxf(a, 0.f) : a;
+    }
+    *reinterpret_cast<float4*>(out + pix * Cout + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+hipError_t launch_stem(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
+                       int act, hipStream_t s) {
+  if (Cout % 4) return hipErrorInvalidValue;
+  const long long total = (long long)B * H * W * (Cout / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, out, B, H, W, Cout, act);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// nn.MaxPool2d(kernel 2) NHWC (resnet.py:94,106,120); padding behaves as -inf.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                      int W, int C, int OH, int OW, int SH, int SW, int PH, int PW) {
+  const int cq = C >> 2;
+  const long long total = (long long)B * OH * OW * cq;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq);
+    const long long pix = idx / cq;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const long long b = pix / ((long long)OW * OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + ih) * W + iw) * C + c4 * 4);
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = m;
+  }
+}
+
+hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
+                          hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+  const long long total = (long long)B * OH * OW * (C / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, SH, SW, PH, PW);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dim, one wave per row, row in registers
+// (vision_transformer.py:119-122 eps 1e-6; nn.TransformerDecoderLayer norms eps 1e-5).
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                        float eps) {
+  constexpr int V = D / 256;  // float4 per lane
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  float4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / D) + eps);
+  float* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    float4 o;
+    o.x = v[i].x * rstd * gg.x + bb.x;
+    o.y = v[i].y * rstd * gg.y + bb.y;
+    o.z = v[i].z * rstd * gg.z + bb.z;
+    o.w = v[i].w * rstd * gg.w + bb.w;
+    *reinterpret_cast<float4*>(yr + c) = o;
+  }
+}
+
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps,
+                            hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const dim3 grid((rows + 3) / 4);
+  if (D == 256) hipLaunchKernelGGL(layernorm_kernel<256>, grid, dim3(256), 0, s, x, g, b, y, rows, eps);
+  else if (D == 512) hipLaunchKernelGGL(layernorm_kernel<512>, grid, dim3(256), 0, s, x, g, b, y, rows, eps);
+  else if (D == 1024) hipLaunchKernelGGL(layernorm_kernel<1024>, grid, dim3(256), 0, s, x, g, b, y, rows, eps);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// ViT self-attention (vision_transformer.py:61-81), head_dim 32.
+// qkv [B,N,3,heads,32] -> y [B,N,heads*32].  One block = one (b, head) x 64
+// query rows; K (rows padded to 33 floats) and V of that head live in LDS; each
+// of the 8 waves takes 8 query rows: lanes own keys for q.k^T and softmax,
+// then (key-parity, channel) pairs for P.V.
+// ---------------------------------------------------------------------------
+constexpr int VA_QB = 64;
+constexpr int VA_MAXKPL = 8;  // keys per lane -> N <= 512
+
+__global__ __launch_bounds__(512) void vit_attention_kernel(const float* __restrict__ qkv, float* __restrict__ y, int B,
+                                                            int N, int heads) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;                                  // [N][33]
+  float* Vs = Ks + (((size_t)N * 33 + 3) & ~(size_t)3);  // [N][32], 16-B aligned
+  float* Ps = Vs + (size_t)N * 32;                 // [8 waves][N]
+  const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+  const int C = heads * 32;
+  const float* base = qkv + (size_t)b * N * 3 * C;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N * 8; i += 512) {  // 8 float4 per key row
+    const int j = i >> 3, c = (i & 7) * 4;
+    const float4 kv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + C + hd * 32 + c);
+    const float4 vv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + 2 * C + hd * 32 + c);
+    float* kd = Ks + j * 33 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + j * 32 + c) = vv;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  float* P = Ps + (size_t)wave * N;
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  const int q0 = blockIdx.y * VA_QB;
+  for (int qi = wave; qi < VA_QB; qi += 8) {
+    const int qrow = q0 + qi;
+    if (qrow >= N) break;  // wave-uniform
+    const float* qp = base + (size_t)qrow * 3 * C + hd * 32;
+    float q[32];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + c * 4);
+      q[c * 4 + 0] = t.x; q[c * 4 + 1] = t.y; q[c * 4 + 2] = t.z; q[c * 4 + 3] = t.w;
+    }
+    float sc[VA_MAXKPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < VA_MAXKPL; ++t) {
+      const int j = lane + 64 * t;
+      float a = -INFINITY;
+      if (j < N) {
+        const float* kr = Ks + j * 33;
+        a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a = fmaf(q[c], kr[c], a);
+        a *= scale;
+      }
+      sc[t] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < VA_MAXKPL; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        const float e = expf(sc[t] - mx);
+        sum += e;
+        P[j] = e;
+      }
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): P visible to the whole wave
+    const int c = lane & 31, par = lane >> 5;
+    float acc = 0.f;
+    for (int j = par; j < N; j += 2) acc = fmaf(P[j], Vs[j * 32 + c], acc);
+    acc += __shfl_xor(acc, 32, 64);
+    if (par == 0) y[((size_t)b * N + qrow) * C + hd * 32 + c] = acc / sum;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s) {
+  if (N > 64 * VA_MAXKPL) return hipErrorInvalidValue;
+  const size_t lds = ((((size_t)N * 33 + 3) & ~(size_t)3) + (size_t)N * 32 + 8 * (size_t)N) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(B * heads, (N + VA_QB - 1) / VA_QB);
+  hipLaunchKernelGGL(vit_attention_kernel, grid, dim3(512), lds, s, qkv, y, B, N, heads);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Single-query multi-head attention for one decode step: one wave per (b, head).
+// Replaces nn.MultiheadAttention inside nn.TransformerDecoderLayer
+// (prediction_head/tfm.py:130) for the newest position only, with a KV cache.
+// ---------------------------------------------------------------------------
+constexpr int DA_MAXKPL = 8;  // keys per lane -> L <= 512
+
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const DecAttnP p) {
+  __shared__ float Ps[4][64 * DA_MAXKPL];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= p.B * p.heads) return;
+  const int b = bh / p.heads, head = bh % p.heads;
+  int L = p.L, t = -1;
+  if (p.step_ptr) { t = *p.step_ptr; L = t + 1; }
+  float* Kc = p.k + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
+  float* Vc = p.v + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
+  const float* curk = p.cur_k ? p.cur_k + (size_t)b * p.cur_stride + head * HD : nullptr;
+  const float* curv = p.cur_v ? p.cur_v + (size_t)b * p.cur_stride + head * HD : nullptr;
+  if (curk && t >= 0 && lane < HD) {  // append this step's k,v to the cache
+    Kc[(size_t)t * HD + lane] = curk[lane];
+    Vc[(size_t)t * HD + lane] = curv[lane];
+  }
+  const float* qp = p.q + (size_t)b * p.q_stride + head * HD;
+  float q[HD];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const float4 v4 = *reinterpret_cast<const float4*>(qp + c * 4);
+    q[c * 4 + 0] = v4.x; q[c * 4 + 1] = v4.y; q[c * 4 + 2] = v4.z; q[c * 4 + 3] = v4.w;
+  }
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
+  float sc[DA_MAXKPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DA_MAXKPL; ++i) {
+    const int j = lane + 64 * i;
+    float a = -INFINITY;
+    if (j < L) {
+      const float* kr = (curk && j == t) ? curk : Kc + (size_t)j * HD;
+      a = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD / 4; ++c) {
+        const float4 k4 = *reinterpret_cast<const float4*>(kr + c * 4);
+        a = fmaf(q[c * 4 + 0], k4.x, a);
+        a = fmaf(q[c * 4 + 1], k4.y, a);
+        a = fmaf(q[c * 4 + 2], k4.z, a);
+        a = fmaf(q[c * 4 + 3], k4.w, a);
+      }
+      a *= scale;
+    }
+    sc[i] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  float* P = Ps[wave];
+#pragma unroll
+  for (int i = 0; i < DA_MAXKPL; ++i) {
+    const int j = lane + 64 * i;
+    if (j < L) {
+      const float e = expf(sc[i] - mx);
+      sum += e;
+      P[j] = e;
+    }
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  constexpr int G = 64 / HD;           // key groups per wave
+  const int c = lane % HD, g = lane / HD;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int j = g; j < L; j += G) {
+    const float* vr = (curv && j == t) ? curv : Vc + (size_t)j * HD;
+    acc = fmaf(P[j], vr[c], acc);
+  }
+  if (G == 2) acc += __shfl_xor(acc, 32, 64);
+  if (g == 0) p.y[(size_t)b * p.y_stride + head * HD + c] = acc / sum;
+}
+
+hipError_t launch_decode_attention(const DecAttnP& p, hipStream_t s) {
+  const int Lcap = p.step_ptr ? p.Lmax : p.L;
+  if (Lcap > 64 * DA_MAXKPL) return hipErrorInvalidValue;
+  const dim3 grid((p.B * p.heads + 3) / 4);
+  if (p.hd == 32) hipLaunchKernelGGL(decode_attention_kernel<32>, grid, dim3(256), 0, s, p);
+  else if (p.hd == 64) hipLaunchKernelGGL(decode_attention_kernel<64>, grid, dim3(256), 0, s, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// _embedd_tgt (prediction_head/tfm.py:86-94) for the newest position:
+// Embedding * sqrt(d) + WordPosEnc row t.
+// ---------------------------------------------------------------------------
+__global__ void embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                             const int64_t* __restrict__ start, const int64_t* __restrict__ tokens, int tok_stride,
+                             const int* __restrict__ step_ptr, float* __restrict__ x, int d, float sqrt_d) {
+  const int b = blockIdx.x, t = *step_ptr;
+  const int64_t tok = t == 0 ? start[b] : tokens[(size_t)b * tok_stride + t - 1];
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    x[(size_t)b * d + c] = emb[(size_t)tok * d + c] * sqrt_d + pe[(size_t)t * d + c];
+}
+
+hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start, const int64_t* tokens,
+                        int tok_stride, const int* step_ptr, float* x, int B, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, emb, pe, start, tokens, tok_stride, step_ptr, x, d,
+                     sqrtf((float)d));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Greedy next token (tfm.py:134-139): first maximum of the newest logits row,
+// end-of-sequence bookkeeping kept on the device.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void argmax_kernel(const ArgmaxP p) {
+  const int b = blockIdx.x, lane = threadIdx.x, t = *p.step_ptr;
+  const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < p.V; i += 64) {
+    const float v = row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    p.tokens[(size_t)b * p.tok_stride + t] = bi;
+    if (bi == p.end_token && !p.ended[b]) {
+      p.ended[b] = 1;
+      const int c = atomicAdd(p.end_count, 1) + 1;
+      if (c == p.B) *p.steps_done = t + 1;
+    }
+  }
+}
+
+hipError_t launch_argmax(const ArgmaxP& p, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(p.B), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+hipError_t launch_step_inc(int* step_ptr, hipStream_t s) {
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step_ptr);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing: OIHW -> OHWI with eval-BatchNorm folded
+//   w'[o][kh][kw][c] = w[o][c][kh][kw] * s[o],  s = gamma / sqrt(var + eps)
+//   b'[o] = beta - mean * s  (+ conv_bias * s)
+// ---------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ cb,
+                                 const float* __restrict__ g, const float* __restrict__ be,
+                                 const float* __restrict__ mu, const float* __restrict__ var, float eps,
+                                 float* __restrict__ wo, float* __restrict__ bo, int Cout, int Cin, int KH, int KW) {
+  const long long total = (long long)Cout * Cin * KH * KW;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cin);
+    const int kw = (int)((idx / Cin) % KW);
+    const int kh = (int)((idx / ((long long)Cin * KW)) % KH);
+    const int o = (int)(idx / ((long long)Cin * KW * KH));
+    const float s = g ? g[o] / sqrtf(var[o] + eps) : 1.f;
+    wo[idx] = w[(((size_t)o * Cin + c) * KH + kh) * KW + kw] * s;
+    if (c == 0 && kw == 0 && kh == 0) {
+      float bias = cb ? cb[o] * s : 0.f;
+      if (g) bias += be[o] - mu[o] * s;
+      bo[o] = bias;
+    }
+  }
+}
+
+hipError_t launch_pack_conv(const float* w_oihw, const float* conv_bias, const float* bn_w, const float* bn_b,
+                            const float* bn_mean, const float* bn_var, float eps, float* w_out, float* bias_out,
+                            int Cout, int Cin, int KH, int KW, hipStream_t s) {
+  const long long total = (long long)Cout * Cin * KH * KW;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, conv_bias, bn_w, bn_b, bn_mean, bn_var,
+                     eps, w_out, bias_out, Cout, Cin, KH, KW);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy(const float* src, float* dst, size_t n, hipStream_t s) {
+  return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+}
+
+__global__ void add_rows_kernel(const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+hipError_t launch_add_rows(const float* a, const float* b, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+  return hipGetLastError();
+}
+
+__global__ void fill_cls_kernel(const float* row, float* out, long long img_stride, int D) {
+  for (int i = threadIdx.x; i < D; i += blockDim.x) out[(long long)blockIdx.x * img_stride + i] = row[i];
+}
+hipError_t launch_fill_cls(const float* row, float* out, int B, long long img_stride_floats, int D, hipStream_t s) {
+  hipLaunchKernelGGL(fill_cls_kernel, dim3(B), dim3(256), 0, s, row, out, img_stride_floats, D);
+  return hipGetLastError();
+}
+
+}  // namespace d2t

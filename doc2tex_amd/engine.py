@@ -1,0 +1,152 @@
+"""Thin Python owner of a libd2t context: config marshalling, weight upload,
+encode / decode calls on torch ROCm tensors.  No compute happens here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def config_from_opt(opt):
+    """Flat reference config dict (config/train.yaml schema) -> D2TConfig."""
+    feat = opt["FeatureExtraction"]["name"]
+    seq = opt["SequenceModeling"]["name"]
+    pred = opt["Prediction"]
+    if pred["name"] != "TFM":
+        raise NotImplementedError(f"Prediction '{pred['name']}' is not on the accelerated path (TFM only)")
+    pp = pred["params"]
+    cfg = _lib.D2TConfig()
+    max_dim = opt.get("max_dimension") or [0, 0]
+    if opt.get("imgH"):
+        max_dim = (opt["imgH"], max_dim[1])  # vit_encoder.py:292-294
+    cfg.max_h, cfg.max_w = int(max_dim[0]), int(max_dim[1])
+    if seq == "ViT":
+        sp = opt["SequenceModeling"]["params"]
+        bbp = sp.get("backbone") or {}
+        if bbp.get("name") != "resnet":
+            raise NotImplementedError("ViT without the resnet hybrid backbone cannot run in the reference either "
+                                      "(PatchEmbed returns a 3-tuple, SURVEY.md 3 notes)")
+        if not sp.get("fix_embed", False) or sp.get("patching_style") != "2d":
+            raise NotImplementedError("only fix_embed=True, patching_style='2d' (ViTEncoderV3) is accelerated")
+        if bbp.get("gcb", False):
+            raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
+        cfg.encoder = _lib.ENC_HYBRID_VIT
+        cfg.in_channels = int(bbp["input_channel"])
+        cfg.backbone_out = int(bbp["output_channel"])
+        cfg.vit_depth, cfg.vit_heads, cfg.vit_dim = int(sp["depth"]), int(sp["num_heads"]), int(sp["hidden_size"])
+        ps = sp["patch_size"]
+        ps = (ps, ps) if isinstance(ps, int) else tuple(ps)
+        cfg.patch_h, cfg.patch_w = int(ps[0]), int(ps[1])
+    elif feat == "ResNet" and seq == "None":
+        fp = opt["FeatureExtraction"]["params"]
+        if fp.get("gcb", False):
+            raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
+        cfg.encoder = _lib.ENC_RESNET
+        cfg.in_channels = int(fp["input_channel"])
+        cfg.backbone_out = int(fp["output_channel"])
+    else:
+        raise NotImplementedError(f"Feat={feat} Seq={seq} is not on the accelerated path")
+    cfg.dec_dim, cfg.dec_heads = int(pp["d_model"]), int(pp["nhead"])
+    cfg.dec_layers, cfg.dec_ff = int(pp["num_decoder_layers"]), int(pp["dim_feedforward"])
+    cfg.vocab = int(opt["num_class"])
+    cfg.max_seq_len = int(pp["max_seq_len"])
+    return cfg
+
+
+class Engine:
+    def __init__(self, opt):
+        self.lib = _lib.require_device()
+        self.cfg = config_from_opt(opt)
+        self.ctx = C.c_void_p()
+        rc = self.lib.d2t_create(C.byref(self.cfg), C.byref(self.ctx))
+        if rc != _lib.D2T_OK:
+            msg = self.lib.d2t_last_error(self.ctx).decode() if self.ctx else ""
+            if self.ctx:
+                self.lib.d2t_destroy(self.ctx)
+            self.ctx = None
+            raise RuntimeError(f"d2t_create failed (code {rc}): {msg}")
+        self._sig = None
+
+    def __del__(self):
+        ctx, self.ctx = getattr(self, "ctx", None), None
+        if ctx:
+            try:
+                self.lib.d2t_destroy(ctx)
+            except Exception:
+                pass
+
+    def _check(self, rc, what):
+        _lib.check(rc, self.ctx, what)
+
+    # ---- weights ---------------------------------------------------------
+    def sync_weights(self, module):
+        """Upload + pack the module's state if any tensor changed since last time."""
+        items = []
+        for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if not t.is_floating_point() or name.endswith("image_positional_encoder.pe"):
+                continue
+            items.append((name, t))
+        sig = tuple((n, t.data_ptr(), t._version, tuple(t.shape)) for n, t in items)
+        if sig == self._sig:
+            return
+        stream = None
+        for name, t in items:
+            if not t.is_cuda:
+                raise RuntimeError(f"doc2tex_amd: parameter '{name}' is on {t.device}; move the Model to the GPU")
+            td = t.detach()
+            if td.dtype != torch.float32 or not td.is_contiguous():
+                td = td.float().contiguous()
+            stream = _lib.stream_of(td)
+            shape = (C.c_int64 * td.dim())(*td.shape)
+            self._check(self.lib.d2t_load_weight(self.ctx, name.encode(), _lib.ptr(td), shape, td.dim(), stream),
+                        f"load_weight({name})")
+        self._check(self.lib.d2t_finalize_weights(self.ctx, stream), "finalize_weights")
+        self._sig = sig
+
+    # ---- encoder -----------------------------------------------------------
+    def encoder_shape(self, H, W):
+        v = [C.c_int32() for _ in range(6)]
+        self._check(self.lib.d2t_encoder_shape(self.ctx, H, W, *[C.byref(x) for x in v]), "encoder_shape")
+        T, d, gh, gw, pw, ph = [x.value for x in v]
+        return T, d, gh, gw, pw, ph
+
+    def encode(self, image):
+        if not image.is_cuda:
+            raise RuntimeError("doc2tex_amd: input must be a ROCm (cuda) tensor; the engine has no CPU path")
+        if image.dim() != 4 or image.shape[1] != 1:
+            raise ValueError(f"expected image [B,1,H,W], got {tuple(image.shape)}")
+        image = image.float().contiguous()
+        B, _, H, W = image.shape
+        T, d, gh, gw, pw, ph = self.encoder_shape(H, W)
+        memory = torch.empty((B, T, d), dtype=torch.float32, device=image.device)
+        self._check(self.lib.d2t_encode(self.ctx, _lib.ptr(image), B, H, W, _lib.ptr(memory),
+                                        _lib.stream_of(image)), "encode")
+        return memory, (gh, gw), (pw, ph)
+
+    # ---- decoder -----------------------------------------------------------
+    def decode_greedy(self, memory, start_tokens, is_test):
+        memory = memory.float().contiguous()
+        B, T, _ = memory.shape
+        S, V = self.cfg.max_seq_len + 1, self.cfg.vocab
+        start = start_tokens.to(device=memory.device, dtype=torch.int64).contiguous()
+        tokens = torch.zeros((B, S), dtype=torch.int64, device=memory.device)
+        logits = torch.zeros((B, S, V), dtype=torch.float32, device=memory.device)
+        steps = C.c_int32(0)
+        self._check(self.lib.d2t_decode_greedy(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start), int(bool(is_test)),
+                                               _lib.ptr(tokens), _lib.ptr(logits), C.byref(steps),
+                                               _lib.stream_of(memory)), "decode_greedy")
+        s = steps.value
+        return tokens[:, :s], logits[:, :s]
+
+    def decode_beam(self, memory, beam_size):
+        memory = memory.float().contiguous()
+        if memory.shape[0] != 1:
+            raise AssertionError(
+                f"beam search should only have signle source, encounter with batch size: {memory.shape[0]}")
+        S = self.cfg.max_seq_len + 1
+        seq = (C.c_int64 * S)()
+        n = C.c_int32(0)
+        score = C.c_float(0.0)
+        self._check(self.lib.d2t_decode_beam(self.ctx, _lib.ptr(memory), memory.shape[1], int(beam_size), seq,
+                                             C.byref(n), C.byref(score), _lib.stream_of(memory)), "decode_beam")
+        return torch.LongTensor(list(seq[: n.value])).unsqueeze(0), float(score.value)

@@ -1,0 +1,153 @@
+/*
+ * libd2t -- C-ABI of the MI355X (gfx950) recognizer engine.
+ *
+ * Drop-in boundary for the doc2tex `modules.recognizers` forward pass.  The
+ * reference is 100 % Python and has no FFI of its own; the entry
+ * points below are what a ctypes binding for that path binds, one per reference
+ * call site (citations relative to /root/reference/doc2tex/):
+ *
+ *   d2t_create / d2t_load_weight / d2t_finalize_weights
+ *        <- Model.__init__            modules/build_model.py:8-34
+ *           load_checkpoint           utils/model_utils.py:136-237 (state_dict names)
+ *   d2t_encoder_shape / d2t_encode
+ *        <- Model.forward_encoder     modules/build_model.py:36-43
+ *           (ResNet.forward resnet.py:205-245, HybridEmbed.forward patchembed.py:115-141,
+ *            ViTEncoderV3.forward vit_encoder.py:249-268, SeqModelingBuilder.forward
+ *            recognizers/build_seq.py:42-83)
+ *   d2t_decode_greedy
+ *        <- TransformerPrediction.forward_greedy (eval)  prediction_head/tfm.py:119-143
+ *   d2t_decode_beam
+ *        <- TransformerPrediction.forward_beam tfm.py:145-186 + Beam tools/beam.py:38-140
+ *   d2t_op_*  -- single-kernel entry points used by the parity tests.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions across the boundary;
+ *   - every pointer named *dev* / marked [device] is a raw HIP device pointer
+ *     owned by the CALLER (e.g. a torch tensor's data_ptr()); the engine writes
+ *     outputs in place and keeps its own packed copies of the weights;
+ *   - all arithmetic fp32, token ids int64;
+ *   - every launch goes to the caller's hipStream_t (`stream`, may be NULL for
+ *     the default stream); calls are asynchronous unless they return host
+ *     scalars (d2t_decode_greedy's steps_out, d2t_decode_beam);
+ *   - return value 0 = D2T_OK, otherwise an error code; d2t_last_error(ctx)
+ *     gives the message.  The library never aborts and never falls back to
+ *     the CPU;
+ *   - a ctx is not thread-safe: one ctx per device per process.
+ */
+#ifndef D2T_H
+#define D2T_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct d2t_ctx d2t_ctx;
+typedef void* d2t_stream; /* hipStream_t */
+
+enum {
+  D2T_OK = 0,
+  D2T_EINVAL = 1, /* bad argument / unsupported configuration */
+  D2T_ENOMEM = 2, /* device allocation failed */
+  D2T_EHIP = 3,   /* HIP runtime error */
+  D2T_ESTATE = 4  /* call order (weights missing / not finalized) */
+};
+
+enum { D2T_ENC_RESNET = 0, D2T_ENC_HYBRID_VIT = 1 };
+
+/* Activation codes of d2t_op_conv2d. */
+enum { D2T_ACT_NONE = 0, D2T_ACT_RELU = 1, D2T_ACT_GELU = 2 };
+
+typedef struct d2t_config {
+  int32_t encoder;      /* D2T_ENC_*: Feat=ResNet+Seq=None  |  Seq=ViT (hybrid) */
+  int32_t in_channels;  /* 1 (grey crops) */
+  int32_t backbone_out; /* ResNet output_channel, 512 */
+  int32_t vit_depth, vit_heads, vit_dim; /* ViT blocks / heads / hidden_size */
+  int32_t patch_h, patch_w;              /* patch_size */
+  int32_t max_h, max_w;                  /* max_dimension: sizes the sincos pos-embed grid */
+  int32_t dec_dim, dec_heads, dec_layers, dec_ff; /* TFM d_model / nhead / layers / dim_feedforward */
+  int32_t vocab;        /* num_class */
+  int32_t max_seq_len;  /* Prediction.params.max_seq_len */
+} d2t_config;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int d2t_create(const d2t_config* cfg, d2t_ctx** out);
+void d2t_destroy(d2t_ctx* ctx);
+const char* d2t_last_error(const d2t_ctx* ctx);
+/* 1 if a HIP device is usable from this process, else 0 (no ctx needed). */
+int d2t_device_available(void);
+
+/* ---- weights -------------------------------------------------------------
+ * One call per state_dict entry, `name` being the reference's key (e.g.
+ * "seqmodeler.SequenceModeling.blocks.0.attn.qkv.weight").  `dev` is fp32
+ * [device], contiguous, `shape[ndim]` its torch shape.  Integer entries
+ * (num_batches_tracked) and tables the engine rebuilds itself are ignored.
+ * d2t_finalize_weights folds eval-BatchNorm into the convolutions, packs
+ * everything into the engine's layouts and fails if an entry is missing.  It
+ * may be called again after further d2t_load_weight calls (re-pack). */
+int d2t_load_weight(d2t_ctx* ctx, const char* name, const float* dev, const int64_t* shape, int32_t ndim,
+                    d2t_stream stream);
+int d2t_finalize_weights(d2t_ctx* ctx, d2t_stream stream);
+
+/* ---- encoder -------------------------------------------------------------
+ * d2t_encoder_shape: host-only; token count T, feature dim d, patch grid
+ * (grid_h, grid_w; the backbone feature map size for the ResNet encoder) and
+ * HybridEmbed's (pad_w, pad_h) for an H x W crop.
+ * d2t_encode: image [B,1,H,W] fp32 in [-1,1] [device] -> memory [B,T,d]
+ * [device, caller-allocated]. */
+int d2t_encoder_shape(const d2t_ctx* ctx, int32_t H, int32_t W, int32_t* T, int32_t* d, int32_t* grid_h,
+                      int32_t* grid_w, int32_t* pad_w, int32_t* pad_h);
+int d2t_encode(d2t_ctx* ctx, const float* image_dev, int32_t B, int32_t H, int32_t W, float* memory_dev,
+               d2t_stream stream);
+
+/* ---- greedy decode -------------------------------------------------------
+ * memory [B,T,d]; start_tokens [B] int64 ([GO]).  Runs up to max_seq_len+1
+ * steps with a KV cache; rows that emitted [s] keep generating until the whole
+ * batch has ended (reference semantics).  If is_test != 0 the step count is
+ * the first step at which every row has emitted [s] (tfm.py:138-140),
+ * otherwise max_seq_len+1.
+ * tokens_dev [B, max_seq_len+1] int64 and logits_dev [B, max_seq_len+1, vocab]
+ * fp32 are written for steps [0, *steps_out); entries beyond are unspecified.
+ * Synchronises `stream` before returning (steps_out is a host scalar). */
+int d2t_decode_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T, const int64_t* start_tokens_dev,
+                      int32_t is_test, int64_t* tokens_dev, float* logits_dev, int32_t* steps_out,
+                      d2t_stream stream);
+
+/* ---- beam decode (one sample, fresh beam state per call) ------------------
+ * memory [1,T,d].  seq_out: HOST buffer of max_seq_len+1 int64; *len_out its
+ * used length; *score_out the hypothesis score (tools/beam.py semantics:
+ * best = argmax score/len over completed hypotheses). */
+int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
+                    int32_t* len_out, float* score_out, d2t_stream stream);
+
+/* ---- single-kernel entry points (parity tests) ----------------------------
+ * All tensors [device] fp32.  Activations are NHWC / row-major [rows, features].
+ */
+/* y = act(conv2d(x, w) + bias + residual).  x [B,H,W,Cin] NHWC, w [Cout,KH,KW,Cin]
+ * (OHWI), bias [Cout] or NULL, residual [B,OH,OW,Cout] or NULL, y [B,OH,OW,Cout].
+ * Out-of-range taps read as zero.  Cin must be 1 (direct kernel, 3x3 pad 1 only)
+ * or a multiple of 32 (MFMA implicit GEMM). */
+int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
+                  int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW,
+                  int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + bias + residual); any M (skinny path for M<=64). */
+int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,
+                  int32_t K, int32_t N, int32_t act, d2t_stream stream);
+/* 2x2 max-pool, NHWC, stride (SH,SW), padding (PH,PW) with -inf semantics. */
+int d2t_op_maxpool2x2(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t SH, int32_t SW,
+                      int32_t PH, int32_t PW, d2t_stream stream);
+/* y = LayerNorm(x) * gamma + beta over the last dim (D = 256 or 512). */
+int d2t_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int32_t rows, int32_t D,
+                     float eps, d2t_stream stream);
+/* ViT self-attention.  qkv [B,N,3,heads,32] -> y [B,N,heads*32]; softmax(q k^T / sqrt(32)) v. */
+int d2t_op_vit_attention(const float* qkv, float* y, int32_t B, int32_t N, int32_t heads, d2t_stream stream);
+/* Single-query attention (decoder step).  q [B,heads*hd]; k,v [B,heads,Lmax,hd];
+ * attends over the first L keys; y [B,heads*hd].  hd = 32 or 64. */
+int d2t_op_decode_attention(const float* q, const float* k, const float* v, float* y, int32_t B, int32_t heads,
+                            int32_t hd, int32_t L, int32_t Lmax, d2t_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2T_H */

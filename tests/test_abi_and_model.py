@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads and exports every symbol include/d2t.h declares;
+the drop-in Model has the reference's state_dict keys/shapes and fails loudly
+without a GPU (no fallback).  No compute calls here."""
+import copy
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from doc2tex_amd import Model, _lib, synth
+from doc2tex_amd import params as P
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "d2t.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(d2t_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"libd2t.so does not export {s}"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES out of sync with include/d2t.h"
+
+
+def test_config_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "d2t.h")).read()
+    body = re.search(r"typedef struct d2t_config \{(.*?)\} d2t_config;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"int32_t([^;]+);", body) for n in decl.split(",")]
+    assert names == [f[0] for f in _lib.D2TConfig._fields_]
+    assert ctypes.sizeof(_lib.D2TConfig) == 4 * len(names)
+
+
+@pytest.mark.parametrize("name", ["C2", "C1", "T2"])
+def test_state_dict_keys_and_shapes_match_reference_manifest(manifests, name):
+    m = Model(synth.make_config(name))
+    sd = m.state_dict()
+    ref = manifests[name]
+    assert sorted(sd) == sorted(ref)
+    for k, v in sd.items():
+        assert list(v.shape) == ref[k], k
+
+
+def test_parameters_are_real_and_pos_embed_frozen():
+    m = Model(synth.make_config("T2"))
+    ps = dict(m.named_parameters())
+    assert all(isinstance(p, torch.nn.Parameter) for p in ps.values())
+    assert not ps["seqmodeler.SequenceModeling.pos_embed"].requires_grad  # vit_encoder.py:235-237
+    n_train = sum(p.numel() for p in ps.values() if p.requires_grad)
+    assert n_train > 45e6
+    # optimizer construction / clip_grad_norm_ work on the tree
+    torch.optim.AdamW([p for p in ps.values() if p.requires_grad], lr=1e-3)
+    assert m.seqmodeler.SequenceModeling.patch_embed.grid_size == (1, 9)  # touched by load_checkpoint
+
+
+def test_load_state_dict_roundtrip_and_strict(manifests):
+    cfg = synth.make_config("T2")
+    m = Model(cfg)
+    sd = synth.synth_state_dict(m.state_dict())
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_c1_posenc_table_key_without_8gb():
+    m = Model(synth.make_config("C1"))
+    pe = m.state_dict()["seqmodeler.image_positional_encoder.pe"]
+    assert tuple(pe.shape) == (512, 2000, 2000)
+    assert pe.untyped_storage().nbytes() <= 64  # zero-stride view, not 8 GB
+    sd = {k: v for k, v in synth.synth_state_dict(
+        {k: v for k, v in m.state_dict().items() if not k.endswith("image_positional_encoder.pe")}).items()}
+    m.load_state_dict(sd, strict=True)  # a checkpoint without the table loads
+    sd["seqmodeler.image_positional_encoder.pe"] = torch.zeros(1)  # and one with it is tolerated
+    m.load_state_dict(sd, strict=True)
+
+
+def test_constructor_mutates_config_like_reference():
+    cfg = synth.make_config("C1")
+    cfg["FeatureExtraction"]["params"]["mean_height"] = True
+    Model(cfg)
+    assert "mean_height" not in cfg["FeatureExtraction"]["params"]  # build_feat.py:16
+    assert cfg["Prediction"]["params"]["num_classes"] == cfg["num_class"]  # build_pred.py:16-17
+    assert cfg["Prediction"]["params"]["device"] == cfg["device"]
+
+
+def test_unsupported_configs_raise():
+    cfg = synth.make_config("C2")
+    cfg["Prediction"]["name"] = "Attn"
+    with pytest.raises(NotImplementedError):
+        Model(cfg)
+    cfg = synth.make_config("C2")
+    cfg["FeatureExtraction"]["name"] = "ResNet"
+    with pytest.raises(AssertionError):  # build_model.py:18-19
+        Model(cfg)
+
+
+def test_tables_equal_oracle_tables():
+    from oracle import restatement as R
+    assert torch.equal(P.sincos_2d_table(256, 4, 65), R.sincos_2d_table(256, 4, 65))
+    assert torch.equal(P.WordPosEncParams(256).pe, R.word_pos_table(256))
+    assert P.backbone_out_hw(128, 512) == R.resnet_out_hw(128, 512) == (7, 129)
+    assert P.backbone_out_hw(64, 256) == (3, 65) and P.backbone_out_hw(160, 640) == (9, 161)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_forward_without_gpu_fails_loudly():
+    m = Model(synth.make_config("T2")).eval()
+    img = synth.synth_images(1, 48, 64)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU"):
+        m(img, torch.ones(1, 1, dtype=torch.long), is_train=False)

@@ -1,0 +1,174 @@
+"""GPU: every HIP kernel, called through the C-ABI, against a plain fp32 CPU
+PyTorch evaluation of the same op (tolerances written per test)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from doc2tex_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _conv(x_nchw, w_oihw, bias, res_nchw, stride, pad, act):
+    """Run d2t_op_conv2d; returns NCHW CPU tensor."""
+    lib = _lib.require_device()
+    B, Cin, H, W = x_nchw.shape
+    Cout, _, KH, KW = w_oihw.shape
+    x = x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w = w_oihw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+    OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+    y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+    b = bias.to(DEV) if bias is not None else None
+    r = res_nchw.permute(0, 2, 3, 1).contiguous().to(DEV) if res_nchw is not None else None
+    rc = lib.d2t_op_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), B, H, W, Cin, Cout, KH, KW,
+                           stride[0], stride[1], pad[0], pad[1], act, _lib.stream_of(x))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return y.cpu().permute(0, 3, 1, 2)
+
+
+def _ref_conv(x, w, bias, res, stride, pad, act):
+    y = F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), stride, pad)
+    if res is not None:
+        y = y + res.double()
+    if act == _lib.ACT_RELU:
+        y = F.relu(y)
+    elif act == _lib.ACT_GELU:
+        y = F.gelu(y)
+    return y.float()
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, act, residual      (which reference layer)
+    (2, 32, 16, 24, 64, (3, 3), (1, 1), (1, 1), 1, False),    # conv0_2 (128x64 tile path needs big M; here 64x64)
+    (3, 64, 12, 20, 128, (3, 3), (1, 1), (1, 1), 1, True),    # BasicBlock conv2 + residual
+    (2, 64, 9, 13, 128, (1, 1), (1, 1), (0, 0), 0, False),    # downsample 1x1
+    (2, 256, 8, 17, 512, (3, 3), (1, 1), (1, 1), 1, False),   # layer3 entry
+    (2, 512, 6, 11, 512, (2, 2), (2, 1), (0, 1), 1, False),   # conv4_1
+    (2, 512, 4, 12, 512, (2, 2), (1, 1), (0, 0), 1, False),   # conv4_2
+    (1, 512, 16, 129, 512, (3, 3), (1, 1), (1, 1), 1, True),  # the hot 16x129 conv (odd width, ragged tiles)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_mfma_vs_torch(case):
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res = case
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, *k, seed=2, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    bias = _rand(Cout, seed=3, scale=0.1)
+    OH = (H + 2 * pad[0] - k[0]) // stride[0] + 1
+    OW = (W + 2 * pad[1] - k[1]) // stride[1] + 1
+    res = _rand(B, Cout, OH, OW, seed=4) if use_res else None
+    y = _conv(x, w, bias, res, stride, pad, act)
+    ref = _ref_conv(x, w, bias, res, stride, pad, act)
+    err = float((y - ref).abs().max())
+    assert err <= 2e-4, err  # fp32 accumulation over K <= 4608, |y| ~ O(3)
+
+
+def test_conv_large_m_tile_paths():
+    """M large enough to take the 128x128 and 128x64 tile configurations (grid >= 256 tiles)."""
+    for Cin, Cout, H, W in [(32, 64, 128, 260), (128, 256, 64, 140)]:
+        x = _rand(1, Cin, H, W, seed=5)
+        w = _rand(Cout, Cin, 3, 3, seed=6, scale=(2.0 / (Cin * 9)) ** 0.5)
+        b = _rand(Cout, seed=7, scale=0.1)
+        y = _conv(x, w, b, None, (1, 1), (1, 1), 1)
+        ref = _ref_conv(x, w, b, None, (1, 1), (1, 1), 1)
+        assert float((y - ref).abs().max()) <= 2e-4
+
+
+def test_stem_conv_cin1():
+    x = _rand(2, 1, 20, 36, seed=8)
+    w = _rand(32, 1, 3, 3, seed=9, scale=0.3)
+    b = _rand(32, seed=10, scale=0.1)
+    y = _conv(x, w, b, None, (1, 1), (1, 1), 1)
+    ref = _ref_conv(x, w, b, None, (1, 1), (1, 1), 1)
+    assert float((y - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(16704 // 8, 256, 768, 0, False), (300, 1024, 256, 0, True),
+                                            (200, 256, 1024, 2, False), (64, 256, 768, 0, False),
+                                            (64, 1024, 256, 0, True), (5, 256, 500, 0, False),
+                                            (37, 512, 1536, 1, False), (64, 256, 500, 0, False)])
+def test_linear_vs_torch(M, K, N, act, res):
+    lib = _lib.require_device()
+    x = _rand(M, K, seed=11)
+    w = _rand(N, K, seed=12, scale=K ** -0.5)
+    b = _rand(N, seed=13, scale=0.1)
+    r = _rand(M, N, seed=14) if res else None
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    rd = r.to(DEV) if res else None
+    y = torch.full((M, N), float("nan"), device=DEV)
+    rc = lib.d2t_op_linear(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), M, K, N, act,
+                           _lib.stream_of(xd))
+    assert rc == 0
+    ref = F.linear(x.double(), w.double(), b.double())
+    if res:
+        ref = ref + r.double()
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    err = float((y.cpu() - ref.float()).abs().max())
+    assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("H,W,C,s,p", [(16, 24, 64, (2, 2), (0, 0)), (9, 11, 128, (2, 2), (0, 0)),
+                                        (8, 13, 256, (2, 1), (0, 1))])
+def test_maxpool_vs_torch(H, W, C, s, p):
+    lib = _lib.require_device()
+    x = _rand(2, C, H, W, seed=15)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ref = F.max_pool2d(x, 2, s, p)
+    y = torch.empty((2, ref.shape[2], ref.shape[3], C), device=DEV)
+    assert lib.d2t_op_maxpool2x2(_lib.ptr(xd), _lib.ptr(y), 2, H, W, C, s[0], s[1], p[0], p[1], _lib.stream_of(xd)) == 0
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)  # bit-exact
+
+
+@pytest.mark.parametrize("D,eps", [(256, 1e-6), (512, 1e-5)])
+def test_layernorm_vs_torch(D, eps):
+    lib = _lib.require_device()
+    x = _rand(77, D, seed=16, scale=3.0) + 0.5
+    g, b = _rand(D, seed=17) * 0.2 + 1.0, _rand(D, seed=18) * 0.1
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    y = torch.empty_like(xd)
+    assert lib.d2t_op_layernorm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y), 77, D, eps,
+                                _lib.stream_of(xd)) == 0
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), eps).float()
+    assert float((y.cpu() - ref).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 10, 8), (2, 261, 8), (1, 406, 8), (3, 65, 16)])
+def test_vit_attention_vs_torch(B, N, heads):
+    lib = _lib.require_device()
+    C_ = heads * 32
+    qkv = _rand(B, N, 3, heads, 32, seed=19)
+    qd = qkv.to(DEV)
+    y = torch.empty((B, N, C_), device=DEV)
+    assert lib.d2t_op_vit_attention(_lib.ptr(qd), _lib.ptr(y), B, N, heads, _lib.stream_of(qd)) == 0
+    q, k, v = [t.double() for t in qkv.permute(2, 0, 3, 1, 4)]
+    a = ((q @ k.transpose(-2, -1)) * 32 ** -0.5).softmax(-1)
+    ref = (a @ v).transpose(1, 2).reshape(B, N, C_).float()
+    assert float((y.cpu() - ref).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("B,heads,hd,L,Lmax", [(3, 8, 32, 1, 152), (3, 8, 32, 152, 152), (2, 8, 32, 261, 261),
+                                                (2, 8, 64, 195, 195), (5, 8, 64, 77, 152), (1, 8, 32, 406, 406)])
+def test_decode_attention_vs_torch(B, heads, hd, L, Lmax):
+    lib = _lib.require_device()
+    q = _rand(B, heads * hd, seed=20)
+    k = _rand(B, heads, Lmax, hd, seed=21)
+    v = _rand(B, heads, Lmax, hd, seed=22)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    y = torch.empty((B, heads * hd), device=DEV)
+    assert lib.d2t_op_decode_attention(_lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(y), B, heads, hd, L, Lmax,
+                                       _lib.stream_of(qd)) == 0
+    qq = q.view(B, heads, 1, hd).double()
+    a = ((qq @ k[:, :, :L].double().transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (a @ v[:, :, :L].double()).reshape(B, heads * hd).float()
+    assert float((y.cpu() - ref).abs().max()) <= 2e-6

@@ -1,0 +1,92 @@
+"""CPU: oracle/restatement.py against the fixtures generated from the reference
+(tools/make_golden.py).  Pins the oracle wherever the tests run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, oracle_state_dict
+from doc2tex_amd import synth
+from oracle import restatement as R
+
+# the two full-size greedy cases take ~15 s each on 8 cores; everything else is seconds
+GREEDY = ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_small_crop", "c2_greedy", "c1_greedy"]
+
+
+def _case(cases, kind, name):
+    return next(c for c in cases[kind] if c["case"] == name)
+
+
+@pytest.mark.parametrize("name", GREEDY)
+def test_greedy_matches_reference_fixture(cases, manifests, name):
+    c = _case(cases, "greedy", name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        mem, shape, pad = R.forward_encoder(cfg, sd, img, faithful=False)
+        preds, logits, _ = R.forward(cfg, sd, img, text, is_test=c["is_test"], faithful=False)
+    assert list(mem.shape) == c["mem_shape"]
+    assert (list(shape) if shape else None) == c["output_shape"]
+    assert (list(pad) if pad else None) == c["feat_pad"]
+    scale = max(1.0, c["mem_absmax"])
+    rows = z["mem_rows"].tolist()
+    assert np.abs(mem[:, rows].numpy() - z["mem_sample"]).max() / scale <= 2e-5
+    assert abs(float(mem.double().sum()) - c["mem_sum"]) <= 1e-4 * max(1.0, c["mem_abs"]) 
+    assert preds.shape[1] == c["steps"]
+    assert np.array_equal(preds.numpy(), z["tokens"])  # bit-exact token ids
+    steps = z["logit_steps"].tolist()
+    assert np.abs(logits[:, steps].numpy() - z["logits_sample"]).max() <= 1e-4
+
+
+def test_faithful_mode_equals_cached_mode(cases, manifests):
+    """The reference-faithful (no KV cache, unfused BN) restatement used for the CPU
+    baseline computes the same tokens/logits as the cached mode."""
+    c = _case(cases, "greedy", "t2_greedy")
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"])
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        pf, lf, _ = R.forward(cfg, sd, img, text, faithful=True)
+        pa, la, _ = R.forward(cfg, sd, img, text, faithful=False)
+    assert torch.equal(pf, pa)
+    assert float((lf - la).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish"])
+def test_beam_matches_reference_fixture(cases, manifests, name):
+    c = _case(cases, "beam", name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    cfg["beam_size"] = c["beam_size"]
+    img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"])
+    with torch.no_grad():
+        seq, score, _ = R.forward(cfg, sd, img, torch.full((1, 1), R.GO, dtype=torch.long), is_test=True)
+    assert seq[0].tolist() == c["seq"]
+    assert abs(score - c["score"]) <= 1e-3
+
+
+def test_teacher_forced_loss_matches_reference_fixture(cases, manifests):
+    c = _case(cases, "train", "t2_train")
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = torch.tensor(c["text"], dtype=torch.long)
+    pp = cfg["Prediction"]["params"]
+    with torch.no_grad():
+        mem, _, _ = R.forward_encoder(cfg, sd, img, faithful=False)
+        logits = R.tfm_full_pass(text[:, :-1], mem, sd, "predicter.Prediction.", pp["num_decoder_layers"],
+                                 pp["nhead"], key_padding=True)
+        loss = R.ce_loss(logits, text[:, 1:])
+    assert abs(float(loss) - c["loss"]) <= 1e-4
+    assert abs(float(logits.double().sum()) - c["logits_sum"]) <= 1e-2
+
+
+def test_tables_match_reference_checksums(cases):
+    c = _case(cases, "greedy", "c2_greedy")
+    t = R.sincos_2d_table(256, 4, 65)
+    assert abs(float(t.double().sum()) - c["pos_embed_sum"]) < 1e-6
+    assert abs(float(t.double().abs().sum()) - c["pos_embed_abs"]) < 1e-6
+    assert abs(float(R.word_pos_table(256).double().sum()) - c["pe_sum"]) < 1e-6
+    c1 = _case(cases, "greedy", "c1_greedy")
+    assert abs(float(R.posenc2d_crop(512, 9, 80).double().sum()) - c1["pe2d_crop_sum"]) < 1e-6
