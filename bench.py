@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: formulas/s, greedy decode of 128x512 crops (BASELINE.json
+configs[2]: HybridViT encoder + 6-layer transformer decoder, B=64 per GPU, all
+151 decode steps), one process per GPU.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (Model.forward: encode + KV-cached greedy
+decode) over one batch of synthetic crops already resident in HBM.  Data-parallel
+weak scaling: every rank decodes its own batch, no data-path collective
+(SURVEY.md 8e); the only collectives are the timing barrier / max-reduce.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     dominant kernel (the 512->512 3x3 conv @16x129, fp32 MFMA implicit GEMM)
+               timed live with HIP events inside the timed region (d2t_profile_*)
+  cpu_baseline the CPU oracle in reference-faithful mode (no KV cache, unfused BN),
+               timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from doc2tex_amd import Model, synth
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+
+
+def decoder_flops(L, M, d=256, ff=1024, n=6, V=500):
+    """KV-cached algorithmic decoder FLOPs for L generated tokens."""
+    per_tok = n * (2 * d * 3 * d + 3 * 2 * d * d + 4 * d * ff) + 2 * d * V
+    attn = sum(n * 4 * d * (l + 1 + M) for l in range(L))
+    return L * per_tok + attn + n * 2 * M * d * 2 * d
+
+
+def host_cores():
+    """CPU cores this process may actually use (affinity mask and cgroup quota), not the host total."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg_name, H, W, max_len, sample_b):
+    """Reference-faithful CPU oracle timed on the host cores (bounded sample)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import oracle_state_dict
+    from oracle import restatement as R
+
+    with open(os.path.join(ROOT, "tests", "golden", "manifests.json")) as f:
+        man = json.load(f)
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: {sample_b} crops on {cores} threads ...")
+    cfg, sd = oracle_state_dict(cfg_name, man[cfg_name], max_len)
+    img = synth.synth_images(sample_b, H, W, seed=1000)
+    text = torch.full((sample_b, 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        R.forward_encoder(cfg, sd, img[:1], faithful=True)  # warm the thread pool / allocator
+        t0 = time.perf_counter()
+        R.forward(cfg, sd, img, text, is_test=False, faithful=True)
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(sample_b / dt, 4), "unit": "formulas/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{sample_b} crops {H}x{W}, {max_len + 1} greedy steps, oracle/restatement.py faithful mode "
+                  f"(no KV cache, unfused BN), 1 timed pass = {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    name = args.config
+    H, W = synth.crop_shape(name)
+    B = args.batch or synth.batch_size(name)
+    cfg = synth.make_config(name, device=str(dev))
+    L = cfg["Prediction"]["params"]["max_seq_len"]
+    model = Model(cfg)
+    tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
+    model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
+    model.eval().to(dev)
+    img = synth.synth_images(B, H, W, seed=1000 + rank).to(dev)  # each rank its own shard
+    text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return model(img, text, is_train=False, is_test=False)
+
+    for _ in range(args.warmup):
+        out = step()
+    if rank == 0:
+        log(f"warm-up done ({args.warmup} steps)")
+    eng = model.engine()
+    torch.cuda.synchronize(dev)
+    eng.profile(True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    recs = eng.profile_read()
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out[0].shape == (B, L + 1), out[0].shape
+
+    if rank == 0:
+        log(f"timed {args.steps} steps in {elapsed:.3f} s")
+        T = model.engine().encoder_shape(H, W)[0]
+        # dominant kernel: the most expensive GEMM shape of the timed region
+        by_shape = {}
+        for M_, N_, K_, ms in recs:
+            if ms > 0:
+                by_shape.setdefault((M_, N_, K_), []).append(ms)
+        total_ms = sum(sum(v) for v in by_shape.values())
+        total_flop = sum(2.0 * m * n * k * len(v) for (m, n, k), v in by_shape.items())
+        dom = max(by_shape, key=lambda s: sum(by_shape[s]))
+        dom_ms = sum(by_shape[dom]) / len(by_shape[dom])
+        dom_flop = 2.0 * dom[0] * dom[1] * dom[2]
+        achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": "conv_mfma_kernel<128,128> (512->512 3x3 conv @16x129 as implicit GEMM)",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "gemm_MNK": list(dom), "flop_per_launch": dom_flop, "avg_launch_ms": round(dom_ms, 4),
+            "launches_timed": len(by_shape[dom]),
+            "share_of_gemm_time": round(sum(by_shape[dom]) / total_ms, 4),
+            "all_encoder_gemms": {"achieved": round(total_flop / (total_ms * 1e-3) / 1e12, 2),
+                                  "ms_per_step": round(total_ms / args.steps, 3)},
+        }
+        formulas = world * B * args.steps
+        ms_step = elapsed / args.steps * 1e3
+        enc_flops = {"C2": 205.28e9, "C1": 50.79e9}.get(name, 0.0)
+        algo = enc_flops + decoder_flops(L + 1, T, d=cfg["Prediction"]["params"]["d_model"],
+                                         ff=cfg["Prediction"]["params"]["dim_feedforward"],
+                                         n=cfg["Prediction"]["params"]["num_decoder_layers"])
+        result = {
+            "metric": "formulas/s (greedy decode, 128x512 crops)" if name == "C2" else f"formulas/s ({name})",
+            "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
+                                   f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
+                       "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
+                       "parallelism": f"dp{world} (batch-sharded, no collective)"},
+            "algorithmic_gflop_per_formula": round(algo / 1e9, 2),
+            "e2e_tflops": round(algo * formulas / elapsed / 1e12, 2),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(name, H, W, L, args.cpu_sample)
+            result["speedup_vs_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,10 @@ struct d2t_ctx {
   hipEvent_t ev_in = nullptr;
   hipGraphExec_t graph = nullptr;
   struct GraphKey { int B, T; const void* tok; const void* logits; const void* start; const void* mem; } gkey{};
+  // kernel timing log (d2t_profile_*)
+  bool profiling = false;
+  struct ProfRec { int M, N, K; hipEvent_t a, b; };
+  std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -207,6 +211,19 @@ void backbone_hw(int H, int W, int* oh, int* ow) {
   *oh = h - 1; *ow = w - 1;          // conv4_2  k2 s1 p0
 }
 
+// launch_conv, bracketed by HIP events on `s` while profiling is enabled
+hipError_t conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) {
+  if (!c->profiling) return launch_conv(p, s);
+  d2t_ctx::ProfRec r{p.M, p.Cout, p.K, nullptr, nullptr};
+  hipError_t e;
+  if ((e = hipEventCreate(&r.a)) != hipSuccess || (e = hipEventCreate(&r.b)) != hipSuccess) return e;
+  if ((e = hipEventRecord(r.a, s)) != hipSuccess) return e;
+  e = launch_conv(p, s);
+  hipError_t e2 = hipEventRecord(r.b, s);
+  c->prof.push_back(r);
+  return e != hipSuccess ? e : e2;
+}
+
 Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& w, int sh, int sw, int ph, int pw,
          int act, const float* res, float* outbuf, const ConvP* extra = nullptr) {
   Act y{outbuf, x.B, (x.H + 2 * ph - w.KH) / sh + 1, (x.W + 2 * pw - w.KW) / sw + 1, w.Cout};
@@ -216,21 +233,23 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
   p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
-  hipError_t e = launch_conv(p, s);
+  hipError_t e = conv_timed(c, p, s);
   if (e != hipSuccess && *err == hipSuccess) *err = e;
   return y;
 }
 
-hipError_t linear_big(hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M, int act) {
+hipError_t linear_big(d2t_ctx* c, hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M,
+                      int act) {
   ConvP p{};
   p.in = x; p.w = w.w; p.bias = w.b; p.res = res; p.out = y;
   p.B = 1; p.H = 1; p.W = M; p.Cin = w.K; p.OH = 1; p.OW = M; p.Cout = w.N;
   p.KH = p.KW = p.SH = p.SW = 1; p.PH = p.PW = 0; p.M = M; p.K = w.K; p.act = act;
-  return launch_conv(p, s);
+  return c ? conv_timed(c, p, s) : launch_conv(p, s);
 }
 
-hipError_t linear_any(hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M, int act) {
-  if (M > 64 && w.K % 32 == 0) return linear_big(s, x, w, res, y, M, act);
+hipError_t linear_any(d2t_ctx* c, hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M,
+                      int act) {
+  if (M > 64 && w.K % 32 == 0) return linear_big(c, s, x, w, res, y, M, act);
   SkinnyP p{};
   p.x = x; p.w = w.w; p.bias = w.b; p.res = res; p.y = y;
   p.M = M; p.K = w.K; p.N = w.N; p.ldx = w.K; p.ldy = w.N; p.ldres = w.N; p.act = act;
@@ -592,7 +611,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
     p.row_add = c->pos_embed; p.rows_per_img = gh * gw; p.img_stride = T; p.row_off = 1; p.row_add_off = 1;
-    HIPCHK(c, launch_conv(p, s));
+    HIPCHK(c, conv_timed(c, p, s));
     HIPCHK(c, launch_fill_cls(c->cls_row, X, B, (long long)T * dim, dim, s));
   }
   const int M = B * T;
@@ -602,12 +621,12 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
   for (const VitBlock& vb : c->vit) {
     // Block.forward (vision_transformer.py:119-122), LayerNorm eps 1e-6 (:175)
     HIPCHK(c, launch_layernorm(X, vb.n1.g, vb.n1.b, Hn, M, dim, 1e-6f, s));
-    HIPCHK(c, linear_any(s, Hn, vb.qkv, nullptr, Q, M, ACT_NONE));
+    HIPCHK(c, linear_any(c, s, Hn, vb.qkv, nullptr, Q, M, ACT_NONE));
     HIPCHK(c, launch_vit_attention(Q, Hn, B, T, g.vit_heads, s));
-    HIPCHK(c, linear_any(s, Hn, vb.proj, X, X2, M, ACT_NONE));
+    HIPCHK(c, linear_any(c, s, Hn, vb.proj, X, X2, M, ACT_NONE));
     HIPCHK(c, launch_layernorm(X2, vb.n2.g, vb.n2.b, Hn, M, dim, 1e-6f, s));
-    HIPCHK(c, linear_any(s, Hn, vb.fc1, nullptr, Q, M, ACT_GELU));
-    HIPCHK(c, linear_any(s, Q, vb.fc2, X2, X, M, ACT_NONE));
+    HIPCHK(c, linear_any(c, s, Hn, vb.fc1, nullptr, Q, M, ACT_GELU));
+    HIPCHK(c, linear_any(c, s, Q, vb.fc2, X2, X, M, ACT_NONE));
   }
   HIPCHK(c, launch_layernorm(X, c->vit_norm.g, c->vit_norm.b, memory, M, dim, 1e-6f, s));
   (void)err;
@@ -780,6 +799,31 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   return fail(c, D2T_EINVAL, "beam decode is not implemented in this build");
 }
 
+int d2t_profile_enable(d2t_ctx* c, int32_t on) {
+  if (!c) return D2T_EINVAL;
+  c->profiling = on != 0;
+  return D2T_OK;
+}
+
+int d2t_profile_read(d2t_ctx* c, int32_t max_records, int32_t* n, int32_t* M, int32_t* N, int32_t* K, float* ms) {
+  if (!c || !n) return D2T_EINVAL;
+  HIPCHK(c, hipDeviceSynchronize());
+  int out = 0;
+  for (auto& r : c->prof) {
+    if (out < max_records && M && N && K && ms) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+      M[out] = r.M; N[out] = r.N; K[out] = r.K; ms[out] = t;
+      ++out;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  c->prof.clear();
+  *n = out;
+  return D2T_OK;
+}
+
 // ---------------------------------------------------------------------------
 // single-kernel entry points
 // ---------------------------------------------------------------------------
@@ -806,7 +850,7 @@ int d2t_op_linear(const float* x, const float* w, const float* bias, const float
                   int32_t K, int32_t N, int32_t act, d2t_stream stream) {
   if (!x || !w || !y || K % 16) return D2T_EINVAL;
   LinW lw{w, bias, N, K};
-  return linear_any((hipStream_t)stream, x, lw, residual, y, M, act) == hipSuccess ? D2T_OK : D2T_EHIP;
+  return linear_any(nullptr, (hipStream_t)stream, x, lw, residual, y, M, act) == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
 int d2t_op_maxpool2x2(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t SH, int32_t SW,

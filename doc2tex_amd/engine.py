@@ -123,6 +123,18 @@ class Engine:
                                         _lib.stream_of(image)), "encode")
         return memory, (gh, gw), (pw, ph)
 
+    # ---- kernel timing -------------------------------------------------------
+    def profile(self, on):
+        self._check(self.lib.d2t_profile_enable(self.ctx, int(bool(on))), "profile_enable")
+
+    def profile_read(self, max_records=4096):
+        """[(M, N, K, ms)] for every MFMA implicit-GEMM launch since the last read."""
+        n = C.c_int32(0)
+        M, N, K = [(C.c_int32 * max_records)() for _ in range(3)]
+        ms = (C.c_float * max_records)()
+        self._check(self.lib.d2t_profile_read(self.ctx, max_records, C.byref(n), M, N, K, ms), "profile_read")
+        return [(M[i], N[i], K[i], ms[i]) for i in range(n.value)]
+
     # ---- decoder -----------------------------------------------------------
     def decode_greedy(self, memory, start_tokens, is_test):
         memory = memory.float().contiguous()

@@ -121,6 +121,14 @@ int d2t_decode_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t 
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
+/* ---- in-engine kernel timing (bench.py roofline leg) ------------------------
+ * While enabled, d2t_encode brackets every implicit-GEMM (MFMA) launch with a
+ * pair of HIP events on the launch stream.  d2t_profile_read synchronises,
+ * returns up to max_records launches in issue order as GEMM shape (M,N,K) and
+ * elapsed milliseconds, and clears the log.  *n receives the number written. */
+int d2t_profile_enable(d2t_ctx* ctx, int32_t on);
+int d2t_profile_read(d2t_ctx* ctx, int32_t max_records, int32_t* n, int32_t* M, int32_t* N, int32_t* K, float* ms);
+
 /* ---- single-kernel entry points (parity tests) ----------------------------
  * All tensors [device] fp32.  Activations are NHWC / row-major [rows, features].
  */

@@ -92,7 +92,7 @@ def test_determinism_and_weight_reload(cases):
         b = m(img, text, is_train=False)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         # in-place weight change must be picked up (engine re-packs)
-        m.predicter.Prediction.proj.bias.data[5] += 50.0
+        m.predicter.Prediction.proj.bias[5] += 50.0  # in-place under no_grad bumps ._version
         d = m(img, text, is_train=False)
     assert (d[0] == 5).all()
 
