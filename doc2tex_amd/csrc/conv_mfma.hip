@@ -223,74 +223,4 @@ hipError_t launch_conv(const ConvP& p, hipStream_t s) {
   return launch_cfg<64, 64>(p, s);
 }
 
-// ---------------------------------------------------------------------------
-// Skinny GEMM (decode steps, M <= 64 per block row): weights streamed from L2
-// straight into registers, v_mfma_f32_16x16x4_f32, block tile 64 x 16.
-// Replaces the per-step nn.Linear / in_proj calls of nn.TransformerDecoderLayer
-// (prediction_head/tfm.py:130-133).
-// ---------------------------------------------------------------------------
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyP p) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = lane & 15, q = lane >> 4;
-  const int m = blockIdx.y * 64 + wave * 16 + r;  // A row this lane loads
-  const int n = blockIdx.x * 16 + r;              // B (weight) row this lane loads
-  const bool mok = m < p.M, nok = n < p.N;
-  const float* xa = p.x + (size_t)(mok ? m : 0) * p.ldx + q * 4;
-  const float* wb = p.w + (size_t)(nok ? n : 0) * p.K + q * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int KC = p.K >> 4;
-  int c = 0;
-  for (; c + 4 <= KC; c += 4) {  // 4 chunks (8 x 16-B loads) in flight per lane
-    float4 a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = *reinterpret_cast<const float4*>(xa + (c + u) * 16);
-      b[u] = *reinterpret_cast<const float4*>(wb + (c + u) * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!mok) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!nok) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
-    }
-  }
-  for (; c < KC; ++c) {
-    float4 a = *reinterpret_cast<const float4*>(xa + c * 16);
-    float4 b = *reinterpret_cast<const float4*>(wb + c * 16);
-    if (!mok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-  }
-  // C/D map: col = lane&15 -> n, row = (lane>>4)*4 + reg -> m
-  const int nn = blockIdx.x * 16 + r;
-  if (nn >= p.N) return;
-  float* y = p.y;
-  if (p.step_ptr) y += (long long)(*p.step_ptr) * p.out_step_stride;
-  const float bias = p.bias ? p.bias[nn] : 0.f;
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int mm = blockIdx.y * 64 + wave * 16 + q * 4 + reg;
-    if (mm >= p.M) continue;
-    float v = acc[reg] + bias;
-    if (p.res) v += p.res[(size_t)mm * p.ldres + nn];
-    y[(size_t)mm * p.ldy + nn] = apply_act(v, p.act);
-  }
-}
-
-hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.K % 16 != 0 || p.ldx % 4 != 0) return hipErrorInvalidValue;
-  dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
-  hipLaunchKernelGGL(skinny_gemm_kernel, grid, dim3(256), 0, s, p);
-  return hipGetLastError();
-}
-
 }  // namespace d2t

@@ -1,0 +1,376 @@
+// Decode-step kernels (gfx950, fp32): everything the KV-cached greedy / beam loop
+// launches once per generated token.  Replaces, for the newest position only, what
+// nn.TransformerDecoder recomputes over the whole prefix at every step in the
+// reference (prediction_head/tfm.py:125-140).  All position-dependent values are
+// read from a device-side step counter so one captured hipGraph replays for every step.
+#include "kernels.h"
+
+namespace d2t {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Skinny GEMM  y[M,N] = act(A @ w[N,K]^T + bias + res),  A = x or LayerNorm(x).
+// M <= 64 rows per block row (the decode batch), weights streamed from L2 straight
+// into registers.  Block tile 64 x 16; the K dimension is split over the NW waves
+// of the block (each wave: all 64 rows x its K-slice, v_mfma_f32_16x16x4_f32, every
+// load issued before the first MFMA), partial tiles are summed through LDS.
+// The optional LayerNorm prologue (post-norm decoder: the previous sub-layer's
+// LayerNorm) is evaluated on the register-resident rows: two-pass mean / variance
+// with a cross-wave LDS reduction, so no standalone LayerNorm launch is needed.
+// ---------------------------------------------------------------------------
+template <int NW, int NCH>  // K == NW * NCH * 16
+__global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p) {
+  constexpr int KS = NCH * 16;
+  __shared__ float part[NW][64][17];
+  __shared__ float stat[NW][64];
+  __shared__ float s_mean[64], s_rstd[64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int mbase = blockIdx.y * 64;
+  const int n = blockIdx.x * 16 + r;
+  const bool nok = n < p.N;
+  const int k0 = wave * KS + q * 4;
+
+  float4 a[4][NCH], b[NCH];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbase + i * 16 + r;
+    const bool mok = m < p.M;
+    const float* src = p.x + (size_t)(mok ? m : 0) * p.ldx + k0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      a[i][c] = *reinterpret_cast<const float4*>(src + c * 16);
+      if (!mok) a[i][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  {
+    const float* src = p.w + (size_t)(nok ? n : 0) * p.K + k0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      b[c] = *reinterpret_cast<const float4*>(src + c * 16);
+      if (!nok) b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  if (p.ln_g) {
+    const float invK = 1.f / (float)p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) s += (a[i][c].x + a[i][c].y) + (a[i][c].z + a[i][c].w);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (q == 0) stat[wave][i * 16 + r] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w][tid];
+      s_mean[tid] = t * invK;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float mu = s_mean[i * 16 + r];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        a[i][c].x -= mu; a[i][c].y -= mu; a[i][c].z -= mu; a[i][c].w -= mu;
+        s += (a[i][c].x * a[i][c].x + a[i][c].y * a[i][c].y) + (a[i][c].z * a[i][c].z + a[i][c].w * a[i][c].w);
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (q == 0) stat[wave][i * 16 + r] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += stat[w][tid];
+      s_rstd[tid] = 1.f / sqrtf(t * invK + p.ln_eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + k0 + c * 16);
+      const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + k0 + c * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float rs = s_rstd[i * 16 + r];
+        a[i][c].x = a[i][c].x * rs * g4.x + b4.x;
+        a[i][c].y = a[i][c].y * rs * g4.y + b4.y;
+        a[i][c].z = a[i][c].z * rs * g4.z + b4.z;
+        a[i][c].w = a[i][c].w * rs * g4.w + b4.w;
+      }
+    }
+  }
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].x, b[c].x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].y, b[c].y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].z, b[c].z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].w, b[c].w, acc[i], 0, 0, 0);
+    }
+  }
+  // C/D map: col = lane&15 -> n, row = (lane>>4)*4 + reg -> m
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[wave][i * 16 + q * 4 + reg][r] = acc[i][reg];
+  __syncthreads();
+
+  float* y = p.y;
+  if (p.step_ptr) y += (long long)(*p.step_ptr) * p.out_step_stride;
+  for (int idx = tid; idx < 64 * 16; idx += NW * 64) {
+    const int row = idx >> 4, col = idx & 15;
+    const int m = mbase + row, nn = blockIdx.x * 16 + col;
+    if (m >= p.M || nn >= p.N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += part[w][row][col];
+    v += p.bias ? p.bias[nn] : 0.f;
+    if (p.res) v += p.res[(size_t)m * p.ldres + nn];
+    y[(size_t)m * p.ldy + nn] = act_fn(v, p.act);
+    if (p.ln_out && nn < p.K) {
+      const float xv = p.x[(size_t)m * p.ldx + nn];
+      p.ln_out[(size_t)m * p.K + nn] = (xv - s_mean[row]) * s_rstd[row] * p.ln_g[nn] + p.ln_b[nn];
+    }
+  }
+}
+
+// generic fallback (any K % 16 == 0, no LayerNorm prologue): one wave per 16 rows
+__global__ __launch_bounds__(256) void skinny_generic_kernel(const SkinnyP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int m = blockIdx.y * 64 + wave * 16 + r;
+  const int n = blockIdx.x * 16 + r;
+  const bool mok = m < p.M, nok = n < p.N;
+  const float* xa = p.x + (size_t)(mok ? m : 0) * p.ldx + q * 4;
+  const float* wb = p.w + (size_t)(nok ? n : 0) * p.K + q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int KC = p.K >> 4;
+  for (int c = 0; c < KC; ++c) {
+    float4 a = *reinterpret_cast<const float4*>(xa + c * 16);
+    float4 b = *reinterpret_cast<const float4*>(wb + c * 16);
+    if (!mok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!nok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  const int nn = blockIdx.x * 16 + r;
+  if (nn >= p.N) return;
+  float* y = p.y;
+  if (p.step_ptr) y += (long long)(*p.step_ptr) * p.out_step_stride;
+  const float bias = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int mm = blockIdx.y * 64 + wave * 16 + q * 4 + reg;
+    if (mm >= p.M) continue;
+    float v = acc[reg] + bias;
+    if (p.res) v += p.res[(size_t)mm * p.ldres + nn];
+    y[(size_t)mm * p.ldy + nn] = act_fn(v, p.act);
+  }
+}
+
+hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if (p.K % 16 != 0 || p.ldx % 4 != 0) return hipErrorInvalidValue;
+  const dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
+  if (p.K == 256) hipLaunchKernelGGL((skinny_splitk_kernel<4, 4>), grid, dim3(256), 0, s, p);
+  else if (p.K == 512) hipLaunchKernelGGL((skinny_splitk_kernel<8, 4>), grid, dim3(512), 0, s, p);
+  else if (p.K == 1024) hipLaunchKernelGGL((skinny_splitk_kernel<8, 8>), grid, dim3(512), 0, s, p);
+  else {
+    if (p.ln_g) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(skinny_generic_kernel, grid, dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Single-query multi-head attention for one decode step: one block (4 waves) per
+// (row, head).  K and V rows of a head are contiguous, so a wave-wide 16-B load
+// covers 64/(HD/4) whole keys: fully coalesced.  Each wave takes every 4th group of
+// keys, keeps a wave-local (max, sum, weighted V) triple and the four triples are
+// merged through LDS (log-sum-exp combine).  Self-attention mode appends this
+// step's k,v to the cache.  Replaces nn.MultiheadAttention inside
+// nn.TransformerDecoderLayer (tfm.py:130) for the newest position.
+// ---------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const DecAttnP p) {
+  constexpr int LPK = HD / 4;          // lanes per key
+  constexpr int KPI = 64 / LPK;        // keys per wave-iteration
+  constexpr int MAXIT = 512 / (KPI * 4);
+  __shared__ float w_m[4], w_s[4];
+  __shared__ __attribute__((aligned(16))) float w_acc[4][HD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kig = lane / LPK, ch = lane % LPK;
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  int L = p.L, t = -1;
+  if (p.step_ptr) { t = *p.step_ptr; L = t + 1; }
+  float* Kc = p.k + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
+  float* Vc = p.v + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
+  const float* curk = p.cur_k ? p.cur_k + (size_t)b * p.cur_stride + head * HD : nullptr;
+  const float* curv = p.cur_v ? p.cur_v + (size_t)b * p.cur_stride + head * HD : nullptr;
+  if (curk && t >= 0 && tid < HD) {  // append this step's k,v to the cache
+    Kc[(size_t)t * HD + tid] = curk[tid];
+    Vc[(size_t)t * HD + tid] = curv[tid];
+  }
+  const float4 q4 = *reinterpret_cast<const float4*>(p.q + (size_t)b * p.q_stride + head * HD + ch * 4);
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
+  const int nit = (L + KPI * 4 - 1) / (KPI * 4);  // iterations of this block (wave-uniform)
+
+  float sc[MAXIT];
+  float mloc = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    sc[it] = -INFINITY;
+    if (it < nit) {
+      const int j = (it * 4 + wave) * KPI + kig;
+      float d = 0.f;
+      if (j < L) {
+        const float* kr = (curk && j == t) ? curk : Kc + (size_t)j * HD;
+        const float4 k4 = *reinterpret_cast<const float4*>(kr + ch * 4);
+        d = (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+      }
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      if (j < L) {
+        sc[it] = d * scale;
+        mloc = fmaxf(mloc, sc[it]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o, 64));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    if (it < nit) {
+      const int j = (it * 4 + wave) * KPI + kig;
+      if (j < L) {
+        const float pj = expf(sc[it] - mloc);
+        const float* vr = (curv && j == t) ? curv : Vc + (size_t)j * HD;
+        const float4 v4 = *reinterpret_cast<const float4*>(vr + ch * 4);
+        ssum += pj;
+        acc.x = fmaf(pj, v4.x, acc.x); acc.y = fmaf(pj, v4.y, acc.y);
+        acc.z = fmaf(pj, v4.z, acc.z); acc.w = fmaf(pj, v4.w, acc.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    ssum += __shfl_xor(ssum, o, 64);
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (kig == 0) *reinterpret_cast<float4*>(&w_acc[wave][ch * 4]) = acc;
+  if (lane == 0) { w_m[wave] = mloc; w_s[wave] = ssum; }
+  __syncthreads();
+  if (tid < HD) {
+    const float m = fmaxf(fmaxf(w_m[0], w_m[1]), fmaxf(w_m[2], w_m[3]));
+    float tot = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = w_s[w] > 0.f ? expf(w_m[w] - m) : 0.f;  // waves without keys contribute nothing
+      tot += w_s[w] * f;
+      o += w_acc[w][tid] * f;
+    }
+    p.y[(size_t)b * p.y_stride + head * HD + tid] = o / tot;
+  }
+}
+
+hipError_t launch_decode_attention(const DecAttnP& p, hipStream_t s) {
+  const int Lcap = p.step_ptr ? p.Lmax : p.L;
+  if (Lcap > 512 || Lcap < 1) return hipErrorInvalidValue;
+  const dim3 grid(p.B * p.heads);
+  if (p.hd == 32) hipLaunchKernelGGL(decode_attention_kernel<32>, grid, dim3(256), 0, s, p);
+  else if (p.hd == 64) hipLaunchKernelGGL(decode_attention_kernel<64>, grid, dim3(256), 0, s, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// _embedd_tgt (tfm.py:86-94) for the newest position: Embedding * sqrt(d) + WordPosEnc row t.
+// ---------------------------------------------------------------------------
+__global__ void embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                             const int64_t* __restrict__ start, const int64_t* __restrict__ tokens, int tok_stride,
+                             const int* __restrict__ step_ptr, float* __restrict__ x, int d, float sqrt_d) {
+  const int b = blockIdx.x, t = *step_ptr;
+  const int64_t tok = t == 0 ? start[b] : tokens[(size_t)b * tok_stride + t - 1];
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    x[(size_t)b * d + c] = emb[(size_t)tok * d + c] * sqrt_d + pe[(size_t)t * d + c];
+}
+
+hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start, const int64_t* tokens,
+                        int tok_stride, const int* step_ptr, float* x, int B, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, emb, pe, start, tokens, tok_stride, step_ptr, x, d,
+                     sqrtf((float)d));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Greedy next token (tfm.py:134-139) for every row + the next step's input
+// embedding + step counter increment, one block.  First maximum wins ties;
+// end-of-sequence bookkeeping stays on the device.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_embed_kernel(const ArgmaxP p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = *p.step_ptr;
+  const float sqrt_d = sqrtf((float)p.d);
+  for (int b = wave; b < p.B; b += 4) {
+    const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < p.V; i += 64) {
+      const float v = row[i];
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi >= p.V) bi = 0;  // all-NaN row: keep indexing in range
+    if (lane == 0) {
+      p.tokens[(size_t)b * p.tok_stride + t] = bi;
+      if (bi == p.end_token && !p.ended[b]) {
+        p.ended[b] = 1;
+        const int c = atomicAdd(p.end_count, 1) + 1;
+        if (c == p.B) *p.steps_done = t + 1;
+      }
+    }
+    if (p.x) {
+      const float* e = p.emb + (size_t)bi * p.d;
+      const float* pe = p.pe + (size_t)(t + 1) * p.d;
+      for (int c = lane; c < p.d; c += 64) p.x[(size_t)b * p.d + c] = e[c] * sqrt_d + pe[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *p.step_ptr = t + 1;
+}
+
+hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_embed_kernel, dim3(1), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace d2t

@@ -638,7 +638,9 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
 // ---------------------------------------------------------------------------
 namespace {
 struct DecBufs {
-  float *x, *y, *x1, *x2, *qkv, *q2, *a, *f;
+  float *x;    // normalised layer input (x0 embedding, or LN3 of the previous layer)
+  float *y1, *x1, *y2, *x2, *y3;  // pre-LayerNorm sums y* and their normalised forms x*
+  float *qkv, *q2, *a, *f;
 };
 
 int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
@@ -647,27 +649,26 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   int rc;
   if ((rc = ensure(c, &c->ckv, &c->ckv_cap, (size_t)g.dec_layers * 2 * B * T * d * 4))) return rc;
   if ((rc = ensure(c, &c->skv, &c->skv_cap, (size_t)g.dec_layers * 2 * B * Lmax * d * 4))) return rc;
-  const size_t per = (size_t)B * (5 * d + 3 * d + d + g.dec_ff);
+  const size_t per = (size_t)B * (8 * d + 3 * d + g.dec_ff);
   if ((rc = ensure(c, &c->dws, &c->dws_cap, per * 4))) return rc;
   if ((rc = ensure(c, &c->dstate, &c->dstate_cap, (size_t)(4 + B) * 4))) return rc;
   float* p = c->dws;
-  bufs->x = p; p += (size_t)B * d;
-  bufs->y = p; p += (size_t)B * d;
-  bufs->x1 = p; p += (size_t)B * d;
-  bufs->x2 = p; p += (size_t)B * d;
-  bufs->q2 = p; p += (size_t)B * d;
+  float** six[] = {&bufs->x, &bufs->y1, &bufs->x1, &bufs->y2, &bufs->x2, &bufs->y3, &bufs->q2, &bufs->a};
+  for (float** q : six) { *q = p; p += (size_t)B * d; }
   bufs->qkv = p; p += (size_t)B * 3 * d;
-  bufs->a = p; p += (size_t)B * d;
   bufs->f = p;
   return D2T_OK;
 }
 
-hipError_t skinny(hipStream_t s, const float* x, int ldx, const LinW& w, const float* res, float* y, int ldy, int M,
-                  int act, const int* step_ptr = nullptr, long long step_stride = 0) {
+struct Lin { const float* x; int ldx; const LinW* w; const float* res; float* y; int ldy; int act; };
+
+hipError_t skinny(hipStream_t s, const Lin& l, int M, const LNW* ln = nullptr, float* ln_out = nullptr,
+                  const int* step_ptr = nullptr, long long step_stride = 0) {
   SkinnyP p{};
-  p.x = x; p.w = w.w; p.bias = w.b; p.res = res; p.y = y;
-  p.M = M; p.K = w.K; p.N = w.N; p.ldx = ldx; p.ldy = ldy; p.ldres = w.N; p.act = act;
+  p.x = l.x; p.w = l.w->w; p.bias = l.w->b; p.res = l.res; p.y = l.y;
+  p.M = M; p.K = l.w->K; p.N = l.w->N; p.ldx = l.ldx; p.ldy = l.ldy; p.ldres = l.w->N; p.act = l.act;
   p.step_ptr = step_ptr; p.out_step_stride = step_stride;
+  if (ln) { p.ln_g = ln->g; p.ln_b = ln->b; p.ln_eps = 1e-5f; p.ln_out = ln_out; }
   return launch_skinny(p, s);
 }
 
@@ -683,23 +684,30 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
   return launch_conv(p, s);
 }
 
-// one decode step for M rows (greedy: M = B).  All position-dependent values are
-// read from the device step counter so the launch sequence is graph-replayable.
-// shared_mem: cross K/V of sample 0 shared by every row (beam search, one sample).
+// One decode step for M rows up to the vocabulary logits (greedy: M = B rows).
+// bf.x holds the embedded input of this step.  Post-norm decoder layer
+// (nn.TransformerDecoderLayer, norm_first=False): every LayerNorm is evaluated as
+// the prologue of the GEMM that consumes it (which also writes the normalised rows
+// needed later as the residual), so a layer is 8 launches:
+//   qkv | self-attn | out-proj+res | [LN1] q-proj | cross-attn | out-proj+res | [LN2] ff1+ReLU | ff2+res
+// All position-dependent values come from the device step counter (graph-replayable).
+// shared_mem: cross K/V of sample 0 shared by every row (beam search over one sample).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
-                       const int64_t* start, int64_t* tokens, int tok_stride, float* logits, long long logit_row_stride,
-                       long long logit_step_stride) {
+                       float* logits, long long logit_row_stride, long long logit_step_stride) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
   hipError_t e;
-#define TRY(x) if ((e = (x)) != hipSuccess) return e
-  TRY(launch_embed(c->word_embed, c->word_pe, start, tokens, tok_stride, step, bf.x, M, d, s));
+#define TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
   const size_t skv_layer = (size_t)kvB * heads * Lmax * hd;
   const size_t ckv_slab = (size_t)(shared_mem ? 1 : kvB) * heads * T * hd;
   for (int l = 0; l < g.dec_layers; ++l) {
     const DecLayer& L = c->dec[l];
-    TRY(skinny(s, bf.x, d, L.sa_in, nullptr, bf.qkv, 3 * d, M, ACT_NONE));
+    if (l == 0) {
+      TRY(skinny(s, Lin{bf.x, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M));
+    } else {
+      TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x));
+    }
     DecAttnP a{};
     a.q = bf.qkv; a.q_stride = 3 * d;
     a.k = c->skv + (size_t)(2 * l) * skv_layer; a.v = c->skv + (size_t)(2 * l + 1) * skv_layer;
@@ -707,22 +715,20 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     a.y = bf.a; a.y_stride = d; a.B = M; a.heads = heads; a.hd = hd; a.Lmax = Lmax; a.step_ptr = step;
     a.kv_batch_stride = (long long)heads * Lmax * hd;
     TRY(launch_decode_attention(a, s));
-    TRY(skinny(s, bf.a, d, L.sa_out, bf.x, bf.y, d, M, ACT_NONE));
-    TRY(launch_layernorm(bf.y, L.n1.g, L.n1.b, bf.x1, M, d, 1e-5f, s));
-    TRY(skinny(s, bf.x1, d, L.ca_q, nullptr, bf.q2, d, M, ACT_NONE));
+    TRY(skinny(s, Lin{bf.a, d, &L.sa_out, bf.x, bf.y1, d, ACT_NONE}, M));
+    TRY(skinny(s, Lin{bf.y1, d, &L.ca_q, nullptr, bf.q2, d, ACT_NONE}, M, &L.n1, bf.x1));
     DecAttnP ca{};
     ca.q = bf.q2; ca.q_stride = d;
     ca.k = c->ckv + (size_t)(2 * l) * ckv_slab; ca.v = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
     ca.y = bf.a; ca.y_stride = d; ca.B = M; ca.heads = heads; ca.hd = hd; ca.Lmax = T; ca.L = T;
     ca.kv_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
     TRY(launch_decode_attention(ca, s));
-    TRY(skinny(s, bf.a, d, L.ca_out, bf.x1, bf.y, d, M, ACT_NONE));
-    TRY(launch_layernorm(bf.y, L.n2.g, L.n2.b, bf.x2, M, d, 1e-5f, s));
-    TRY(skinny(s, bf.x2, d, L.l1, nullptr, bf.f, g.dec_ff, M, ACT_RELU));
-    TRY(skinny(s, bf.f, g.dec_ff, L.l2, bf.x2, bf.y, d, M, ACT_NONE));
-    TRY(launch_layernorm(bf.y, L.n3.g, L.n3.b, bf.x, M, d, 1e-5f, s));
+    TRY(skinny(s, Lin{bf.a, d, &L.ca_out, bf.x1, bf.y2, d, ACT_NONE}, M));
+    TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2));
+    TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M));
   }
-  TRY(skinny(s, bf.x, d, c->out_proj, nullptr, logits, (int)logit_row_stride, M, ACT_NONE, step, logit_step_stride));
+  TRY(skinny(s, Lin{bf.y3, d, &c->out_proj, nullptr, logits, (int)logit_row_stride, ACT_NONE}, M,
+             &c->dec[g.dec_layers - 1].n3, nullptr, step, logit_step_stride));
 #undef TRY
   return hipSuccess;
 }
@@ -747,16 +753,19 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
   HIPCHK(c, hipMemsetAsync(c->dstate, 0, (size_t)(4 + B) * 4, s));
   HIPCHK(c, cross_kv(c, s, memory, B, T));
 
+  // step 0 input: Embedding([GO]) * sqrt(d) + pe[0]; later inputs are written by argmax_embed
+  HIPCHK(c, launch_embed(c->word_embed, c->word_pe, start_tokens, tokens, S, c->dstate, bf.x, B, g.dec_dim, s));
+
   ArgmaxP am{};
   am.logits = logits; am.row_stride = (long long)S * V; am.step_stride = V;
   am.tokens = tokens; am.tok_stride = S;
   am.ended = c->dstate + 4; am.end_count = c->dstate + 1; am.steps_done = c->dstate + 2; am.step_ptr = c->dstate;
   am.B = B; am.V = V; am.end_token = TOK_END;
+  am.emb = c->word_embed; am.pe = c->word_pe; am.x = bf.x; am.d = g.dec_dim;
   auto one_step = [&](hipStream_t st) -> hipError_t {
-    hipError_t e = decode_step(c, st, bf, B, T, B, false, start_tokens, tokens, S, logits, (long long)S * V, V);
+    hipError_t e = decode_step(c, st, bf, B, T, B, false, logits, (long long)S * V, V);
     if (e != hipSuccess) return e;
-    if ((e = launch_argmax(am, st)) != hipSuccess) return e;
-    return launch_step_inc(c->dstate, st);
+    return launch_argmax_embed(am, st);
   };
 
   const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;

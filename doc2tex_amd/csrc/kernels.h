@@ -43,6 +43,9 @@ struct SkinnyP {
   int act;
   const int* step_ptr;
   long long out_step_stride;
+  // optional LayerNorm prologue: the A operand is LN(x)*ln_g + ln_b over the K features of each row
+  // (K = 256 or 512 only).  ln_out, if set, receives the normalised rows [M][K] as a side output.
+  const float* ln_g; const float* ln_b; float ln_eps; float* ln_out;
 };
 hipError_t launch_skinny(const SkinnyP& p, hipStream_t s);
 
@@ -78,11 +81,12 @@ struct ArgmaxP {
   int* ended;       // [B]
   int* end_count;   // [1]
   int* steps_done;  // [1]: first t+1 at which all rows have ended (0 = not yet)
-  const int* step_ptr;
+  int* step_ptr;    // read at entry, incremented at exit
   int B, V, end_token;
+  // next-step embedding written by the same kernel: x[b] = emb[token]*sqrt(d) + pe[t+1]
+  const float* emb; const float* pe; float* x; int d;
 };
-hipError_t launch_argmax(const ArgmaxP& p, hipStream_t s);
-hipError_t launch_step_inc(int* step_ptr, hipStream_t s);
+hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s);
 
 // weight packing
 // OIHW (+ optional eval-BN) -> OHWI with the BN scale folded; bias_out = bn_b - mean*scale (+ conv bias*scale)

@@ -256,157 +256,6 @@ hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int he
 }
 
 // ---------------------------------------------------------------------------
-// Single-query multi-head attention for one decode step: one wave per (b, head).
-// Replaces nn.MultiheadAttention inside nn.TransformerDecoderLayer
-// (prediction_head/tfm.py:130) for the newest position only, with a KV cache.
-// ---------------------------------------------------------------------------
-constexpr int DA_MAXKPL = 8;  // keys per lane -> L <= 512
-
-template <int HD>
-__global__ __launch_bounds__(256) void decode_attention_kernel(const DecAttnP p) {
-  __shared__ float Ps[4][64 * DA_MAXKPL];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bh = blockIdx.x * 4 + wave;
-  if (bh >= p.B * p.heads) return;
-  const int b = bh / p.heads, head = bh % p.heads;
-  int L = p.L, t = -1;
-  if (p.step_ptr) { t = *p.step_ptr; L = t + 1; }
-  float* Kc = p.k + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
-  float* Vc = p.v + (size_t)b * p.kv_batch_stride + (size_t)head * p.Lmax * HD;
-  const float* curk = p.cur_k ? p.cur_k + (size_t)b * p.cur_stride + head * HD : nullptr;
-  const float* curv = p.cur_v ? p.cur_v + (size_t)b * p.cur_stride + head * HD : nullptr;
-  if (curk && t >= 0 && lane < HD) {  // append this step's k,v to the cache
-    Kc[(size_t)t * HD + lane] = curk[lane];
-    Vc[(size_t)t * HD + lane] = curv[lane];
-  }
-  const float* qp = p.q + (size_t)b * p.q_stride + head * HD;
-  float q[HD];
-#pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    const float4 v4 = *reinterpret_cast<const float4*>(qp + c * 4);
-    q[c * 4 + 0] = v4.x; q[c * 4 + 1] = v4.y; q[c * 4 + 2] = v4.z; q[c * 4 + 3] = v4.w;
-  }
-  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
-  float sc[DA_MAXKPL];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < DA_MAXKPL; ++i) {
-    const int j = lane + 64 * i;
-    float a = -INFINITY;
-    if (j < L) {
-      const float* kr = (curk && j == t) ? curk : Kc + (size_t)j * HD;
-      a = 0.f;
-#pragma unroll
-      for (int c = 0; c < HD / 4; ++c) {
-        const float4 k4 = *reinterpret_cast<const float4*>(kr + c * 4);
-        a = fmaf(q[c * 4 + 0], k4.x, a);
-        a = fmaf(q[c * 4 + 1], k4.y, a);
-        a = fmaf(q[c * 4 + 2], k4.z, a);
-        a = fmaf(q[c * 4 + 3], k4.w, a);
-      }
-      a *= scale;
-    }
-    sc[i] = a;
-    mx = fmaxf(mx, a);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  float* P = Ps[wave];
-#pragma unroll
-  for (int i = 0; i < DA_MAXKPL; ++i) {
-    const int j = lane + 64 * i;
-    if (j < L) {
-      const float e = expf(sc[i] - mx);
-      sum += e;
-      P[j] = e;
-    }
-  }
-  sum = wave_sum(sum);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-  constexpr int G = 64 / HD;           // key groups per wave
-  const int c = lane % HD, g = lane / HD;
-  float acc = 0.f;
-#pragma unroll 4
-  for (int j = g; j < L; j += G) {
-    const float* vr = (curv && j == t) ? curv : Vc + (size_t)j * HD;
-    acc = fmaf(P[j], vr[c], acc);
-  }
-  if (G == 2) acc += __shfl_xor(acc, 32, 64);
-  if (g == 0) p.y[(size_t)b * p.y_stride + head * HD + c] = acc / sum;
-}
-
-hipError_t launch_decode_attention(const DecAttnP& p, hipStream_t s) {
-  const int Lcap = p.step_ptr ? p.Lmax : p.L;
-  if (Lcap > 64 * DA_MAXKPL) return hipErrorInvalidValue;
-  const dim3 grid((p.B * p.heads + 3) / 4);
-  if (p.hd == 32) hipLaunchKernelGGL(decode_attention_kernel<32>, grid, dim3(256), 0, s, p);
-  else if (p.hd == 64) hipLaunchKernelGGL(decode_attention_kernel<64>, grid, dim3(256), 0, s, p);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// _embedd_tgt (prediction_head/tfm.py:86-94) for the newest position:
-// Embedding * sqrt(d) + WordPosEnc row t.
-// ---------------------------------------------------------------------------
-__global__ void embed_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
-                             const int64_t* __restrict__ start, const int64_t* __restrict__ tokens, int tok_stride,
-                             const int* __restrict__ step_ptr, float* __restrict__ x, int d, float sqrt_d) {
-  const int b = blockIdx.x, t = *step_ptr;
-  const int64_t tok = t == 0 ? start[b] : tokens[(size_t)b * tok_stride + t - 1];
-  for (int c = threadIdx.x; c < d; c += blockDim.x)
-    x[(size_t)b * d + c] = emb[(size_t)tok * d + c] * sqrt_d + pe[(size_t)t * d + c];
-}
-
-hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start, const int64_t* tokens,
-                        int tok_stride, const int* step_ptr, float* x, int B, int d, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, emb, pe, start, tokens, tok_stride, step_ptr, x, d,
-                     sqrtf((float)d));
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// Greedy next token (tfm.py:134-139): first maximum of the newest logits row,
-// end-of-sequence bookkeeping kept on the device.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void argmax_kernel(const ArgmaxP p) {
-  const int b = blockIdx.x, lane = threadIdx.x, t = *p.step_ptr;
-  const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = lane; i < p.V; i += 64) {
-    const float v = row[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
-  if (lane == 0) {
-    p.tokens[(size_t)b * p.tok_stride + t] = bi;
-    if (bi == p.end_token && !p.ended[b]) {
-      p.ended[b] = 1;
-      const int c = atomicAdd(p.end_count, 1) + 1;
-      if (c == p.B) *p.steps_done = t + 1;
-    }
-  }
-}
-
-hipError_t launch_argmax(const ArgmaxP& p, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_kernel, dim3(p.B), dim3(64), 0, s, p);
-  return hipGetLastError();
-}
-
-__global__ void step_inc_kernel(int* step) { *step += 1; }
-hipError_t launch_step_inc(int* step_ptr, hipStream_t s) {
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step_ptr);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // Weight packing: OIHW -> OHWI with eval-BatchNorm folded
 //   w'[o][kh][kw][c] = w[o][c][kh][kw] * s[o],  s = gamma / sqrt(var + eps)
 //   b'[o] = beta - mean * s  (+ conv_bias * s)
