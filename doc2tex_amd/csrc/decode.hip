@@ -331,45 +331,226 @@ hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start,
 // embedding + step counter increment, one block.  First maximum wins ties;
 // end-of-sequence bookkeeping stays on the device.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_embed_kernel(const ArgmaxP p) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64) void argmax_embed_kernel(const ArgmaxP p) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int t = *p.step_ptr;
-  const float sqrt_d = sqrtf((float)p.d);
-  for (int b = wave; b < p.B; b += 4) {
-    const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = lane; i < p.V; i += 64) {
-      const float v = row[i];
-      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-    }
+  const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < p.V; i += 64) {
+    const float v = row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (bi >= p.V) bi = 0;  // all-NaN row: keep indexing in range
+  if (p.x) {
+    const float sqrt_d = sqrtf((float)p.d);
+    const float* e = p.emb + (size_t)bi * p.d;
+    const float* pe = p.pe + (size_t)(t + 1) * p.d;
+    for (int c = lane; c < p.d; c += 64) p.x[(size_t)b * p.d + c] = e[c] * sqrt_d + pe[c];
+  }
+  if (lane == 0) {
+    p.tokens[(size_t)b * p.tok_stride + t] = bi;
+    if (bi == p.end_token && !p.ended[b]) {
+      p.ended[b] = 1;
+      const int c = atomicAdd(p.end_count, 1) + 1;
+      if (c == p.B) *p.steps_done = t + 1;
     }
-    if (bi >= p.V) bi = 0;  // all-NaN row: keep indexing in range
-    if (lane == 0) {
-      p.tokens[(size_t)b * p.tok_stride + t] = bi;
-      if (bi == p.end_token && !p.ended[b]) {
-        p.ended[b] = 1;
-        const int c = atomicAdd(p.end_count, 1) + 1;
-        if (c == p.B) *p.steps_done = t + 1;
-      }
-    }
-    if (p.x) {
-      const float* e = p.emb + (size_t)bi * p.d;
-      const float* pe = p.pe + (size_t)(t + 1) * p.d;
-      for (int c = lane; c < p.d; c += 64) p.x[(size_t)b * p.d + c] = e[c] * sqrt_d + pe[c];
+    // every block has read the step counter before it arrives here, so the
+    // last arriver may advance it (the kernel boundary publishes the store)
+    __threadfence();
+    if (atomicAdd(p.done_count, 1) == p.B - 1) {
+      *p.done_count = 0;
+      *p.step_ptr = t + 1;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) *p.step_ptr = t + 1;
 }
 
 hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_embed_kernel, dim3(1), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(argmax_embed_kernel, dim3(p.B), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Fused row kernel (see DecRowP).  512 threads = 8 waves = 8 heads.
+// ---------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ void row_attention(const float* q, const float* Kc, const float* Vc, const float* curk,
+                                              const float* curv, int t, int L, float* out, int lane) {
+  constexpr int LPK = HD / 4, KPI = 64 / LPK;
+  const int kig = lane / LPK, ch = lane % LPK;
+  const float4 q4 = *reinterpret_cast<const float4*>(q + ch * 4);
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
+  float m = -INFINITY, l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nit = (L + KPI - 1) / KPI;
+  constexpr int U = 4;  // key groups fetched together: 2*U 16-B loads in flight per lane
+  for (int it0 = 0; it0 < nit; it0 += U) {
+    float4 k4[U], v4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (it0 + u) * KPI + kig;
+      const int jj = j < L ? j : 0;
+      const float* kr = (curk && jj == t) ? curk : Kc + (size_t)jj * HD;
+      const float* vr = (curv && jj == t) ? curv : Vc + (size_t)jj * HD;
+      k4[u] = *reinterpret_cast<const float4*>(kr + ch * 4);
+      v4[u] = *reinterpret_cast<const float4*>(vr + ch * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (it0 + u) * KPI + kig;
+      float d = (q4.x * k4[u].x + q4.y * k4[u].y) + (q4.z * k4[u].z + q4.w * k4[u].w);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      if (j < L) {
+        const float sj = d * scale;
+        const float mn = fmaxf(m, sj);
+        const float f = expf(m - mn);  // exp(-inf) = 0 on the first key
+        const float pj = expf(sj - mn);
+        l = l * f + pj;
+        acc.x = acc.x * f + pj * v4[u].x; acc.y = acc.y * f + pj * v4[u].y;
+        acc.z = acc.z * f + pj * v4[u].z; acc.w = acc.w * f + pj * v4[u].w;
+        m = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {  // merge the key groups (log-sum-exp combine)
+    const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+    const float ax = __shfl_xor(acc.x, o, 64), ay = __shfl_xor(acc.y, o, 64);
+    const float az = __shfl_xor(acc.z, o, 64), aw = __shfl_xor(acc.w, o, 64);
+    const float mn = fmaxf(m, mo);
+    const float f1 = l > 0.f ? expf(m - mn) : 0.f, f2 = lo > 0.f ? expf(mo - mn) : 0.f;
+    l = l * f1 + lo * f2;
+    acc.x = acc.x * f1 + ax * f2; acc.y = acc.y * f1 + ay * f2;
+    acc.z = acc.z * f1 + az * f2; acc.w = acc.w * f1 + aw * f2;
+    m = mn;
+  }
+  if (kig == 0) {
+    const float inv = 1.f / l;
+    *reinterpret_cast<float4*>(out + ch * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+// out_part[g][n] = sum_{k in group g} in[k] * Wt[k][n]; caller reduces over g after a barrier
+template <int D>
+__device__ __forceinline__ void row_gemv(const float* in_s, const float* __restrict__ Wt, float* part_s, int tid) {
+  constexpr int LPR = D / 4, G = 512 / LPR, KG = D / G;
+  const int lr = tid % LPR, g = tid / LPR;
+  const float* w = Wt + (size_t)(g * KG) * D + lr * 4;
+  const float* in = in_s + g * KG;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 16
+  for (int k = 0; k < KG; ++k) {
+    const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
+    const float a = in[k];
+    acc.x = fmaf(a, w4.x, acc.x); acc.y = fmaf(a, w4.y, acc.y);
+    acc.z = fmaf(a, w4.z, acc.z); acc.w = fmaf(a, w4.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(part_s + g * D + lr * 4) = acc;
+}
+
+template <int D, int HD>
+__global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
+  constexpr int G = 512 / (D / 4);
+  __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D], part_s[G * D];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const int t = *p.step_ptr;
+  const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
+  // ---- self-attention, wave = head ----
+  {
+    float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)wave * p.s_Lmax * HD;
+    float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)wave * p.s_Lmax * HD;
+    const float* curk = qkv + D + wave * HD;
+    const float* curv = qkv + 2 * D + wave * HD;
+    if (lane < HD) {
+      Kc[(size_t)t * HD + lane] = curk[lane];
+      Vc[(size_t)t * HD + lane] = curv[lane];
+    }
+    row_attention<HD>(qkv + wave * HD, Kc, Vc, curk, curv, t, t + 1, a_s + wave * HD, lane);
+  }
+  __syncthreads();
+  row_gemv<D>(a_s, p.wo_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bo[tid] + p.xres[(size_t)b * D + tid];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[g * D + tid];
+    y_s[tid] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {  // LN1, two-pass, one wave
+    constexpr int V = D / 64;
+    float v[V], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = y_s[i * 64 + lane]; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.f / sqrtf(q * (1.f / D) + p.eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = i * 64 + lane;
+      x1_s[c] = v[i] * rstd * p.ln1_g[c] + p.ln1_b[c];
+    }
+  }
+  __syncthreads();
+  row_gemv<D>(x1_s, p.wq_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bq[tid];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[g * D + tid];
+    q2_s[tid] = v;
+  }
+  __syncthreads();
+  // ---- cross-attention over the memory K/V, wave = head ----
+  {
+    const float* Kc = p.ck + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
+    const float* Vc = p.cv + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
+    row_attention<HD>(q2_s + wave * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + wave * HD, lane);
+  }
+  __syncthreads();
+  row_gemv<D>(a_s, p.wco_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bco[tid] + x1_s[tid];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[g * D + tid];
+    p.y2[(size_t)b * D + tid] = v;
+  }
+}
+
+hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
+  if (p.heads != 8) return hipErrorInvalidValue;
+  if (p.D == 256) hipLaunchKernelGGL((decoder_row_kernel<256, 32>), dim3(p.M), dim3(512), 0, s, p);
+  else if (p.D == 512) hipLaunchKernelGGL((decoder_row_kernel<512, 64>), dim3(p.M), dim3(512), 0, s, p);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  const long long total = (long long)rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / rows), r = (int)(i % rows);
+    dst[i] = src[(size_t)r * cols + c];
+  }
+}
+hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s) {
+  const long long total = (long long)rows * cols;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256),
+                     0, s, src, dst, rows, cols);
   return hipGetLastError();
 }
 

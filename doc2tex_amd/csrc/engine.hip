@@ -49,6 +49,7 @@ struct VitBlock {
 struct DecLayer {
   LinW sa_in, sa_out, ca_q, ca_out, l1, l2;
   LNW n1, n2, n3;
+  float *sa_out_t = nullptr, *ca_q_t = nullptr, *ca_out_t = nullptr;  // [k][n] copies for the row kernel
 };
 struct Block {
   ConvW c1, c2, down;
@@ -365,6 +366,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   const int hd = cfg->dec_heads > 0 ? cfg->dec_dim / cfg->dec_heads : 0;
   if (cfg->dec_dim != 256 && cfg->dec_dim != 512) return fail(c, D2T_EINVAL, "decoder d_model must be 256 or 512");
   if (hd != 32 && hd != 64) return fail(c, D2T_EINVAL, "decoder head_dim must be 32 or 64");
+  if (cfg->dec_heads != 8) return fail(c, D2T_EINVAL, "decoder nhead must be 8");
   if (cfg->dec_ff % 64) return fail(c, D2T_EINVAL, "dim_feedforward must be a multiple of 64");
   if (cfg->max_seq_len + 2 > 512) return fail(c, D2T_EINVAL, "max_seq_len must be <= 510");
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
@@ -520,6 +522,14 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
         (rc = get_ln(c, l + "norm1", &dl.n1, d)) || (rc = get_ln(c, l + "norm2", &dl.n2, d)) ||
         (rc = get_ln(c, l + "norm3", &dl.n3, d)))
       return rc;
+    for (auto pr : {std::make_pair(&dl.sa_out_t, dl.sa_out.w), std::make_pair(&dl.ca_q_t, dl.ca_q.w),
+                    std::make_pair(&dl.ca_out_t, dl.ca_out.w)}) {
+      void* tp;
+      if ((rc = dev_alloc(c, &tp, (size_t)d * d * 4))) return rc;
+      c->owned.push_back(tp);
+      *pr.first = (float*)tp;
+      HIPCHK(c, launch_transpose(pr.second, *pr.first, d, d, s));
+    }
     c->dec.push_back(dl);
   }
   if ((rc = get_lin(c, pp + "proj", &c->out_proj, V, d))) return rc;
@@ -688,8 +698,9 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 // bf.x holds the embedded input of this step.  Post-norm decoder layer
 // (nn.TransformerDecoderLayer, norm_first=False): every LayerNorm is evaluated as
 // the prologue of the GEMM that consumes it (which also writes the normalised rows
-// needed later as the residual), so a layer is 8 launches:
-//   qkv | self-attn | out-proj+res | [LN1] q-proj | cross-attn | out-proj+res | [LN2] ff1+ReLU | ff2+res
+// needed later as the residual), so a layer is 4 launches:
+//   [LN3 prev] qkv GEMM | fused row kernel (self-attn, out-proj+res, LN1, q-proj, cross-attn, out-proj+res)
+//   | [LN2] ff1+ReLU GEMM | ff2+res GEMM
 // All position-dependent values come from the device step counter (graph-replayable).
 // shared_mem: cross K/V of sample 0 shared by every row (beam search over one sample).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
@@ -708,22 +719,17 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     } else {
       TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x));
     }
-    DecAttnP a{};
-    a.q = bf.qkv; a.q_stride = 3 * d;
-    a.k = c->skv + (size_t)(2 * l) * skv_layer; a.v = c->skv + (size_t)(2 * l + 1) * skv_layer;
-    a.cur_k = bf.qkv + d; a.cur_v = bf.qkv + 2 * d; a.cur_stride = 3 * d;
-    a.y = bf.a; a.y_stride = d; a.B = M; a.heads = heads; a.hd = hd; a.Lmax = Lmax; a.step_ptr = step;
-    a.kv_batch_stride = (long long)heads * Lmax * hd;
-    TRY(launch_decode_attention(a, s));
-    TRY(skinny(s, Lin{bf.a, d, &L.sa_out, bf.x, bf.y1, d, ACT_NONE}, M));
-    TRY(skinny(s, Lin{bf.y1, d, &L.ca_q, nullptr, bf.q2, d, ACT_NONE}, M, &L.n1, bf.x1));
-    DecAttnP ca{};
-    ca.q = bf.q2; ca.q_stride = d;
-    ca.k = c->ckv + (size_t)(2 * l) * ckv_slab; ca.v = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
-    ca.y = bf.a; ca.y_stride = d; ca.B = M; ca.heads = heads; ca.hd = hd; ca.Lmax = T; ca.L = T;
-    ca.kv_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
-    TRY(launch_decode_attention(ca, s));
-    TRY(skinny(s, Lin{bf.a, d, &L.ca_out, bf.x1, bf.y2, d, ACT_NONE}, M));
+    DecRowP r{};
+    r.qkv = bf.qkv; r.qkv_stride = 3 * d; r.xres = bf.x;
+    r.sk = c->skv + (size_t)(2 * l) * skv_layer; r.sv = c->skv + (size_t)(2 * l + 1) * skv_layer;
+    r.s_batch_stride = (long long)heads * Lmax * hd; r.s_Lmax = Lmax;
+    r.ck = c->ckv + (size_t)(2 * l) * ckv_slab; r.cv = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
+    r.c_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
+    r.T = T;
+    r.wo_t = L.sa_out_t; r.bo = L.sa_out.b; r.ln1_g = L.n1.g; r.ln1_b = L.n1.b; r.eps = 1e-5f;
+    r.wq_t = L.ca_q_t; r.bq = L.ca_q.b; r.wco_t = L.ca_out_t; r.bco = L.ca_out.b;
+    r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
+    TRY(launch_decoder_row(r, s));
     TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2));
     TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M));
   }
@@ -762,6 +768,7 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
   am.ended = c->dstate + 4; am.end_count = c->dstate + 1; am.steps_done = c->dstate + 2; am.step_ptr = c->dstate;
   am.B = B; am.V = V; am.end_token = TOK_END;
   am.emb = c->word_embed; am.pe = c->word_pe; am.x = bf.x; am.d = g.dec_dim;
+  am.done_count = c->dstate + 3;
   auto one_step = [&](hipStream_t st) -> hipError_t {
     hipError_t e = decode_step(c, st, bf, B, T, B, false, logits, (long long)S * V, V);
     if (e != hipSuccess) return e;

@@ -71,6 +71,28 @@ struct DecAttnP {
 };
 hipError_t launch_decode_attention(const DecAttnP& p, hipStream_t s);
 
+// Fused per-row middle of a post-norm decoder layer (one block per row, one wave per head):
+//   a  = SelfAttn(q,k,v of this step + cache)          (appends k,v to the cache)
+//   y1 = a @ Wo^T + bo + xres ;  x1 = LN1(y1)
+//   q2 = x1 @ Wq^T + bq ;  a2 = CrossAttn(q2, memory K/V)
+//   y2 = a2 @ Wco^T + bco + x1                          (written out, pre-LN2)
+// Weights are passed TRANSPOSED ([k][n], k-major) so GEMV reads are coalesced.
+struct DecRowP {
+  const float* qkv; int qkv_stride;   // [M][3D]
+  const float* xres;                  // [M][D]
+  float* sk; float* sv; long long s_batch_stride; int s_Lmax;
+  const float* ck; const float* cv; long long c_batch_stride; int T;
+  const float* wo_t; const float* bo;
+  const float* ln1_g; const float* ln1_b; float eps;
+  const float* wq_t; const float* bq;
+  const float* wco_t; const float* bco;
+  float* y2;                          // [M][D]
+  const int* step_ptr;
+  int M, D, heads;
+};
+hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
+hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
+
 // x[b] = emb[tok]*sqrt(d) + pe[t];  tok = (t == 0) ? start[b] : tokens[b*tok_stride + t - 1]
 hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start, const int64_t* tokens,
                         int tok_stride, const int* step_ptr, float* x, int B, int d, hipStream_t s);
@@ -81,7 +103,8 @@ struct ArgmaxP {
   int* ended;       // [B]
   int* end_count;   // [1]
   int* steps_done;  // [1]: first t+1 at which all rows have ended (0 = not yet)
-  int* step_ptr;    // read at entry, incremented at exit
+  int* step_ptr;    // read at entry, incremented by the last block to finish
+  int* done_count;  // [1] zero-initialised arrival counter (reset by the kernel)
   int B, V, end_token;
   // next-step embedding written by the same kernel: x[b] = emb[token]*sqrt(d) + pe[t+1]
   const float* emb; const float* pe; float* x; int d;
