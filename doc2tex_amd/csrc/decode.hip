@@ -25,22 +25,23 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // LayerNorm) is evaluated on the register-resident rows: two-pass mean / variance
 // with a cross-wave LDS reduction, so no standalone LayerNorm launch is needed.
 // ---------------------------------------------------------------------------
-template <int NW, int NCH>  // K == NW * NCH * 16
+template <int NW, int NCH, int MT>  // K == NW * NCH * 16; block tile (16*MT) rows x 16 columns
 __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p) {
   constexpr int KS = NCH * 16;
-  __shared__ float part[NW][64][17];
-  __shared__ float stat[NW][64];
-  __shared__ float s_mean[64], s_rstd[64];
+  constexpr int ROWS = 16 * MT;
+  __shared__ float part[NW][ROWS][17];
+  __shared__ float stat[NW][ROWS];
+  __shared__ float s_mean[ROWS], s_rstd[ROWS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
-  const int mbase = blockIdx.y * 64;
+  const int mbase = blockIdx.y * ROWS;
   const int n = blockIdx.x * 16 + r;
   const bool nok = n < p.N;
   const int k0 = wave * KS + q * 4;
 
-  float4 a[4][NCH], b[NCH];
+  float4 a[MT][NCH], b[NCH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int m = mbase + i * 16 + r;
     const bool mok = m < p.M;
     const float* src = p.x + (size_t)(mok ? m : 0) * p.ldx + k0;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
   if (p.ln_g) {
     const float invK = 1.f / (float)p.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       float s = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) s += (a[i][c].x + a[i][c].y) + (a[i][c].z + a[i][c].w);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
       if (q == 0) stat[wave][i * 16 + r] = s;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < ROWS) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += stat[w][tid];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const float mu = s_mean[i * 16 + r];
       float s = 0.f;
 #pragma unroll
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
       if (q == 0) stat[wave][i * 16 + r] = s;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < ROWS) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += stat[w][tid];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
       const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + k0 + c * 16);
       const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + k0 + c * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const float rs = s_rstd[i * 16 + r];
         a[i][c].x = a[i][c].x * rs * g4.x + b4.x;
         a[i][c].y = a[i][c].y * rs * g4.y + b4.y;
@@ -114,13 +115,13 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
     }
   }
 
-  f32x4 acc[4];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].x, b[c].x, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].y, b[c].y, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][c].z, b[c].z, acc[i], 0, 0, 0);
@@ -129,14 +130,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
   }
   // C/D map: col = lane&15 -> n, row = (lane>>4)*4 + reg -> m
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) part[wave][i * 16 + q * 4 + reg][r] = acc[i][reg];
   __syncthreads();
 
   float* y = p.y;
   if (p.step_ptr) y += (long long)(*p.step_ptr) * p.out_step_stride;
-  for (int idx = tid; idx < 64 * 16; idx += NW * 64) {
+  for (int idx = tid; idx < ROWS * 16; idx += NW * 64) {
     const int row = idx >> 4, col = idx & 15;
     const int m = mbase + row, nn = blockIdx.x * 16 + col;
     if (m >= p.M || nn >= p.N) continue;
@@ -192,14 +193,22 @@ __global__ __launch_bounds__(256) void skinny_generic_kernel(const SkinnyP p) {
 hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % 16 != 0 || p.ldx % 4 != 0) return hipErrorInvalidValue;
-  const dim3 grid((p.N + 15) / 16, (p.M + 63) / 64);
-  if (p.K == 256) hipLaunchKernelGGL((skinny_splitk_kernel<4, 4>), grid, dim3(256), 0, s, p);
-  else if (p.K == 512) hipLaunchKernelGGL((skinny_splitk_kernel<8, 4>), grid, dim3(512), 0, s, p);
-  else if (p.K == 1024) hipLaunchKernelGGL((skinny_splitk_kernel<8, 8>), grid, dim3(512), 0, s, p);
+  // narrow outputs (N <= 512) take 16-row tiles so that the few column tiles still fill >= 64 CUs
+  const int mt = p.N <= 512 ? 1 : 2;
+  const dim3 grid((p.N + 15) / 16, (p.M + 16 * mt - 1) / (16 * mt));
+#define D2T_SK(NW, NCH)                                                                                  \
+  do {                                                                                                   \
+    if (mt == 1) hipLaunchKernelGGL((skinny_splitk_kernel<NW, NCH, 1>), grid, dim3(NW * 64), 0, s, p);   \
+    else hipLaunchKernelGGL((skinny_splitk_kernel<NW, NCH, 2>), grid, dim3(NW * 64), 0, s, p);           \
+  } while (0)
+  if (p.K == 256) D2T_SK(4, 4);
+  else if (p.K == 512) D2T_SK(8, 4);
+  else if (p.K == 1024) D2T_SK(8, 8);
   else {
     if (p.ln_g) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(skinny_generic_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(skinny_generic_kernel, dim3((p.N + 15) / 16, (p.M + 63) / 64), dim3(256), 0, s, p);
   }
+#undef D2T_SK
   return hipGetLastError();
 }
 
@@ -379,7 +388,7 @@ hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // Fused row kernel (see DecRowP).  512 threads = 8 waves = 8 heads.
 // ---------------------------------------------------------------------------
-template <int HD>
+template <int HD, int U>  // U key groups fetched together: 2*U 16-B loads in flight per lane
 __device__ __forceinline__ void row_attention(const float* q, const float* Kc, const float* Vc, const float* curk,
                                               const float* curv, int t, int L, float* out, int lane) {
   constexpr int LPK = HD / 4, KPI = 64 / LPK;
@@ -389,7 +398,6 @@ __device__ __forceinline__ void row_attention(const float* q, const float* Kc, c
   float m = -INFINITY, l = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int nit = (L + KPI - 1) / KPI;
-  constexpr int U = 4;  // key groups fetched together: 2*U 16-B loads in flight per lane
   for (int it0 = 0; it0 < nit; it0 += U) {
     float4 k4[U], v4[U];
 #pragma unroll
@@ -445,7 +453,7 @@ __device__ __forceinline__ void row_gemv(const float* in_s, const float* __restr
   const float* w = Wt + (size_t)(g * KG) * D + lr * 4;
   const float* in = in_s + g * KG;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
+#pragma unroll
   for (int k = 0; k < KG; ++k) {
     const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
     const float a = in[k];
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
       Kc[(size_t)t * HD + lane] = curk[lane];
       Vc[(size_t)t * HD + lane] = curv[lane];
     }
-    row_attention<HD>(qkv + wave * HD, Kc, Vc, curk, curv, t, t + 1, a_s + wave * HD, lane);
+    row_attention<HD, 4>(qkv + wave * HD, Kc, Vc, curk, curv, t, t + 1, a_s + wave * HD, lane);
   }
   __syncthreads();
   row_gemv<D>(a_s, p.wo_t, part_s, tid);
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
   {
     const float* Kc = p.ck + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
     const float* Vc = p.cv + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
-    row_attention<HD>(q2_s + wave * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + wave * HD, lane);
+    row_attention<HD, 8>(q2_s + wave * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + wave * HD, lane);
   }
   __syncthreads();
   row_gemv<D>(a_s, p.wco_t, part_s, tid);
