@@ -548,6 +548,105 @@ hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Beam search device side (reference: tfm.py:145-186 runs the model, tools/beam.py:68-105
+// does log_softmax + flat top-k on the host).
+// ---------------------------------------------------------------------------
+__global__ void embed_tokens_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
+                                    const int64_t* __restrict__ tok, const int* __restrict__ step_ptr,
+                                    float* __restrict__ x, int d, float sqrt_d) {
+  const int b = blockIdx.x, t = *step_ptr;
+  const int64_t tk = tok[b];
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    x[(size_t)b * d + c] = emb[(size_t)tk * d + c] * sqrt_d + pe[(size_t)t * d + c];
+}
+hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t* tok, const int* step_ptr, float* x,
+                               int M, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(256), 0, s, emb, pe, tok, step_ptr, x, d, sqrtf((float)d));
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits,
+                                                        const float* __restrict__ scores, int M, int V, int k,
+                                                        float* __restrict__ topv, int* __restrict__ topi) {
+  __shared__ float s_lse[16];
+  __shared__ float r_v[4];
+  __shared__ int r_i[4];
+  __shared__ float sel_v;
+  __shared__ int sel_i;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // log-sum-exp of every row (F.log_softmax, tfm.py:169)
+  for (int i = wave; i < M; i += 4) {
+    const float* row = logits + (size_t)i * V;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, row[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += expf(row[v] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_lse[i] = mx + logf(sum);
+  }
+  __syncthreads();
+  const int total = M * V;
+  float last_v = INFINITY;
+  int last_i = -1;
+  for (int sel = 0; sel < k; ++sel) {
+    // best candidate strictly after (last_v, last_i) in (value desc, index asc) order
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int i = idx / V;
+      const float c = scores[i] + (logits[idx] - s_lse[i]);
+      const bool after = c < last_v || (c == last_v && idx > last_i);
+      if (after && (c > bv || (c == bv && idx < bi))) { bv = c; bi = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { r_v[wave] = bv; r_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (r_v[w] > bv || (r_v[w] == bv && r_i[w] < bi)) { bv = r_v[w]; bi = r_i[w]; }
+      sel_v = bv; sel_i = bi;
+      topv[sel] = bv; topi[sel] = bi;
+    }
+    __syncthreads();
+    last_v = sel_v; last_i = sel_i;
+    __syncthreads();
+  }
+}
+hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
+                            hipStream_t s) {
+  if (M < 1 || M > 16 || k < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(256), 0, s, logits, scores, M, V, k, topv, topi);
+  return hipGetLastError();
+}
+
+__global__ void cache_gather_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    const int* __restrict__ prev, int cap, int M, int heads, int Lmax, int hd,
+                                    int rows) {
+  // grid: (slab, i, head); copies rows*hd contiguous floats
+  const int slab = blockIdx.x, i = blockIdx.y, h = blockIdx.z;
+  const size_t per_row = (size_t)heads * Lmax * hd;
+  const float* s = src + ((size_t)slab * cap + prev[i]) * per_row + (size_t)h * Lmax * hd;
+  float* d = dst + ((size_t)slab * cap + i) * per_row + (size_t)h * Lmax * hd;
+  const int n4 = rows * hd / 4;
+  for (int c = threadIdx.x; c < n4; c += blockDim.x)
+    reinterpret_cast<float4*>(d)[c] = reinterpret_cast<const float4*>(s)[c];
+}
+hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, int slabs, int cap, int M, int heads,
+                               int Lmax, int hd, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(cache_gather_kernel, dim3(slabs, M, heads), dim3(256), 0, s, src, dst, prev, cap, M, heads, Lmax,
+                     hd, rows);
+  return hipGetLastError();
+}
+
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
   const long long total = (long long)rows * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

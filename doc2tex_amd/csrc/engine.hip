@@ -4,6 +4,7 @@
 // path and no fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -94,6 +95,9 @@ struct d2t_ctx {
   // decoder state
   float* ckv = nullptr; size_t ckv_cap = 0;
   float* skv = nullptr; size_t skv_cap = 0;
+  float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
+  float* skv_cur = nullptr;                          // cache decode_step reads / appends
+  float* beam_ws = nullptr; size_t beam_ws_cap = 0;  // beam logits / scores / tokens / top-k
   float* dws = nullptr; size_t dws_cap = 0;
   int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]
   size_t dstate_cap = 0;
@@ -386,6 +390,8 @@ void d2t_destroy(d2t_ctx* c) {
   for (int i = 0; i < 4; ++i) if (c->act[i]) hipFree(c->act[i]);
   if (c->ckv) hipFree(c->ckv);
   if (c->skv) hipFree(c->skv);
+  if (c->skv_alt) hipFree(c->skv_alt);
+  if (c->beam_ws) hipFree(c->beam_ws);
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -721,7 +727,7 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     }
     DecRowP r{};
     r.qkv = bf.qkv; r.qkv_stride = 3 * d; r.xres = bf.x;
-    r.sk = c->skv + (size_t)(2 * l) * skv_layer; r.sv = c->skv + (size_t)(2 * l + 1) * skv_layer;
+    r.sk = c->skv_cur + (size_t)(2 * l) * skv_layer; r.sv = c->skv_cur + (size_t)(2 * l + 1) * skv_layer;
     r.s_batch_stride = (long long)heads * Lmax * hd; r.s_Lmax = Lmax;
     r.ck = c->ckv + (size_t)(2 * l) * ckv_slab; r.cv = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
     r.c_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
@@ -753,6 +759,7 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
   DecBufs bf;
   int rc = dec_prepare(c, B, T, &bf);
   if (rc) return rc;
+  c->skv_cur = c->skv;
   // order the internal stream after the caller's work (memory, start tokens)
   HIPCHK(c, hipEventRecord(c->ev_in, user));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev_in, 0));
@@ -811,8 +818,123 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
 
 int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
                     float* score_out, d2t_stream stream) {
-  (void)memory; (void)T; (void)beam_size; (void)seq_out; (void)len_out; (void)score_out; (void)stream;
-  return fail(c, D2T_EINVAL, "beam decode is not implemented in this build");
+  // TransformerPrediction.forward_beam (tfm.py:145-186) with tools/beam.py:38-140 bookkeeping on the
+  // host; a fresh beam per call (demo reset_beam semantics).  The model runs KV-cached on
+  // the device for the live hypotheses only; log_softmax + flat top-k run on the device too, so each
+  // step moves k <= beam_size (value, index) pairs to the host instead of the [hyp, V] log-prob matrix.
+  if (!c || !memory || !seq_out || !len_out || !score_out || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  const d2t_config& g = c->cfg;
+  const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = beam_size;
+  const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
+  if ((long long)cap * V > 16 * 4096) return fail(c, D2T_EINVAL, "beam_size * vocab too large");
+  hipStream_t user = (hipStream_t)stream, s = c->dstream;
+  DecBufs bf;
+  int rc = dec_prepare(c, cap, T, &bf);
+  if (rc) return rc;
+  const size_t skv_bytes = (size_t)g.dec_layers * 2 * cap * Lmax * d * 4;
+  if ((rc = ensure(c, &c->skv_alt, &c->skv_alt_cap, skv_bytes))) return rc;
+  // beam workspace: logits [cap][V] | scores [cap] | topv [cap] | tok [cap] i64 | topi [cap] | prev [cap]
+  const size_t ws_bytes = ((size_t)cap * V + 2 * cap) * 4 + (size_t)cap * 8 + 2 * (size_t)cap * 4 + 64;
+  if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, ws_bytes))) return rc;
+  float* d_logits = c->beam_ws;
+  float* d_scores = d_logits + (size_t)cap * V;
+  float* d_topv = d_scores + cap;
+  const size_t tok_off = ((size_t)cap * V + 2 * (size_t)cap + 1) & ~(size_t)1;  // 8-byte aligned
+  int64_t* d_tok = reinterpret_cast<int64_t*>(d_logits + tok_off);
+  int* d_topi = reinterpret_cast<int*>(d_tok + cap);
+  int* d_prev = d_topi + cap;
+  // pinned host mirror: [0]=step | tok i64[cap] | scores[cap] | topv[cap] | topi[cap] | prev[cap]
+  static_assert(sizeof(int64_t) == 8, "");
+  char* hp = nullptr;
+  const size_t hbytes = 16 + (size_t)cap * (8 + 4 * 4);
+  if (hipHostMalloc(reinterpret_cast<void**>(&hp), hbytes, hipHostMallocDefault) != hipSuccess)
+    return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
+  int* h_step = reinterpret_cast<int*>(hp);
+  int64_t* h_tok = reinterpret_cast<int64_t*>(hp + 16);
+  float* h_scores = reinterpret_cast<float*>(hp + 16 + (size_t)cap * 8);
+  float* h_topv = h_scores + cap;
+  int* h_topi = reinterpret_cast<int*>(h_topv + cap);
+  int* h_prev = h_topi + cap;
+  auto done = [&](int code) { hipHostFree(hp); return code; };
+#define BCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return done(fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+
+  BCHK(hipEventRecord(c->ev_in, user));
+  BCHK(hipStreamWaitEvent(s, c->ev_in, 0));
+  BCHK(hipMemsetAsync(c->dstate, 0, (size_t)(4 + cap) * 4, s));
+  BCHK(cross_kv(c, s, memory, 1, T));
+  c->skv_cur = c->skv;
+  float* skv_other = c->skv_alt;
+
+  struct Hyp { std::vector<int64_t> seq; float score; };  // seq without the leading [GO]
+  std::vector<Hyp> hyps(1), completed;
+  hyps[0].score = 0.f;
+  int64_t last_tok[16];
+  last_tok[0] = TOK_GO;
+  for (int step = 0; step < S; ++step) {
+    const int M = (int)hyps.size();
+    *h_step = step;
+    for (int i = 0; i < M; ++i) { h_tok[i] = last_tok[i]; h_scores[i] = hyps[i].score; }
+    BCHK(hipMemcpyAsync(c->dstate, h_step, 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)M * 8, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)M * 4, hipMemcpyHostToDevice, s));
+    BCHK(launch_embed_tokens(c->word_embed, c->word_pe, d_tok, c->dstate, bf.x, M, d, s));
+    BCHK(decode_step(c, s, bf, M, T, cap, true, d_logits, V, 0));
+    const int live = beam_size - (int)completed.size();
+    BCHK(launch_beam_topk(d_logits, d_scores, M, V, live, d_topv, d_topi, s));
+    BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)live * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)live * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    // Beam.advance (tools/beam.py:68-105)
+    std::vector<Hyp> next;
+    int nprev = 0;
+    for (int r = 0; r < live; ++r) {
+      const int prev = h_topi[r] / V, word = h_topi[r] % V;
+      Hyp h;
+      h.seq = hyps[prev].seq;
+      h.seq.push_back(word);
+      h.score = h_topv[r];
+      if (word == TOK_END) {
+        completed.push_back(std::move(h));
+      } else {
+        last_tok[nprev] = word;
+        h_prev[nprev++] = prev;
+        next.push_back(std::move(h));
+      }
+    }
+    if ((int)completed.size() == beam_size) { hyps.swap(next); break; }  // Beam.done, tfm.py:175-176
+    hyps.swap(next);
+    if (step + 1 < S) {  // reorder the self-attention caches to the surviving hypotheses
+      BCHK(hipMemcpyAsync(d_prev, h_prev, (size_t)nprev * 4, hipMemcpyHostToDevice, s));
+      BCHK(launch_cache_gather(c->skv_cur, skv_other, d_prev, g.dec_layers * 2, cap, nprev, heads, Lmax, hd, step + 1,
+                               s));
+      std::swap(c->skv_cur, skv_other);
+    }
+  }
+  BCHK(hipStreamSynchronize(s));
+#undef BCHK
+  if (completed.empty()) {  // Beam.set_hypothesis (beam.py:132-140): hypotheses[0, 1:] incl. trailing [PAD]s
+    Hyp h = hyps.empty() ? Hyp{} : hyps[0];
+    h.seq.resize((size_t)g.max_seq_len + 1, TOK_PAD);
+    completed.push_back(std::move(h));
+  }
+  size_t best = 0;
+  for (size_t i = 1; i < completed.size(); ++i)
+    if ((double)completed[i].score / (double)std::max<size_t>(1, completed[i].seq.size()) >
+        (double)completed[best].score / (double)std::max<size_t>(1, completed[best].seq.size()))
+      best = i;
+  const Hyp& bh = completed[best];
+  const int n = (int)std::min<size_t>(bh.seq.size(), (size_t)S);
+  for (int i = 0; i < n; ++i) seq_out[i] = bh.seq[i];
+  *len_out = n;
+  *score_out = bh.score;
+  return done(D2T_OK);
 }
 
 int d2t_profile_enable(d2t_ctx* c, int32_t on) {

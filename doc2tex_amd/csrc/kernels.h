@@ -111,6 +111,19 @@ struct ArgmaxP {
 };
 hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s);
 
+// ---- beam search helpers (tools/beam.py semantics, one sample) ----
+// x[i] = emb[tok[i]]*sqrt(d) + pe[*step]
+hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t* tok, const int* step_ptr, float* x,
+                               int M, int d, hipStream_t s);
+// cand[i*V+v] = score[i] + log_softmax(logits[i])[v]; the k best (value desc, flat index asc on ties)
+// are written to topv[k], topi[k].  One block; M*V <= 16 * 4096.
+hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
+                            hipStream_t s);
+// dst[slab][i][...] = src[slab][prev[i]][...] for the first `rows` positions of every head
+// (self-attention KV cache reorder after a beam step); caches are [slabs][cap][heads][Lmax][hd].
+hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, int slabs, int cap, int M, int heads,
+                               int Lmax, int hd, int rows, hipStream_t s);
+
 // weight packing
 // OIHW (+ optional eval-BN) -> OHWI with the BN scale folded; bias_out = bn_b - mean*scale (+ conv bias*scale)
 hipError_t launch_pack_conv(const float* w_oihw, const float* conv_bias, const float* bn_w, const float* bn_b,

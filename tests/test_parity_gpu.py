@@ -107,3 +107,41 @@ def test_headline_shape_properties(cases):
     assert torch.isfinite(logits).all()
     assert np.array_equal(preds[:2].numpy(), z["tokens"])
     assert torch.equal(preds, logits.argmax(-1))  # tokens are the argmax of the returned logits
+
+
+@pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish"])
+def test_beam_vs_reference_fixture(cases, name):
+    """forward_beam + Beam (tfm.py:145-186, tools/beam.py) for one sample: the best
+    hypothesis' token ids are exact and its score is within 1e-3."""
+    c = _case(cases, "beam", name)
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c["beam_size"])
+    img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((1, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        seq, score, _ = m(img, text, is_train=False, is_test=True)
+        seq2, score2, _ = m(img, text, is_train=False, is_test=True)  # fresh beam state per call
+    assert seq.shape[0] == 1 and seq[0].tolist() == c["seq"], (seq, c["seq"])
+    assert abs(score - c["score"]) <= 1e-3, (score, c["score"])
+    assert torch.equal(seq, seq2) and score == score2
+
+
+def test_beam_vs_oracle_other_seeds(cases, manifests):
+    c = _case(cases, "beam", "t2_beam5")
+    for iseed, eb in [(501, 1.8), (502, 1.75), (503, 0.0)]:
+        cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], eb, beam_size=5)
+        ocfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], eb)
+        ocfg["beam_size"] = 5
+        img = synth.synth_images(1, c["H"], c["W"], seed=iseed)
+        text = torch.full((1, 1), R.GO, dtype=torch.long)
+        with torch.no_grad():
+            seq, score, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=True)
+            oseq, oscore, _ = R.forward(ocfg, sd, img, text, is_test=True)
+        assert seq[0].tolist() == oseq[0].tolist(), (iseed, eb)
+        assert abs(score - oscore) <= 1e-3
+
+
+def test_beam_rejects_batches():
+    cfg, m = engine_model("T2", 8, beam_size=3)
+    img = synth.synth_images(2, 48, 64).cuda()
+    with pytest.raises(AssertionError):  # tfm.py:146-148
+        m(img, torch.ones(2, 1, dtype=torch.long, device="cuda"), is_train=False, is_test=True)
