@@ -54,6 +54,18 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/rNN_pmc_dominant_kernel.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant_kernel.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        pm = json.load(f)
+    return pm.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -165,10 +177,12 @@ def main():
         dom_ms = sum(by_shape[dom]) / len(by_shape[dom])
         dom_flop = 2.0 * dom[0] * dom[1] * dom[2]
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         roofline = {
             "bound": "mfma", "kernel": "conv_mfma_kernel<128,128> (512->512 3x3 conv @16x129 as implicit GEMM)",
             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "traffic_source": traffic_src,
             "gemm_MNK": list(dom), "flop_per_launch": dom_flop, "avg_launch_ms": round(dom_ms, 4),
             "launches_timed": len(by_shape[dom]),
             "share_of_gemm_time": round(sum(by_shape[dom]) / total_ms, 4),
