@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish each batch's decode before the next batch's encoder starts")
     ap.add_argument("--cpu-sample", type=int, default=4)
     args = ap.parse_args()
 
@@ -131,6 +133,7 @@ def main():
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.eval().to(dev)
+    model.pipelined = not args.no_pipeline  # decode of batch i overlaps the encoder of batch i+1
     img = synth.synth_images(B, H, W, seed=1000 + rank).to(dev)  # each rank its own shard
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
 
@@ -140,6 +143,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    model.synchronize()
     if rank == 0:
         log(f"warm-up done ({args.warmup} steps)")
     eng = model.engine()
@@ -151,6 +155,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    model.synchronize()  # every batch fully decoded
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -203,7 +208,8 @@ def main():
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
-                       "parallelism": f"dp{world} (batch-sharded, no collective)"},
+                       "parallelism": f"dp{world} (batch-sharded, no collective)",
+                       "pipelined": bool(model.pipelined)},
             "algorithmic_gflop_per_formula": round(algo / 1e9, 2),
             "e2e_tflops": round(algo * formulas / elapsed / 1e12, 2),
             "roofline": roofline,

@@ -34,6 +34,8 @@ SIGNATURES = {
     "d2t_encoder_shape": (_I, [_P, _I, _I] + [C.POINTER(_I)] * 6),
     "d2t_encode": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "d2t_decode_greedy": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, C.POINTER(_I), _P]),
+    "d2t_decode_greedy_async": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
+    "d2t_decode_wait": (_I, [_P, _P, _I]),
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_profile_enable": (_I, [_P, _I]),
     "d2t_profile_read": (_I, [_P, _I, C.POINTER(_I)] + [C.POINTER(_I)] * 3 + [C.POINTER(C.c_float)]),

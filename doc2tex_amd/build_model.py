@@ -93,6 +93,15 @@ class Model(nn.Module):
         self.seqmodeler = SeqModelingBuilder(stages, opt, getattr(self.featextractor, "FeatureExtraction_output", None))
         self.predicter = PredictBuilder(stages, opt, getattr(self.seqmodeler, "SequenceModeling_output", None))
         self._engine = None
+        # Opt-in software pipelining across consecutive forward() calls (eval, greedy, is_test=False):
+        # forward returns while the latency-bound decode loop still runs on the engine's stream, so the
+        # next batch's encoder overlaps it.  Results are valid after synchronize().
+        self.pipelined = False
+
+    def synchronize(self, host_sync=True):
+        """Order the current stream (and optionally the host) after every outstanding pipelined decode."""
+        if self._engine is not None:
+            self._engine.decode_wait(host_sync=host_sync)
 
     # -- engine plumbing -----------------------------------------------------
     def engine(self):
@@ -129,7 +138,10 @@ class Model(nn.Module):
         else:
             if text.dim() != 2 or text.shape[1] != 1:
                 raise ValueError("eval decoding expects text = [B,1] start tokens ([GO])")
-            prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
+            if self.pipelined and not is_test:
+                prediction, logits = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0])
+            else:
+                prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
         return prediction, logits, None, {}
 
     def forward(self, input, text, is_train=True, is_test=False, rtl_text=None):

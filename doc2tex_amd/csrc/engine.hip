@@ -93,7 +93,11 @@ struct d2t_ctx {
   size_t act_cap = 0;
   std::map<std::pair<int, int>, float*> pe2d;  // PositionalEncoding2D crops [h*w][C]
   // decoder state
-  float* ckv = nullptr; size_t ckv_cap = 0;
+  float* ckv2[2] = {nullptr, nullptr}; size_t ckv2_cap[2] = {0, 0};  // cross K/V, double-buffered across decodes
+  float* ckv = nullptr;                                              // the slot the current decode reads
+  hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
+  bool ev_done_valid[2] = {false, false};
+  unsigned decode_seq = 0;
   float* skv = nullptr; size_t skv_cap = 0;
   float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
@@ -104,8 +108,9 @@ struct d2t_ctx {
   int* h_pinned = nullptr;
   hipStream_t dstream = nullptr;
   hipEvent_t ev_in = nullptr;
-  hipGraphExec_t graph = nullptr;
-  struct GraphKey { int B, T; const void* tok; const void* logits; const void* start; const void* mem; } gkey{};
+  struct GraphKey { int B, T; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
+  struct GraphEnt { GraphKey key; hipGraphExec_t exec; };
+  std::vector<GraphEnt> graphs;  // small cache of captured decode steps (most recent last)
   // kernel timing log (d2t_profile_*)
   bool profiling = false;
   struct ProfRec { int M, N, K; hipEvent_t a, b; };
@@ -376,6 +381,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault));
   return D2T_OK;
 }
@@ -383,12 +389,16 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
 void d2t_destroy(d2t_ctx* c) {
   if (!c) return;
   hipDeviceSynchronize();
-  if (c->graph) hipGraphExecDestroy(c->graph);
+  for (auto& ge : c->graphs) hipGraphExecDestroy(ge.exec);
+  c->graphs.clear();
   free_packed(c);
   for (auto& kv : c->raw) hipFree(kv.second.p);
   for (auto& kv : c->pe2d) hipFree(kv.second);
   for (int i = 0; i < 4; ++i) if (c->act[i]) hipFree(c->act[i]);
-  if (c->ckv) hipFree(c->ckv);
+  for (int i = 0; i < 2; ++i) {
+    if (c->ckv2[i]) hipFree(c->ckv2[i]);
+    if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
+  }
   if (c->skv) hipFree(c->skv);
   if (c->skv_alt) hipFree(c->skv_alt);
   if (c->beam_ws) hipFree(c->beam_ws);
@@ -426,7 +436,8 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
   if (!c) return D2T_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipDeviceSynchronize();
-  if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+  for (auto& ge : c->graphs) hipGraphExecDestroy(ge.exec);
+  c->graphs.clear();
   free_packed(c);
   const d2t_config& g = c->cfg;
   int rc;
@@ -663,7 +674,9 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, Lmax = g.max_seq_len + 2;
   int rc;
-  if ((rc = ensure(c, &c->ckv, &c->ckv_cap, (size_t)g.dec_layers * 2 * B * T * d * 4))) return rc;
+  for (int i = 0; i < 2; ++i)
+    if ((rc = ensure(c, &c->ckv2[i], &c->ckv2_cap[i], (size_t)g.dec_layers * 2 * B * T * d * 4))) return rc;
+  if (!c->ckv) c->ckv = c->ckv2[0];
   if ((rc = ensure(c, &c->skv, &c->skv_cap, (size_t)g.dec_layers * 2 * B * Lmax * d * 4))) return rc;
   const size_t per = (size_t)B * (8 * d + 3 * d + g.dec_ff);
   if ((rc = ensure(c, &c->dws, &c->dws_cap, per * 4))) return rc;
@@ -746,26 +759,28 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
 }
 }  // namespace
 
-int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
-                      int32_t is_test, int64_t* tokens, float* logits, int32_t* steps_out, d2t_stream stream) {
-  if (!c || !memory || !start_tokens || !tokens || !logits || !steps_out || B < 1 || T < 1)
-    return fail(c, D2T_EINVAL, "bad argument");
-  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+namespace {
+// Greedy decode.  The cross-attention K/V projection runs on the caller's stream into one of two slots;
+// the step loop runs on the internal stream, ordered after it.  async != 0: return right after
+// enqueueing (always max_seq_len+1 steps); the caller orders later work with d2t_decode_wait.
+int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* start_tokens, int is_test,
+                int64_t* tokens, float* logits, int* steps_out, hipStream_t user, bool async) {
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab;
-  hipStream_t user = (hipStream_t)stream;
   hipStream_t s = c->dstream;
   DecBufs bf;
   int rc = dec_prepare(c, B, T, &bf);
   if (rc) return rc;
   c->skv_cur = c->skv;
-  // order the internal stream after the caller's work (memory, start tokens)
+  const int slot = (int)(c->decode_seq++ & 1u);
+  c->ckv = c->ckv2[slot];
+  // the decode that last read this K/V slot must be finished before it is overwritten
+  if (c->ev_done_valid[slot]) HIPCHK(c, hipStreamWaitEvent(user, c->ev_done[slot], 0));
+  HIPCHK(c, cross_kv(c, user, memory, B, T));
+  // order the internal stream after the caller's work (K/V slot, start tokens)
   HIPCHK(c, hipEventRecord(c->ev_in, user));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev_in, 0));
   HIPCHK(c, hipMemsetAsync(c->dstate, 0, (size_t)(4 + B) * 4, s));
-  HIPCHK(c, cross_kv(c, s, memory, B, T));
-
   // step 0 input: Embedding([GO]) * sqrt(d) + pe[0]; later inputs are written by argmax_embed
   HIPCHK(c, launch_embed(c->word_embed, c->word_pe, start_tokens, tokens, S, c->dstate, bf.x, B, g.dec_dim, s));
 
@@ -783,10 +798,16 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
   };
 
   const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
+  hipGraphExec_t exec = nullptr;
   if (use_graph) {
-    d2t_ctx::GraphKey k{B, T, tokens, logits, start_tokens, memory};
-    if (!c->graph || memcmp(&k, &c->gkey, sizeof k) != 0) {
-      if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    d2t_ctx::GraphKey k{B, T, tokens, logits, c->ckv, c->dws, c->skv, c->dstate};
+    for (size_t i = 0; i < c->graphs.size(); ++i)
+      if (memcmp(&k, &c->graphs[i].key, sizeof k) == 0) {
+        exec = c->graphs[i].exec;
+        if (i + 1 != c->graphs.size()) std::swap(c->graphs[i], c->graphs.back());
+        break;
+      }
+    if (!exec) {
       hipGraph_t gr = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       hipError_t e = one_step(s);
@@ -795,24 +816,57 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
         if (gr) hipGraphDestroy(gr);
         return fail(c, D2T_EHIP, "decode graph capture: %s", hipGetErrorString(e != hipSuccess ? e : e2));
       }
-      e = hipGraphInstantiate(&c->graph, gr, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
       hipGraphDestroy(gr);
-      if (e != hipSuccess) { c->graph = nullptr; return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-      c->gkey = k;
+      if (e != hipSuccess) return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      if (c->graphs.size() >= 8) {  // evict the least recently used; it may still be queued on the stream
+        HIPCHK(c, hipStreamSynchronize(s));
+        hipGraphExecDestroy(c->graphs.front().exec);
+        c->graphs.erase(c->graphs.begin());
+      }
+      c->graphs.push_back({k, exec});
     }
   }
   int steps = S;
   for (int t = 0; t < S; ++t) {
-    if (use_graph) HIPCHK(c, hipGraphLaunch(c->graph, s));
+    if (use_graph) HIPCHK(c, hipGraphLaunch(exec, s));
     else HIPCHK(c, one_step(s));
-    if (is_test && ((t & 7) == 7 || t == S - 1)) {
+    if (!async && is_test && ((t & 7) == 7 || t == S - 1)) {
       HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->dstate + 2, 4, hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
       if (c->h_pinned[0] > 0) { steps = c->h_pinned[0]; break; }
     }
   }
-  HIPCHK(c, hipStreamSynchronize(s));
-  *steps_out = steps;
+  HIPCHK(c, hipEventRecord(c->ev_done[slot], s));
+  c->ev_done_valid[slot] = true;
+  if (!async) HIPCHK(c, hipStreamSynchronize(s));
+  if (steps_out) *steps_out = steps;
+  return D2T_OK;
+}
+}  // namespace
+
+int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
+                      int32_t is_test, int64_t* tokens, float* logits, int32_t* steps_out, d2t_stream stream) {
+  if (!c || !memory || !start_tokens || !tokens || !logits || !steps_out || B < 1 || T < 1)
+    return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  return greedy_impl(c, memory, B, T, start_tokens, is_test, tokens, logits, steps_out, (hipStream_t)stream, false);
+}
+
+int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
+                            int64_t* tokens, float* logits, d2t_stream stream) {
+  if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  return greedy_impl(c, memory, B, T, start_tokens, 0, tokens, logits, nullptr, (hipStream_t)stream, true);
+}
+
+int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
+  if (!c) return D2T_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (c->ev_done_valid[i]) HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_done[i], 0));
+  if (host_sync) HIPCHK(c, hipStreamSynchronize(c->dstream));
   return D2T_OK;
 }
 
@@ -868,6 +922,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   BCHK(hipEventRecord(c->ev_in, user));
   BCHK(hipStreamWaitEvent(s, c->ev_in, 0));
   BCHK(hipMemsetAsync(c->dstate, 0, (size_t)(4 + cap) * 4, s));
+  c->ckv = c->ckv2[0];  // the internal stream is in order, so earlier decodes are done with the slot
   BCHK(cross_kv(c, s, memory, 1, T));
   c->skv_cur = c->skv;
   float* skv_other = c->skv_alt;

@@ -150,6 +150,36 @@ class Engine:
         s = steps.value
         return tokens[:, :s], logits[:, :s]
 
+    def decode_greedy_async(self, memory, start_tokens, ring=3):
+        """Pipelined greedy decode (always max_seq_len+1 steps): returns views of engine-held
+        ring buffers that become valid after decode_wait(); at most `ring` - 1 later calls may be
+        issued before the result is consumed."""
+        memory = memory.float().contiguous()
+        B, T, _ = memory.shape
+        S, V = self.cfg.max_seq_len + 1, self.cfg.vocab
+        key = (B, S, V, memory.device)
+        if getattr(self, "_ring_key", None) != key:
+            self.decode_wait(host_sync=True)
+            self._ring = [(torch.zeros((B,), dtype=torch.int64, device=memory.device),
+                           torch.zeros((B, S), dtype=torch.int64, device=memory.device),
+                           torch.zeros((B, S, V), dtype=torch.float32, device=memory.device)) for _ in range(ring)]
+            self._ring_key, self._ring_pos = key, 0
+        start, tokens, logits = self._ring[self._ring_pos % len(self._ring)]
+        self._ring_pos += 1
+        start.copy_(start_tokens.to(device=memory.device, dtype=torch.int64))
+        self._check(self.lib.d2t_decode_greedy_async(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start),
+                                                     _lib.ptr(tokens), _lib.ptr(logits), _lib.stream_of(memory)),
+                    "decode_greedy_async")
+        self._wait_dev = memory.device
+        return tokens, logits
+
+    def decode_wait(self, host_sync=False):
+        dev = getattr(self, "_wait_dev", None)
+        if dev is None:
+            return
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self._check(self.lib.d2t_decode_wait(self.ctx, stream, int(bool(host_sync))), "decode_wait")
+
     def decode_beam(self, memory, beam_size):
         memory = memory.float().contiguous()
         if memory.shape[0] != 1:

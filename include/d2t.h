@@ -114,6 +114,15 @@ int d2t_decode_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t 
                       int32_t is_test, int64_t* tokens_dev, float* logits_dev, int32_t* steps_out,
                       d2t_stream stream);
 
+/* Pipelined variant: always runs max_seq_len+1 steps (is_test = 0 semantics) and returns as soon as the
+ * work is enqueued, so the caller can start encoding the next batch while this one decodes (the decode
+ * loop is latency-bound and leaves most CUs idle).  tokens_dev / logits_dev / start_tokens_dev must stay
+ * alive and untouched until d2t_decode_wait: it makes `stream` wait for every outstanding decode
+ * (and, if host_sync != 0, blocks the host until they are complete). */
+int d2t_decode_greedy_async(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T,
+                            const int64_t* start_tokens_dev, int64_t* tokens_dev, float* logits_dev, d2t_stream stream);
+int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
+
 /* ---- beam decode (one sample, fresh beam state per call) ------------------
  * memory [1,T,d].  seq_out: HOST buffer of max_seq_len+1 int64; *len_out its
  * used length; *score_out the hypothesis score (tools/beam.py semantics:

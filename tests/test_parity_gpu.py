@@ -145,3 +145,28 @@ def test_beam_rejects_batches():
     img = synth.synth_images(2, 48, 64).cuda()
     with pytest.raises(AssertionError):  # tfm.py:146-148
         m(img, torch.ones(2, 1, dtype=torch.long, device="cuda"), is_train=False, is_test=True)
+
+
+def test_pipelined_decode_equals_synchronous(cases):
+    """Opt-in cross-batch pipelining (decode of batch i overlaps the encoder of batch i+1)
+    returns exactly what the synchronous path returns."""
+    c = _case(cases, "greedy", "t2_greedy")
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    imgs = [synth.synth_images(3, c["H"], c["W"], seed=900 + i).cuda() for i in range(5)]
+    text = torch.full((3, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        ref = [m(x, text, is_train=False) for x in imgs]
+        ref = [(p.clone(), l.clone()) for p, l, _ in ref]
+        m.pipelined = True
+        got = []
+        for x in imgs:
+            p, l, _ = m(x, text, is_train=False)
+            got.append((p, l))
+            if len(got) >= 2:  # consume with one batch of lag, as a serving loop would
+                m.synchronize(host_sync=False)
+        m.synchronize()
+        torch.cuda.synchronize()
+    # ring depth 3: only the last three results are still resident
+    for (p, l), (rp, rl) in list(zip(got, ref))[-3:]:
+        assert torch.equal(p, rp) and torch.equal(l, rl)
+    m.pipelined = False
