@@ -11,14 +11,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libd2t.so")
 
 D2T_OK = 0
-ENC_RESNET, ENC_HYBRID_VIT = 0, 1
+ENC_RESNET, ENC_HYBRID_VIT, ENC_VGG_BILSTM, ENC_RESNET_BILSTM = 0, 1, 2, 3
+DEC_TFM, DEC_ATTN = 0, 1
+ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
 class D2TConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "encoder", "in_channels", "backbone_out", "vit_depth", "vit_heads", "vit_dim", "patch_h", "patch_w",
-        "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len")]
+        "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len",
+        "decoder", "attn_hidden", "attn_kernel_size", "attn_kernel_dim", "attn_keys", "attn_enc_init",
+        "attn_coverage", "bilstm_hidden", "batch_max_length")]
 
 
 _P = C.c_void_p
@@ -34,6 +38,7 @@ SIGNATURES = {
     "d2t_encoder_shape": (_I, [_P, _I, _I] + [C.POINTER(_I)] * 6),
     "d2t_encode": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "d2t_decode_greedy": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, C.POINTER(_I), _P]),
+    "d2t_decode_attn_greedy": (_I, [_P, _P, _I, _I, _I, _P, _P, C.POINTER(_I), _P]),
     "d2t_decode_greedy_async": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "d2t_decode_wait": (_I, [_P, _P, _I]),
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),

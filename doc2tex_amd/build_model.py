@@ -16,7 +16,8 @@ from .engine import Engine
 
 
 class FeatExtractorBuilder(nn.Module):
-    """recognizers/build_feat.py:8-63 (parameter tree; ResNet only)."""
+    """recognizers/build_feat.py:8-63 (parameter tree; ResNet or VGG; the height-mean for Seq=BiLSTM
+    runs inside the engine)."""
 
     def __init__(self, flow, config):
         super().__init__()
@@ -25,9 +26,12 @@ class FeatExtractorBuilder(nn.Module):
         self.feat_name = flow["Feat"]
         if self.feat_name != "None":
             config["FeatureExtraction"]["params"].pop("mean_height", True)  # build_feat.py:16
-            if self.feat_name != "ResNet":
+            if self.feat_name == "VGG":
+                self.FeatureExtraction = P.VGGFeatureExtractorParams(**config["FeatureExtraction"]["params"])
+            elif self.feat_name == "ResNet":
+                self.FeatureExtraction = P.ResNetFeatureExtractorParams(**config["FeatureExtraction"]["params"])
+            else:
                 raise NotImplementedError(f"FeatureExtraction '{self.feat_name}' is not on the accelerated path")
-            self.FeatureExtraction = P.ResNetFeatureExtractorParams(**config["FeatureExtraction"]["params"])
             self.FeatureExtraction_output = config["FeatureExtraction"]["params"]["output_channel"]
         else:
             if flow["Seq"] != "ViT":
@@ -36,7 +40,7 @@ class FeatExtractorBuilder(nn.Module):
 
 
 class SeqModelingBuilder(nn.Module):
-    """recognizers/build_seq.py:7-40 (parameter tree; ViT hybrid or None)."""
+    """recognizers/build_seq.py:7-40 (parameter tree; ViT hybrid, BiLSTM or None)."""
 
     def __init__(self, flow, config, FeatureExtraction_output):
         super().__init__()
@@ -55,6 +59,12 @@ class SeqModelingBuilder(nn.Module):
             self.SequenceModeling = P.ViTEncoderV3Params(
                 img_size=tuple(max_dimension), patch_size=ps, in_chans=sp["input_channel"], depth=sp["depth"],
                 embed_dim=sp["hidden_size"], num_heads=sp["num_heads"], hybrid_backbone=backbone)
+        elif flow["Seq"] == "BiLSTM":  # build_seq.py:13-25
+            hidden_size = config["SequenceModeling"]["params"]["hidden_size"]
+            self.SequenceModeling = nn.Sequential(
+                P.BidirectionalLSTMParams(FeatureExtraction_output, hidden_size, hidden_size),
+                P.BidirectionalLSTMParams(hidden_size, hidden_size, hidden_size))
+            self.SequenceModeling_output = hidden_size
         elif flow["Seq"] == "None":
             if flow["Pred"] == "TFM":
                 self.image_positional_encoder = P.PositionalEncoding2DParams(FeatureExtraction_output)
@@ -64,17 +74,20 @@ class SeqModelingBuilder(nn.Module):
 
 
 class PredictBuilder(nn.Module):
-    """recognizers/build_pred.py:9-26 (parameter tree; TFM only)."""
+    """recognizers/build_pred.py:9-26 (parameter tree; TFM, Attn, Attnv2)."""
 
     def __init__(self, flow, config, SequenceModeling_output):
         super().__init__()
         self.flow = flow
         self.config = config
-        if flow["Pred"] != "TFM":
+        if flow["Pred"] not in ("TFM", "Attn", "Attnv2"):
             raise NotImplementedError(f"Prediction '{flow['Pred']}' is not on the accelerated path")
         config["Prediction"]["params"]["num_classes"] = config["num_class"]  # build_pred.py:16-17
         config["Prediction"]["params"]["device"] = config["device"]
-        self.Prediction = P.TransformerPredictionParams(**config["Prediction"]["params"])
+        if flow["Pred"] == "TFM":
+            self.Prediction = P.TransformerPredictionParams(**config["Prediction"]["params"])
+        else:  # Attention and AttentionV2 share parameters (seq2seq_v2.py:11)
+            self.Prediction = P.AttentionParams(**config["Prediction"]["params"])
 
 
 class Model(nn.Module):
@@ -129,6 +142,16 @@ class Model(nn.Module):
         """build_model.py:45-53 / build_pred.py:28-50 / tfm.py:188-195."""
         beam_size = self.opt.get("beam_size", 1)  # read on every call, build_pred.py:31
         eng = self.engine()
+        if self.stages["Pred"] in ("Attn", "Attnv2"):
+            # build_pred.py:36-44 -> Attention.forward (seq2seq.py:333-347)
+            if self.training or is_train:
+                raise NotImplementedError(
+                    "teacher-forced LSTM-attention decoding (is_train=True / model.train()) is not implemented in "
+                    "the HIP engine; call model.eval() and pass is_train=False (engine/inferencing.py:70-76)")
+            if beam_size > 1:
+                raise NotImplementedError("LSTM-attention beam search (seq2seq.py:83-222) is not implemented yet")
+            prediction, logits = eng.decode_attn_greedy(contextual_feature.contiguous(), is_test)
+            return prediction, logits, None, {}
         if self.training:
             raise NotImplementedError(
                 "teacher-forced training pass (tfm.py:103-118) is not implemented in the HIP engine yet; "

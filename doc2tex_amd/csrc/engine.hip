@@ -56,6 +56,22 @@ struct Block {
   ConvW c1, c2, down;
   bool has_down = false;
 };
+struct BiLstmW {
+  float* wih_cat = nullptr;   // [2*4H][in]  forward rows then reverse rows
+  float* bias_cat = nullptr;  // [2*4H]      b_ih + b_hh
+  float* whh_t = nullptr;     // [2][H][4H]
+  LinW lin;                   // Linear(2H -> out)
+  int in = 0;
+};
+struct AttnW {
+  const float* emb = nullptr;
+  LinW key;                    // key_proj
+  float *wq_t = nullptr, *wloc = nullptr, *bloc = nullptr, *wx_t = nullptr, *bx = nullptr, *wg_t = nullptr;
+  float *wih_t = nullptr, *wic_t = nullptr;
+  const float *bq = nullptr, *wscore = nullptr, *bg = nullptr, *bih = nullptr, *bic = nullptr;
+  float bscore = 0.f;
+  int taps = 0;
+};
 struct Act {
   float* p;
   int B, H, W, C;
@@ -74,6 +90,9 @@ struct d2t_ctx {
   // packed weights
   std::string bb;  // backbone key prefix ("...ConvNet.")
   ConvW stem, conv0_2, conv1, conv2, conv3, conv4_1, conv4_2, patch;
+  ConvW vgg[7];      // VGG convs 0,3,6,8,11(+bn12),14(+bn15),18 (feature_extractor/vgg.py:16-41)
+  BiLstmW lstm[2];   // seq_modeling/bilstm.py
+  AttnW attn;        // prediction_head/seq2seq.py
   std::vector<Block> layers[4];
   const float* pos_embed = nullptr;  // [1+gh*gw][dim]
   int pos_rows = 0;
@@ -369,15 +388,31 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
     if (cfg->vit_dim != 256 && cfg->vit_dim != 512) return fail(c, D2T_EINVAL, "ViT hidden_size must be 256 or 512");
     if (cfg->vit_dim / cfg->vit_heads != 32) return fail(c, D2T_EINVAL, "ViT head_dim must be 32");
     if (cfg->patch_h < 1 || cfg->patch_w < 1) return fail(c, D2T_EINVAL, "bad patch size");
-  } else if (cfg->encoder != D2T_ENC_RESNET) {
+  } else if (cfg->encoder != D2T_ENC_RESNET && cfg->encoder != D2T_ENC_VGG_BILSTM &&
+             cfg->encoder != D2T_ENC_RESNET_BILSTM) {
     return fail(c, D2T_EINVAL, "unknown encoder %d", cfg->encoder);
   }
-  const int hd = cfg->dec_heads > 0 ? cfg->dec_dim / cfg->dec_heads : 0;
-  if (cfg->dec_dim != 256 && cfg->dec_dim != 512) return fail(c, D2T_EINVAL, "decoder d_model must be 256 or 512");
-  if (hd != 32 && hd != 64) return fail(c, D2T_EINVAL, "decoder head_dim must be 32 or 64");
-  if (cfg->dec_heads != 8) return fail(c, D2T_EINVAL, "decoder nhead must be 8");
-  if (cfg->dec_ff % 64) return fail(c, D2T_EINVAL, "dim_feedforward must be a multiple of 64");
-  if (cfg->max_seq_len + 2 > 512) return fail(c, D2T_EINVAL, "max_seq_len must be <= 510");
+  if (cfg->decoder == D2T_DEC_TFM) {
+    const int hd = cfg->dec_heads > 0 ? cfg->dec_dim / cfg->dec_heads : 0;
+    if (cfg->dec_dim != 256 && cfg->dec_dim != 512) return fail(c, D2T_EINVAL, "decoder d_model must be 256 or 512");
+    if (hd != 32 && hd != 64) return fail(c, D2T_EINVAL, "decoder head_dim must be 32 or 64");
+    if (cfg->dec_heads != 8) return fail(c, D2T_EINVAL, "decoder nhead must be 8");
+    if (cfg->dec_ff % 64) return fail(c, D2T_EINVAL, "dim_feedforward must be a multiple of 64");
+    if (cfg->max_seq_len + 2 > 512) return fail(c, D2T_EINVAL, "max_seq_len must be <= 510");
+    if (cfg->encoder == D2T_ENC_VGG_BILSTM || cfg->encoder == D2T_ENC_RESNET_BILSTM)
+      return fail(c, D2T_EINVAL, "BiLSTM encoders are paired with the Attn decoder only");
+  } else if (cfg->decoder == D2T_DEC_ATTN) {
+    if (cfg->attn_hidden != 256) return fail(c, D2T_EINVAL, "Attn hidden_size / input_size must be 256");
+    if (cfg->attn_kernel_size < 0 || cfg->attn_kernel_size > 5) return fail(c, D2T_EINVAL, "Attn kernel_size must be <= 5");
+    if (cfg->vocab > 1024) return fail(c, D2T_EINVAL, "Attn decoder supports num_class <= 1024");
+    if (cfg->batch_max_length < 1) return fail(c, D2T_EINVAL, "batch_max_length must be >= 1");
+    if (cfg->encoder == D2T_ENC_RESNET) return fail(c, D2T_EINVAL, "Feat=ResNet+Seq=None is paired with the TFM decoder only");
+    if (cfg->encoder == D2T_ENC_HYBRID_VIT && cfg->vit_dim != 256) return fail(c, D2T_EINVAL, "Attn over ViT needs hidden_size 256");
+    if ((cfg->encoder == D2T_ENC_VGG_BILSTM || cfg->encoder == D2T_ENC_RESNET_BILSTM) && cfg->bilstm_hidden != 256)
+      return fail(c, D2T_EINVAL, "BiLSTM hidden_size must be 256");
+  } else {
+    return fail(c, D2T_EINVAL, "unknown decoder %d", cfg->decoder);
+  }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking));
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
@@ -445,6 +480,18 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
   const std::string sm = "seqmodeler.SequenceModeling.";
   c->bb = vit ? sm + "patch_embed.backbone.ConvNet." : "featextractor.FeatureExtraction.ConvNet.";
   const std::string& bb = c->bb;
+  const bool is_vgg = g.encoder == D2T_ENC_VGG_BILSTM;
+  const bool has_lstm = is_vgg || g.encoder == D2T_ENC_RESNET_BILSTM;
+  if (is_vgg) {
+    // VGG_FeatureExtractor (feature_extractor/vgg.py:16-41): nn.Sequential indices of the convs / BNs
+    const char* convs[7] = {"0", "3", "6", "8", "11", "14", "18"};
+    const char* bns[7] = {"", "", "", "", "12", "15", ""};
+    for (int i = 0; i < 7; ++i)
+      if ((rc = pack_conv(c, bb + convs[i], bns[i][0] ? bb + bns[i] : std::string(), &c->vgg[i], s))) return rc;
+    if (c->vgg[0].Cin != 1 || c->vgg[0].KH != 3 || c->vgg[6].KH != 2 || c->vgg[6].Cout != 512)
+      return fail(c, D2T_EINVAL, "unexpected VGG_FeatureExtractor shapes");
+  }
+  if (!is_vgg) {
   if ((rc = pack_conv(c, bb + "conv0_1", bb + "bn0_1", &c->stem, s))) return rc;
   if (c->stem.Cin != 1 || c->stem.KH != 3 || c->stem.KW != 3)
     return fail(c, D2T_EINVAL, "conv0_1 must be 1-channel 3x3");
@@ -467,6 +514,38 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
   if ((rc = pack_conv(c, bb + "conv3", bb + "bn3", &c->conv3, s))) return rc;
   if ((rc = pack_conv(c, bb + "conv4_1", bb + "bn4_1", &c->conv4_1, s))) return rc;
   if ((rc = pack_conv(c, bb + "conv4_2", bb + "bn4_2", &c->conv4_2, s))) return rc;
+  }  // !is_vgg
+
+  if (has_lstm) {
+    // 2x BidirectionalLSTM (seq_modeling/bilstm.py:6-24, build_seq.py:20-23): nn.LSTM(bidirectional) + Linear
+    const int Hh = g.bilstm_hidden, G4 = 4 * Hh;
+    int in = 512;
+    for (int i = 0; i < 2; ++i) {
+      const std::string lp = sm + std::to_string(i) + ".";
+      BiLstmW& L = c->lstm[i];
+      L.in = in;
+      void *a, *b2, *t;
+      if ((rc = dev_alloc(c, &a, (size_t)2 * G4 * in * 4)) || (rc = dev_alloc(c, &b2, (size_t)2 * G4 * 4)) ||
+          (rc = dev_alloc(c, &t, (size_t)2 * Hh * G4 * 4)))
+        return rc;
+      c->owned.push_back(a); c->owned.push_back(b2); c->owned.push_back(t);
+      L.wih_cat = (float*)a; L.bias_cat = (float*)b2; L.whh_t = (float*)t;
+      const char* sfx[2] = {"", "_reverse"};
+      for (int dirn = 0; dirn < 2; ++dirn) {
+        const RawW *wi, *wh, *bi, *bh;
+        if ((rc = need(c, lp + "rnn.weight_ih_l0" + sfx[dirn], &wi, {G4, in})) ||
+            (rc = need(c, lp + "rnn.weight_hh_l0" + sfx[dirn], &wh, {G4, Hh})) ||
+            (rc = need(c, lp + "rnn.bias_ih_l0" + sfx[dirn], &bi, {G4})) ||
+            (rc = need(c, lp + "rnn.bias_hh_l0" + sfx[dirn], &bh, {G4})))
+          return rc;
+        HIPCHK(c, launch_copy(wi->p, L.wih_cat + (size_t)dirn * G4 * in, (size_t)G4 * in, s));
+        HIPCHK(c, launch_add_rows(bi->p, bh->p, L.bias_cat + (size_t)dirn * G4, G4, s));
+        HIPCHK(c, launch_transpose_into(wh->p, G4, Hh, L.whh_t + (size_t)dirn * Hh * G4, G4, 0, s));
+      }
+      if ((rc = get_lin(c, lp + "linear", &L.lin, Hh, 2 * Hh))) return rc;
+      in = Hh;
+    }
+  }
 
   if (vit) {
     const int D = g.vit_dim;
@@ -497,13 +576,92 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
       c->vit.push_back(vb);
     }
     if ((rc = get_ln(c, sm + "norm", &c->vit_norm, D))) return rc;
-    if (g.dec_dim != D) return fail(c, D2T_EINVAL, "decoder d_model must equal the ViT hidden_size");
-  } else if (g.dec_dim != c->conv4_2.Cout) {
+    if (g.decoder == D2T_DEC_TFM && g.dec_dim != D)
+      return fail(c, D2T_EINVAL, "decoder d_model must equal the ViT hidden_size");
+  } else if (g.decoder == D2T_DEC_TFM && g.dec_dim != c->conv4_2.Cout) {
     return fail(c, D2T_EINVAL, "decoder d_model must equal the backbone output_channel");
   }
 
-  // decoder (prediction_head/tfm.py:36-72)
   const std::string pp = "predicter.Prediction.";
+  if (g.decoder == D2T_DEC_ATTN) {
+    // Attention.__init__ (prediction_head/seq2seq.py:11-68) + LocationAwareAttention (attention1D.py:121-133,203-214)
+    const int Hh = g.attn_hidden, V = g.vocab, taps = 2 * g.attn_kernel_size + 1, kd = g.attn_kernel_dim;
+    const std::string ac = pp + "attention_cell.";
+    AttnW& A = c->attn;
+    A = AttnW{};
+    A.taps = taps;
+    const RawW *emb, *lcw, *lcb, *lpw, *lpb, *qw, *qb, *sw, *sb, *wih, *whh, *bih, *bhh, *gw, *gb;
+    if ((rc = need(c, pp + "embedding.weight", &emb, {V, Hh})) ||
+        (rc = need(c, ac + "attn.loc_conv.weight", &lcw, {kd, 1, taps})) ||
+        (rc = need(c, ac + "attn.loc_conv.bias", &lcb, {kd})) ||
+        (rc = need(c, ac + "attn.loc_proj.weight", &lpw, {Hh, kd})) ||
+        (rc = need(c, ac + "attn.loc_proj.bias", &lpb, {Hh})) ||
+        (rc = need(c, ac + "attn.query_proj.weight", &qw, {Hh, Hh})) ||
+        (rc = need(c, ac + "attn.query_proj.bias", &qb, {Hh})) ||
+        (rc = get_lin(c, ac + "attn.key_proj", &A.key, Hh, Hh)) ||
+        (rc = need(c, ac + "attn.score.weight", &sw, {1, Hh})) || (rc = need(c, ac + "attn.score.bias", &sb, {1})) ||
+        (rc = need(c, ac + "rnn.weight_ih", &wih, {4 * Hh, 2 * Hh})) ||
+        (rc = need(c, ac + "rnn.weight_hh", &whh, {4 * Hh, Hh})) || (rc = need(c, ac + "rnn.bias_ih", &bih, {4 * Hh})) ||
+        (rc = need(c, ac + "rnn.bias_hh", &bhh, {4 * Hh})) || (rc = need(c, ac + "generator.weight", &gw, {V, Hh})) ||
+        (rc = need(c, ac + "generator.bias", &gb, {V})))
+      return rc;
+    A.emb = emb->p; A.bq = qb->p; A.wscore = sw->p; A.bg = gb->p;
+    auto alloc = [&](float** dst, size_t n) -> int {
+      void* q;
+      int r2 = dev_alloc(c, &q, n * 4);
+      if (r2) return r2;
+      c->owned.push_back(q);
+      *dst = (float*)q;
+      return D2T_OK;
+    };
+    if ((rc = alloc(&A.wq_t, (size_t)Hh * Hh)) || (rc = alloc(&A.wloc, (size_t)Hh * taps)) ||
+        (rc = alloc(&A.bloc, Hh)) || (rc = alloc(&A.wx_t, (size_t)3 * Hh * 4 * Hh)) || (rc = alloc(&A.bx, 4 * Hh)) ||
+        (rc = alloc(&A.wg_t, (size_t)Hh * V)))
+      return rc;
+    HIPCHK(c, launch_transpose_into(qw->p, Hh, Hh, A.wq_t, Hh, 0, s));
+    HIPCHK(c, launch_transpose_into(wih->p, 4 * Hh, 2 * Hh, A.wx_t, 4 * Hh, 0, s));       // rows [ctx ; emb]
+    HIPCHK(c, launch_transpose_into(whh->p, 4 * Hh, Hh, A.wx_t, 4 * Hh, 2 * Hh, s));      // rows h
+    HIPCHK(c, launch_add_rows(bih->p, bhh->p, A.bx, 4 * Hh, s));
+    HIPCHK(c, launch_transpose_into(gw->p, V, Hh, A.wg_t, V, 0, s));
+    {  // fold loc_proj o loc_conv (attention1D.py:150-152) into one [H][taps] filter on the host
+      std::vector<float> hcw((size_t)kd * taps), hcb(kd), hpw((size_t)Hh * kd), hpb(Hh), hsb(1);
+      HIPCHK(c, hipStreamSynchronize(s));
+      HIPCHK(c, hipMemcpy(hcw.data(), lcw->p, hcw.size() * 4, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(hcb.data(), lcb->p, hcb.size() * 4, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(hpw.data(), lpw->p, hpw.size() * 4, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(hpb.data(), lpb->p, hpb.size() * 4, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(hsb.data(), sb->p, 4, hipMemcpyDeviceToHost));
+      std::vector<float> w((size_t)Hh * taps), b(Hh);
+      for (int n = 0; n < Hh; ++n) {
+        double bb2 = hpb[n];
+        for (int m = 0; m < kd; ++m) bb2 += (double)hpw[(size_t)n * kd + m] * hcb[m];
+        b[n] = (float)bb2;
+        for (int j = 0; j < taps; ++j) {
+          double a = 0.0;
+          for (int m = 0; m < kd; ++m) a += (double)hpw[(size_t)n * kd + m] * hcw[(size_t)m * taps + j];
+          w[(size_t)n * taps + j] = (float)a;
+        }
+      }
+      HIPCHK(c, hipMemcpy(A.wloc, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(A.bloc, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+      A.bscore = hsb[0];
+    }
+    if (g.attn_enc_init) {
+      const RawW *hw, *hb, *cw, *cb;
+      if ((rc = need(c, pp + "proj_init_h.weight", &hw, {Hh, Hh})) || (rc = need(c, pp + "proj_init_h.bias", &hb, {Hh})) ||
+          (rc = need(c, pp + "proj_init_c.weight", &cw, {Hh, Hh})) || (rc = need(c, pp + "proj_init_c.bias", &cb, {Hh})))
+        return rc;
+      if ((rc = alloc(&A.wih_t, (size_t)Hh * Hh)) || (rc = alloc(&A.wic_t, (size_t)Hh * Hh))) return rc;
+      HIPCHK(c, launch_transpose_into(hw->p, Hh, Hh, A.wih_t, Hh, 0, s));
+      HIPCHK(c, launch_transpose_into(cw->p, Hh, Hh, A.wic_t, Hh, 0, s));
+      A.bih = hb->p; A.bic = cb->p;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->finalized = true;
+    return D2T_OK;
+  }
+
+  // decoder (prediction_head/tfm.py:36-72)
   const int d = g.dec_dim, V = g.vocab;
   const RawW *we, *pe;
   if ((rc = need(c, pp + "word_embed.weight", &we, {V, d})) || (rc = need(c, pp + "pos_enc.pe", &pe))) return rc;
@@ -560,10 +718,18 @@ int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_
   if (!c) return D2T_EINVAL;
   if (H < 4 || W < 4) return D2T_EINVAL;
   int fh, fw;
-  backbone_hw(H, W, &fh, &fw);
+  if (c->cfg.encoder == D2T_ENC_VGG_BILSTM) {  // vgg.py:16-41: pools (2,2),(2,2),(2,1),(2,1), final 2x2 conv
+    fh = H / 2 / 2 / 2 / 2 - 1;
+    fw = W / 2 / 2 - 1;
+  } else {
+    backbone_hw(H, W, &fh, &fw);
+  }
   if (fh < 1 || fw < 1) return D2T_EINVAL;
   int gh = fh, gw = fw, pw = 0, ph = 0, t, dim = c->cfg.backbone_out;
-  if (c->cfg.encoder == D2T_ENC_HYBRID_VIT) {
+  if (c->cfg.encoder == D2T_ENC_VGG_BILSTM || c->cfg.encoder == D2T_ENC_RESNET_BILSTM) {
+    t = fw;  // the height is averaged away (build_feat.py:50-55)
+    dim = c->cfg.bilstm_hidden;
+  } else if (c->cfg.encoder == D2T_ENC_HYBRID_VIT) {
     ph = (c->cfg.patch_h - fh % c->cfg.patch_h) % c->cfg.patch_h;
     pw = (c->cfg.patch_w - fw % c->cfg.patch_w) % c->cfg.patch_w;
     gh = (fh + ph) / c->cfg.patch_h;
@@ -600,6 +766,8 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     size_t v = (size_t)B * T * (hid > 3 * (size_t)dim ? hid : 3 * (size_t)dim);
     if (v > need_floats) need_floats = v;
   }
+  const bool lstm_enc = g.encoder == D2T_ENC_VGG_BILSTM || g.encoder == D2T_ENC_RESNET_BILSTM;
+  if (lstm_enc && (size_t)B * T * 8 * g.bilstm_hidden > need_floats) need_floats = (size_t)B * T * 8 * g.bilstm_hidden;
   if (c->act_cap < need_floats * 4) {
     hipDeviceSynchronize();
     for (int i = 0; i < 4; ++i) {
@@ -614,6 +782,50 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
   }
   Act f{};
   int rc;
+  if (lstm_enc) {
+    hipError_t err = hipSuccess;
+    if (g.encoder == D2T_ENC_VGG_BILSTM) {
+      // VGG_FeatureExtractor.forward (feature_extractor/vgg.py:16-44)
+      Act x{pick(c, {}), B, H, W, c->vgg[0].Cout};
+      HIPCHK(c, launch_stem(image, c->vgg[0].w, c->vgg[0].bias, x.p, B, H, W, x.C, ACT_RELU, s));
+      auto pool = [&](const Act& a, int kh, int kw) {
+        Act y{pick(c, {a.p}), a.B, (a.H - kh) / kh + 1, (a.W - kw) / kw + 1, a.C};
+        hipError_t e = launch_maxpool_k(a.p, y.p, a.B, a.H, a.W, a.C, kh, kw, kh, kw, 0, 0, s);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+        return y;
+      };
+      x = pool(x, 2, 2);
+      x = conv(c, s, &err, x, c->vgg[1], 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      x = pool(x, 2, 2);
+      x = conv(c, s, &err, x, c->vgg[2], 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      x = conv(c, s, &err, x, c->vgg[3], 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      x = pool(x, 2, 1);
+      x = conv(c, s, &err, x, c->vgg[4], 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      x = conv(c, s, &err, x, c->vgg[5], 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+      x = pool(x, 2, 1);
+      f = conv(c, s, &err, x, c->vgg[6], 1, 1, 0, 0, ACT_RELU, nullptr, pick(c, {x.p}));
+      if (err != hipSuccess) return fail(c, D2T_EHIP, "VGG launch: %s", hipGetErrorString(err));
+    } else if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr))) {
+      return rc;
+    }
+    if (f.W != T || f.C != 512) return fail(c, D2T_EINVAL, "unexpected feature map %dx%dx%d", f.H, f.W, f.C);
+    // AdaptiveAvgPool2d((None,1)) over the height (build_feat.py:50-55), then 2x BidirectionalLSTM
+    float* seq = pick(c, {f.p});
+    HIPCHK(c, launch_mean_h(f.p, seq, B, f.H, f.W, f.C, s));
+    const int Hh = g.bilstm_hidden;
+    for (int i = 0; i < 2; ++i) {
+      const BiLstmW& L = c->lstm[i];
+      float* gates = pick(c, {seq});
+      float* rec = pick(c, {seq, gates});
+      LinW ih{L.wih_cat, L.bias_cat, 8 * Hh, L.in};
+      HIPCHK(c, linear_any(c, s, seq, ih, nullptr, gates, B * T, ACT_NONE));
+      HIPCHK(c, launch_bilstm(gates, L.whh_t, rec, B, T, Hh, s));
+      float* out = i == 1 ? memory : pick(c, {rec});
+      HIPCHK(c, linear_any(c, s, rec, L.lin, nullptr, out, B * T, ACT_NONE));
+      seq = out;
+    }
+    return D2T_OK;
+  }
   if (!vit) {
     // Feat=ResNet, Seq=None: PositionalEncoding2D add, [B,C,H,W] -> [B,HW,C] (build_seq.py:69-76)
     int fh, fw;
@@ -851,7 +1063,54 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
     return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
   return greedy_impl(c, memory, B, T, start_tokens, is_test, tokens, logits, steps_out, (hipStream_t)stream, false);
+}
+
+int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, int32_t is_test, int64_t* tokens,
+                           float* probs, int32_t* steps_out, d2t_stream stream) {
+  if (!c || !memory || !tokens || !probs || !steps_out || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  const d2t_config& g = c->cfg;
+  if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
+  const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab;
+  const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
+  if (T - key_off < 1 || T - key_off > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  // workspace: key_proj(memory) [B*T][H] | end_step [B]
+  if ((rc = ensure(c, &c->dws, &c->dws_cap, ((size_t)B * T * Hh + B + 16) * 4))) return rc;
+  float* kp = c->dws;
+  int* end_step = reinterpret_cast<int*>(c->dws + (size_t)B * T * Hh);
+  HIPCHK(c, linear_any(nullptr, s, memory, c->attn.key, nullptr, kp, B * T, ACT_NONE));
+  HIPCHK(c, hipMemsetAsync(end_step, 0xFF, (size_t)B * 4, s));  // -1 = never emitted [s]
+  AttnDecP p{};
+  p.mem = memory; p.T = T; p.D = Hh; p.key_off = key_off;
+  p.init_mode = !g.attn_enc_init ? 0 : (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN ? 1 : 2);
+  p.kp = kp; p.wq_t = c->attn.wq_t; p.bq = c->attn.bq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
+  p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
+  p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
+  p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
+  p.emb = c->attn.emb; p.probs = probs; p.tokens = tokens; p.end_step = end_step;
+  p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage; p.end_token = 1;  // attn_converter.py:8
+  HIPCHK(c, launch_attn_decode(p, s));
+  int steps = S;
+  if (is_test) {
+    // reference: break as soon as every row has emitted [s]; the pre-zeroed probs keep zeros afterwards
+    std::vector<int> h(B);
+    HIPCHK(c, hipMemcpyAsync(h.data(), end_step, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int last = -1;
+    bool all = true;
+    for (int b = 0; b < B; ++b) { all = all && h[b] >= 0; last = std::max(last, h[b]); }
+    if (all && last + 1 < S) {
+      steps = last + 1;
+      HIPCHK(c, hipMemset2DAsync(probs + (size_t)steps * V, (size_t)S * V * 4, 0, (size_t)(S - steps) * V * 4, B, s));
+      HIPCHK(c, hipMemset2DAsync(tokens + steps, (size_t)S * 8, 0, (size_t)(S - steps) * 8, B, s));
+    }
+  }
+  *steps_out = steps;
+  return D2T_OK;
 }
 
 int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
@@ -859,6 +1118,7 @@ int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t 
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
   return greedy_impl(c, memory, B, T, start_tokens, 0, tokens, logits, nullptr, (hipStream_t)stream, true);
 }
 
@@ -879,6 +1139,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   if (!c || !memory || !seq_out || !len_out || !score_out || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
+  if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "beam search is implemented for the TFM decoder only");
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = beam_size;

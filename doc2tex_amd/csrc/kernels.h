@@ -53,7 +53,36 @@ hipError_t launch_skinny(const SkinnyP& p, hipStream_t s);
 hipError_t launch_stem(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
                        int act, hipStream_t s);
 hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
-                          hipStream_t s);
+                          hipStream_t s);  // 2x2 window
+hipError_t launch_maxpool_k(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
+                            int PH, int PW, hipStream_t s);
+// y[b][w][c] = mean_h x[b][h][w][c]   (AdaptiveAvgPool2d((None,1)) on the permuted map, build_feat.py:50-55)
+hipError_t launch_mean_h(const float* x, float* y, int B, int H, int W, int C, hipStream_t s);
+
+// One bidirectional nn.LSTM layer given the input projection of both directions:
+//   g [B*T][2*4H] = x @ [W_ih ; W_ih_reverse]^T + (b_ih + b_hh) ; whh_t [2][H][4H] (transposed W_hh)
+//   out [B][T][2H] = [h_fwd | h_bwd].  H = 256, gate order i,f,g,o.
+hipError_t launch_bilstm(const float* g, const float* whh_t, float* out, int B, int T, int H, hipStream_t s);
+
+// LSTM-attention greedy decoder, all steps in one launch (one block per row).
+struct AttnDecP {
+  const float* mem; int T; int D;      // encoder output [B][T][D] (D = 256)
+  int key_off;                         // 0, or 1 = drop the cls token from the keys (AttentionV2 + TFM)
+  int init_mode;                       // 0 zeros, 1 mean over all T tokens, 2 token 0
+  const float* kp;                     // key_proj(mem) [B][T][H] (bias included)
+  const float* wq_t; const float* bq;  // query_proj^T [H][H], bias
+  const float* wloc; const float* bloc; int taps;  // folded loc_proj o loc_conv: [H][taps], [H]
+  const float* wscore; float bscore;   // score [H]
+  const float* wx_t; const float* bx;  // LSTMCell: [ctx(D) ; emb(E) ; h(H)] -> 4H, transposed [(D+E+H)][4H]; bias b_ih+b_hh
+  const float* wg_t; const float* bg;  // generator^T [H][V], bias
+  const float* wih_t; const float* bih; const float* wic_t; const float* bic;  // proj_init_h/c^T [D][H]
+  const float* emb;                    // [V][E]
+  float* probs; int64_t* tokens; int* end_step;  // [B][S][V], [B][S], [B] (-1 = never ended)
+  int B, S, V, H, E, coverage, end_token;
+};
+hipError_t launch_attn_decode(const AttnDecP& p, hipStream_t s);
+// dst[(row_off + c) * ld + r] = src[r * cols + c]
+hipError_t launch_transpose_into(const float* src, int rows, int cols, float* dst, int ld, int row_off, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps,
                             hipStream_t s);
 hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s);

@@ -12,14 +12,14 @@ def config_from_opt(opt):
     feat = opt["FeatureExtraction"]["name"]
     seq = opt["SequenceModeling"]["name"]
     pred = opt["Prediction"]
-    if pred["name"] != "TFM":
-        raise NotImplementedError(f"Prediction '{pred['name']}' is not on the accelerated path (TFM only)")
     pp = pred["params"]
     cfg = _lib.D2TConfig()
     max_dim = opt.get("max_dimension") or [0, 0]
     if opt.get("imgH"):
         max_dim = (opt["imgH"], max_dim[1])  # vit_encoder.py:292-294
     cfg.max_h, cfg.max_w = int(max_dim[0]), int(max_dim[1])
+    cfg.backbone_out = 512
+    cfg.in_channels = 1
     if seq == "ViT":
         sp = opt["SequenceModeling"]["params"]
         bbp = sp.get("backbone") or {}
@@ -37,19 +37,48 @@ def config_from_opt(opt):
         ps = sp["patch_size"]
         ps = (ps, ps) if isinstance(ps, int) else tuple(ps)
         cfg.patch_h, cfg.patch_w = int(ps[0]), int(ps[1])
-    elif feat == "ResNet" and seq == "None":
+    elif feat in ("ResNet", "VGG") and seq in ("None", "BiLSTM"):
         fp = opt["FeatureExtraction"]["params"]
         if fp.get("gcb", False):
             raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
-        cfg.encoder = _lib.ENC_RESNET
         cfg.in_channels = int(fp["input_channel"])
         cfg.backbone_out = int(fp["output_channel"])
+        if seq == "BiLSTM":
+            cfg.encoder = _lib.ENC_VGG_BILSTM if feat == "VGG" else _lib.ENC_RESNET_BILSTM
+            cfg.bilstm_hidden = int(opt["SequenceModeling"]["params"]["hidden_size"])
+            if opt["SequenceModeling"]["params"].get("pos_enc", False):
+                raise NotImplementedError("BiLSTM pos_enc crashes in the reference (self.gated undefined, build_seq.py:55)")
+        elif feat == "ResNet":
+            cfg.encoder = _lib.ENC_RESNET
+        else:
+            raise NotImplementedError("Feat=VGG with Seq=None crashes in the reference (build_seq.py:78)")
     else:
         raise NotImplementedError(f"Feat={feat} Seq={seq} is not on the accelerated path")
-    cfg.dec_dim, cfg.dec_heads = int(pp["d_model"]), int(pp["nhead"])
-    cfg.dec_layers, cfg.dec_ff = int(pp["num_decoder_layers"]), int(pp["dim_feedforward"])
     cfg.vocab = int(opt["num_class"])
-    cfg.max_seq_len = int(pp["max_seq_len"])
+    cfg.batch_max_length = int(opt.get("batch_max_length", 0))
+    if pred["name"] == "TFM":
+        cfg.decoder = _lib.DEC_TFM
+        cfg.dec_dim, cfg.dec_heads = int(pp["d_model"]), int(pp["nhead"])
+        cfg.dec_layers, cfg.dec_ff = int(pp["num_decoder_layers"]), int(pp["dim_feedforward"])
+        cfg.max_seq_len = int(pp["max_seq_len"])
+    elif pred["name"] in ("Attn", "Attnv2"):
+        cfg.decoder = _lib.DEC_ATTN
+        cfg.attn_hidden = int(pp["hidden_size"])
+        cfg.attn_kernel_size, cfg.attn_kernel_dim = int(pp["kernel_size"]), int(pp["kernel_dim"])
+        cfg.attn_enc_init = int(bool(pp.get("enc_init", False)))
+        cfg.attn_coverage = int(pp.get("attn_type", "coverage") == "coverage")
+        sm = pp.get("seqmodel", "ViT")
+        if pred["name"] == "Attnv2":  # seq2seq_v2.py:182-199
+            if sm in ("BiLSTM", "VIG"):
+                cfg.attn_keys = _lib.ATTN_KEYS_ALL_INIT_MEAN
+            elif sm == "TFM":
+                cfg.attn_keys = _lib.ATTN_KEYS_NOCLS_INIT_CLS
+            else:
+                raise ValueError("seqmodel must be either BiLSTM or TFM option")
+        else:  # seq2seq.py:229-238
+            cfg.attn_keys = _lib.ATTN_KEYS_ALL_INIT_MEAN if sm == "BiLSTM" else _lib.ATTN_KEYS_ALL_INIT_FIRST
+    else:
+        raise NotImplementedError(f"Prediction '{pred['name']}' is not on the accelerated path")
     return cfg
 
 
@@ -149,6 +178,19 @@ class Engine:
                                                _lib.stream_of(memory)), "decode_greedy")
         s = steps.value
         return tokens[:, :s], logits[:, :s]
+
+    def decode_attn_greedy(self, memory, is_test):
+        """Attention/AttentionV2.forward_greedy in eval mode: full-size (preds_index [B,S], probs [B,S,V])."""
+        memory = memory.float().contiguous()
+        B, T, _ = memory.shape
+        S, V = self.cfg.batch_max_length + 1, self.cfg.vocab
+        tokens = torch.zeros((B, S), dtype=torch.int64, device=memory.device)
+        probs = torch.zeros((B, S, V), dtype=torch.float32, device=memory.device)
+        steps = C.c_int32(0)
+        self._check(self.lib.d2t_decode_attn_greedy(self.ctx, _lib.ptr(memory), B, T, int(bool(is_test)),
+                                                    _lib.ptr(tokens), _lib.ptr(probs), C.byref(steps),
+                                                    _lib.stream_of(memory)), "decode_attn_greedy")
+        return tokens, probs
 
     def decode_greedy_async(self, memory, start_tokens, ring=3):
         """Pipelined greedy decode (always max_seq_len+1 steps): returns views of engine-held

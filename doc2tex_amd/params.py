@@ -242,3 +242,79 @@ class PositionalEncoding2DParams(_Holder):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
         if missing_keys is not None and (prefix + "pe") in missing_keys:
             missing_keys.remove(prefix + "pe")
+
+
+class VGGFeatureExtractorParams(_Holder):
+    """VGG_FeatureExtractor, feature_extractor/vgg.py:5-41: same nn.Sequential indices -> same keys."""
+
+    def __init__(self, input_channel, output_channel=512):
+        super().__init__()
+        oc = [output_channel // 8, output_channel // 4, output_channel // 2, output_channel]
+        self.output_channel = oc
+        self.ConvNet = nn.Sequential(
+            nn.Conv2d(input_channel, oc[0], 3, 1, 1), nn.ReLU(True), nn.MaxPool2d(2, 2),
+            nn.Conv2d(oc[0], oc[1], 3, 1, 1), nn.ReLU(True), nn.MaxPool2d(2, 2),
+            nn.Conv2d(oc[1], oc[2], 3, 1, 1), nn.ReLU(True),
+            nn.Conv2d(oc[2], oc[2], 3, 1, 1), nn.ReLU(True), nn.MaxPool2d((2, 1), (2, 1)),
+            nn.Conv2d(oc[2], oc[3], 3, 1, 1, bias=False), nn.BatchNorm2d(oc[3]), nn.ReLU(True),
+            nn.Conv2d(oc[3], oc[3], 3, 1, 1, bias=False), nn.BatchNorm2d(oc[3]), nn.ReLU(True),
+            nn.MaxPool2d((2, 1), (2, 1)),
+            nn.Conv2d(oc[3], oc[3], 2, 1, 0), nn.ReLU(True))
+
+
+class BidirectionalLSTMParams(_Holder):
+    """BidirectionalLSTM, seq_modeling/bilstm.py:6-12."""
+
+    def __init__(self, input_size, hidden_size, output_size):
+        super().__init__()
+        self.rnn = nn.LSTM(input_size, hidden_size, bidirectional=True, batch_first=True)
+        self.linear = nn.Linear(hidden_size * 2, output_size)
+
+
+class _LocationAwareAttentionCellParams(_Holder):
+    """LocationAwareAttentionCell, prediction_head/addon_module/attention1D.py:121-133."""
+
+    def __init__(self, kernel_size, kernel_dim, hidden_dim, input_dim):
+        super().__init__()
+        self.loc_conv = nn.Conv1d(1, kernel_dim, kernel_size=2 * kernel_size + 1, padding=kernel_size, bias=True)
+        self.loc_proj = nn.Linear(kernel_dim, hidden_dim)
+        self.query_proj = nn.Linear(hidden_dim, hidden_dim)
+        self.key_proj = nn.Linear(input_dim, hidden_dim)
+        self.score = nn.Linear(hidden_dim, 1)
+
+
+class _LocationAwareAttentionParams(_Holder):
+    """LocationAwareAttention over BahdanauAttention, attention1D.py:88-97,203-214."""
+
+    def __init__(self, kernel_size, kernel_dim, input_size, hidden_size, num_embeddings, num_classes):
+        super().__init__()
+        self.attn = _LocationAwareAttentionCellParams(kernel_size, kernel_dim, hidden_size, input_size)
+        self.rnn = nn.LSTMCell(input_size + num_embeddings, hidden_size)
+        self.generator = nn.Linear(hidden_size, num_classes)
+
+
+class AttentionParams(_Holder):
+    """Attention.__init__ / AttentionV2, prediction_head/seq2seq.py:11-82 (location-aware cells only)."""
+
+    def __init__(self, kernel_size, kernel_dim, input_size, hidden_size, num_classes, embed_dim=None,
+                 attn_type="coverage", embed_target=False, enc_init=False, teacher_forcing=1.0, droprate=0.1,
+                 method="concat", seqmodel="ViT", viz_attn=False, device="cuda"):
+        super().__init__()
+        if attn_type not in ("coverage", "loc_aware"):
+            raise NotImplementedError(f"attn_type '{attn_type}' is not on the accelerated path")
+        if not embed_target:
+            raise NotImplementedError("embed_target=False (one-hot targets) is not on the accelerated path")
+        if embed_dim is None:
+            embed_dim = input_size
+        if input_size != 256 or hidden_size != 256 or embed_dim != 256:
+            raise NotImplementedError("the Attn kernel is built for input_size = hidden_size = embed_dim = 256")
+        self.embedding = nn.Embedding(num_classes, embed_dim, padding_idx=0)  # ATTN.START() = 0
+        self.attention_cell = _LocationAwareAttentionParams(kernel_size, kernel_dim, input_size, hidden_size,
+                                                            embed_dim, num_classes)
+        self.hidden_size, self.input_size, self.num_classes = hidden_size, input_size, num_classes
+        self.kernel_size, self.kernel_dim = kernel_size, kernel_dim
+        self.attn_type, self.enc_init, self.seqmodel, self.device = attn_type, enc_init, seqmodel, device
+        self.embed_target, self.teacher_forcing = embed_target, teacher_forcing
+        if enc_init:  # init_hidden, seq2seq.py:80-82
+            self.proj_init_h = nn.Linear(input_size, hidden_size, bias=True)
+            self.proj_init_c = nn.Linear(input_size, hidden_size, bias=True)

@@ -95,6 +95,34 @@ _CONFIGS = {
         "_batch": 2,
     },
 }
+def _attn(name, seqmodel):
+    return {"name": name, "params": {"input_size": 256, "hidden_size": 256, "kernel_size": 2, "kernel_dim": 128,
+                                     "embed_target": True, "enc_init": True, "attn_type": "coverage",
+                                     "seqmodel": seqmodel, "droprate": 0.0}}
+
+
+# C0: CNN feature extractor + recurrent (LSTMCell) attention decoder, the reference's CPU case, bs=4
+_CONFIGS["C0"] = {
+    "FeatureExtraction": {"name": "VGG", "params": {"input_channel": 1, "output_channel": 512}},
+    "SequenceModeling": {"name": "BiLSTM", "params": {"hidden_size": 256}},
+    "Prediction": _attn("Attn", "BiLSTM"),
+    "max_dimension": [32, 320],
+    "_crop": (32, 320),
+    "_batch": 4,
+}
+# S0: what every shipped YAML uses (config/train.yaml:17-49): HybridViT + Attnv2 coverage-LSTM decoder
+_CONFIGS["S0"] = {
+    "FeatureExtraction": {"name": "None", "params": {}},
+    "SequenceModeling": _vit_seq(),
+    "Prediction": _attn("Attnv2", "TFM"),
+    "max_dimension": [128, 512],
+    "_crop": (128, 512),
+    "_batch": 4,
+}
+_CONFIGS["TS0"] = copy.deepcopy(_CONFIGS["S0"])  # tiny S0
+_CONFIGS["TS0"]["SequenceModeling"] = _vit_seq(depth=2)
+_CONFIGS["TS0"]["max_dimension"] = [48, 64]
+_CONFIGS["TS0"]["_crop"] = (48, 64)
 _CONFIGS["C3"] = copy.deepcopy(_CONFIGS["C2"])
 _CONFIGS["C3"]["_batch"] = 32  # per GPU; 256 global over 8 GPUs
 
@@ -112,7 +140,8 @@ def make_config(name, device="cpu", max_seq_len=None, beam_size=None):
     cfg["imgH"] = None
     cfg["batch_max_length"] = MAX_LEN
     if max_seq_len is not None:
-        cfg["Prediction"]["params"]["max_seq_len"] = max_seq_len
+        if cfg["Prediction"]["name"] == "TFM":
+            cfg["Prediction"]["params"]["max_seq_len"] = max_seq_len
         cfg["batch_max_length"] = max_seq_len
     if beam_size is not None:
         cfg["beam_size"] = beam_size
@@ -168,7 +197,7 @@ def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0):
         v = g.standard_normal(shape) * 0.1
     elif leaf == "cls_token":
         v = g.standard_normal(shape) * 0.02
-    elif "word_embed" in name:
+    elif "word_embed" in name or name.endswith("Prediction.embedding.weight"):
         v = g.standard_normal(shape)
         v[0] = 0.0  # padding_idx row
     elif len(shape) == 4:  # conv: kaiming-normal fan_out (resnet.py:168), patch proj included
@@ -181,6 +210,8 @@ def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0):
         v = g.standard_normal(shape) * 0.02
         if end_bias and name.endswith("Prediction.proj.bias"):
             v[2] += end_bias  # raise the [s] logit so greedy rows terminate
+        if end_bias and name.endswith("attention_cell.generator.bias"):
+            v[1] += end_bias  # [s] = 1 for the Attn converter
     else:
         v = g.standard_normal(shape) * 0.02
     return torch.from_numpy(np.ascontiguousarray(v)).to(dtype)

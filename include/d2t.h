@@ -16,6 +16,8 @@
  *            recognizers/build_seq.py:42-83)
  *   d2t_decode_greedy
  *        <- TransformerPrediction.forward_greedy (eval)  prediction_head/tfm.py:119-143
+ *   d2t_decode_attn_greedy
+ *        <- Attention.forward_greedy seq2seq.py:224-331, AttentionV2.forward_greedy seq2seq_v2.py:176-293
  *   d2t_decode_beam
  *        <- TransformerPrediction.forward_beam tfm.py:145-186 + Beam tools/beam.py:38-140
  *   d2t_op_*  -- single-kernel entry points used by the parity tests.
@@ -54,7 +56,19 @@ enum {
   D2T_ESTATE = 4  /* call order (weights missing / not finalized) */
 };
 
-enum { D2T_ENC_RESNET = 0, D2T_ENC_HYBRID_VIT = 1 };
+enum {
+  D2T_ENC_RESNET = 0,        /* Feat=ResNet, Seq=None (+PositionalEncoding2D)          -> TFM decoder   */
+  D2T_ENC_HYBRID_VIT = 1,    /* Seq=ViT over the ResNet backbone (HybridEmbed)                          */
+  D2T_ENC_VGG_BILSTM = 2,    /* Feat=VGG,    height-mean, 2x BidirectionalLSTM          -> Attn decoder  */
+  D2T_ENC_RESNET_BILSTM = 3  /* Feat=ResNet, height-mean, 2x BidirectionalLSTM                          */
+};
+enum { D2T_DEC_TFM = 0, D2T_DEC_ATTN = 1 };
+/* d2t_config.attn_keys: which memory tokens the LSTM-attention decoder attends to / starts from */
+enum {
+  D2T_ATTN_KEYS_ALL_INIT_MEAN = 0,  /* Attention / AttentionV2 on a BiLSTM encoder (seq2seq.py:229-233)     */
+  D2T_ATTN_KEYS_NOCLS_INIT_CLS = 1, /* AttentionV2 with seqmodel='TFM' (seq2seq_v2.py:182-199): shipped YAMLs */
+  D2T_ATTN_KEYS_ALL_INIT_FIRST = 2  /* Attention (v1) on a non-BiLSTM encoder (seq2seq.py:234-236)          */
+};
 
 /* Activation codes of d2t_op_conv2d. */
 enum { D2T_ACT_NONE = 0, D2T_ACT_RELU = 1, D2T_ACT_GELU = 2 };
@@ -69,6 +83,16 @@ typedef struct d2t_config {
   int32_t dec_dim, dec_heads, dec_layers, dec_ff; /* TFM d_model / nhead / layers / dim_feedforward */
   int32_t vocab;        /* num_class */
   int32_t max_seq_len;  /* Prediction.params.max_seq_len */
+  /* appended in v2 of the struct: recurrent model family */
+  int32_t decoder;          /* D2T_DEC_* */
+  int32_t attn_hidden;      /* Attn hidden_size (= input_size = embed dim), 256 */
+  int32_t attn_kernel_size; /* location filter half width: Conv1d kernel = 2*k+1 */
+  int32_t attn_kernel_dim;  /* location filter channels */
+  int32_t attn_keys;        /* D2T_ATTN_KEYS_* */
+  int32_t attn_enc_init;    /* enc_init: initial (h,c) projected from the encoder output */
+  int32_t attn_coverage;    /* 1 = attn_type 'coverage' (accumulated alignment), 0 = 'loc_aware' */
+  int32_t bilstm_hidden;    /* SequenceModeling.params.hidden_size of the BiLSTM, 256 */
+  int32_t batch_max_length; /* Attn decoders run batch_max_length + 1 steps */
 } d2t_config;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -113,6 +137,15 @@ int d2t_encode(d2t_ctx* ctx, const float* image_dev, int32_t B, int32_t H, int32
 int d2t_decode_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T, const int64_t* start_tokens_dev,
                       int32_t is_test, int64_t* tokens_dev, float* logits_dev, int32_t* steps_out,
                       d2t_stream stream);
+
+/* ---- LSTM-attention greedy decode (Attn / Attnv2 heads, eval mode) ----------
+ * Attention.forward_greedy (prediction_head/seq2seq.py:224-331), AttentionV2.forward_greedy
+ * (seq2seq_v2.py:176-293) with is_train = False.  memory [B,T,256]; runs batch_max_length+1 steps in one
+ * launch.  tokens_dev [B,S] int64, probs_dev [B,S,V] fp32 (S = batch_max_length+1) are always full size;
+ * with is_test != 0 everything after the first step at which all rows emitted [s] is zeroed, as the
+ * reference leaves its pre-zeroed `probs` untouched after the early break. */
+int d2t_decode_attn_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T, int32_t is_test,
+                           int64_t* tokens_dev, float* probs_dev, int32_t* steps_out, d2t_stream stream);
 
 /* Pipelined variant: always runs max_seq_len+1 steps (is_test = 0 semantics) and returns as soon as the
  * work is enqueued, so the caller can start encoding the next batch while this one decodes (the decode

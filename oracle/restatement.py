@@ -368,6 +368,110 @@ def tfm_beam(mem, sd, p, layers, heads, max_seq_len, beam_size):
 
 
 # ---------------------------------------------------------------------------
+# VGG extractor, BiLSTM, LSTM-attention decoder (config C0 and the shipped ViT+Attnv2 configs)
+# ---------------------------------------------------------------------------
+ATTN_GO, ATTN_END = 0, 1  # modules/converter/attn_converter.py:8,19-29
+
+
+def vgg(x, sd, p, faithful=True):
+    """VGG_FeatureExtractor.forward, feature_extractor/vgg.py:16-44 (p = '...ConvNet.')."""
+    c = lambda x, i, pad=1: F.conv2d(x, sd[f"{p}{i}.weight"], sd.get(f"{p}{i}.bias"), 1, pad)
+    x = F.max_pool2d(F.relu(c(x, 0)), 2, 2)
+    x = F.max_pool2d(F.relu(c(x, 3)), 2, 2)
+    x = F.relu(c(x, 6))
+    x = F.max_pool2d(F.relu(c(x, 8)), (2, 1), (2, 1))
+    for conv, bn in ((11, 12), (14, 15)):
+        if faithful:
+            x = F.relu(_bn(c(x, conv), sd, f"{p}{bn}"))
+        else:
+            wf, bf = fold_bn(sd[f"{p}{conv}.weight"], sd, f"{p}{bn}")
+            x = F.relu(F.conv2d(x, wf, bf, 1, 1))
+        if conv == 14:
+            x = F.max_pool2d(x, (2, 1), (2, 1))
+    return F.relu(c(x, 18, 0))
+
+
+def bilstm(x, sd, p):
+    """BidirectionalLSTM.forward, seq_modeling/bilstm.py:14-24: nn.LSTM(bidirectional) + Linear.
+    x [B,T,in]; gate order i,f,g,o."""
+    B, T, _ = x.shape
+    outs = []
+    for sfx, order in (("", range(T)), ("_reverse", range(T - 1, -1, -1))):
+        wi, wh = sd[f"{p}rnn.weight_ih_l0{sfx}"], sd[f"{p}rnn.weight_hh_l0{sfx}"]
+        bi, bh = sd[f"{p}rnn.bias_ih_l0{sfx}"], sd[f"{p}rnn.bias_hh_l0{sfx}"]
+        H = wh.shape[1]
+        h = torch.zeros(B, H)
+        c = torch.zeros(B, H)
+        out = [None] * T
+        for t in order:
+            g = F.linear(x[:, t], wi, bi) + F.linear(h, wh, bh)
+            i, f, gg, o = g.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out[t] = h
+        outs.append(torch.stack(out, dim=1))
+    return F.linear(torch.cat(outs, dim=2), sd[p + "linear.weight"], sd[p + "linear.bias"])
+
+
+def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False):
+    """Attention.forward_greedy (prediction_head/seq2seq.py:224-331) / AttentionV2.forward_greedy
+    (seq2seq_v2.py:176-293) in eval mode (is_train=False) with embed_target=True, on the
+    LocationAwareAttention cell (addon_module/attention1D.py:121-161,203-242).
+
+    seqmodel: 'BiLSTM' (keys = all tokens, init from their mean), 'TFM' (AttentionV2: keys without the
+    cls token, init from the cls token), 'first' (Attention v1 on a non-BiLSTM encoder: keys = all
+    tokens, init from token 0)."""
+    B = batch_H.shape[0]
+    a = p + "attention_cell."
+    keys = batch_H[:, 1:] if seqmodel == "TFM" else batch_H
+    init = batch_H.mean(dim=1) if seqmodel == "BiLSTM" else batch_H[:, 0]
+    Hd = sd[a + "rnn.weight_hh"].shape[1]
+    if enc_init:
+        h = F.linear(init, sd[p + "proj_init_h.weight"], sd[p + "proj_init_h.bias"])
+        c = F.linear(init, sd[p + "proj_init_c.weight"], sd[p + "proj_init_c.bias"])
+    else:
+        h, c = torch.zeros(B, Hd), torch.zeros(B, Hd)
+    V = sd[a + "generator.weight"].shape[0]
+    T = keys.shape[1]
+    probs = torch.zeros(B, num_steps, V)
+    targets = torch.zeros(B, dtype=torch.long)  # [GO]
+    mem = None  # attention memory: None on the first step (-> zeros, attention1D.py:147-148)
+    alpha_cum = torch.zeros(B, T, 1)
+    end = torch.zeros(B, dtype=torch.bool)
+    kp = F.linear(keys, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
+    pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
+    for i in range(num_steps):
+        emb = F.embedding(targets, sd[p + "embedding.weight"])
+        hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
+        last = torch.zeros(B, T, 1) if mem is None else mem
+        loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
+        loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
+        e = F.linear(torch.tanh(kp + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])
+        alpha = F.softmax(e, dim=1)
+        context = torch.bmm(alpha.permute(0, 2, 1), keys).squeeze(1)
+        g = (F.linear(torch.cat([context, emb], 1), sd[a + "rnn.weight_ih"], sd[a + "rnn.bias_ih"])
+             + F.linear(h, sd[a + "rnn.weight_hh"], sd[a + "rnn.bias_hh"]))
+        gi, gf, gg, go = g.chunk(4, dim=1)
+        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+        h = torch.sigmoid(go) * torch.tanh(c)
+        out = F.linear(h, sd[a + "generator.weight"], sd[a + "generator.bias"])
+        if attn_type == "coverage":
+            alpha_cum = alpha_cum + alpha
+            mem = alpha_cum
+        else:  # loc_aware
+            mem = alpha
+        probs[:, i] = out
+        if i == num_steps - 1:
+            break
+        targets = out.argmax(1)
+        if is_test:
+            end |= targets == ATTN_END
+            if end.all():
+                break
+    return probs.argmax(2), probs
+
+
+# ---------------------------------------------------------------------------
 # Model.forward  (modules/build_model.py:36-79)
 # ---------------------------------------------------------------------------
 def forward_encoder(cfg, sd, image, faithful=True, taps=None):
@@ -379,6 +483,16 @@ def forward_encoder(cfg, sd, image, faithful=True, taps=None):
                                            sp["num_heads"], tuple(sp["patch_size"]), faithful, taps)
         shape = (size["height"] // sp["patch_size"][0], size["width"] // sp["patch_size"][1])
         return x, shape, pad_info
+    if seq["name"] == "BiLSTM":
+        # Feat=VGG|ResNet -> AdaptiveAvgPool2d((None,1)) over the height (build_feat.py:50-55) -> 2x BiLSTM
+        fe = resnet if cfg["FeatureExtraction"]["name"] == "ResNet" else vgg
+        f = fe(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful)
+        if taps is not None:
+            taps["backbone"] = f
+        x = f.permute(0, 3, 1, 2).mean(dim=3)  # [B,W,C]
+        for i in range(2):
+            x = bilstm(x, sd, f"seqmodeler.SequenceModeling.{i}.")
+        return x, None, None
     # Feat=ResNet, Seq=None, Pred=TFM: PositionalEncoding2D add then B,C,H,W -> B,HW,C
     # (recognizers/build_seq.py:69-76)
     f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful)
@@ -394,6 +508,13 @@ def forward(cfg, sd, image, text, is_train=True, is_test=False, faithful=False, 
     pp = cfg["Prediction"]["params"]
     mem, shape, pad = forward_encoder(cfg, sd, image, faithful)
     p = "predicter.Prediction."
+    if cfg["Prediction"]["name"] in ("Attn", "Attnv2"):
+        sm = pp.get("seqmodel", "ViT")
+        if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
+            sm = "first"  # seq2seq.py:229-238: keys = all tokens, init from token 0
+        preds, probs = attn_greedy(mem, sd, p, cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
+                                   pp.get("enc_init", False), is_test)
+        return preds, probs, {}
     if training:
         logits = tfm_full_pass(text, mem, sd, p, pp["num_decoder_layers"], pp["nhead"], key_padding=True)
         return logits.argmax(2), logits, {}

@@ -58,6 +58,8 @@ def engine_model(cfg_name, max_seq_len, wseed=1234, end_bias=0.0, beam_size=None
     cfg = synth.make_config(cfg_name, device=device, max_seq_len=max_seq_len, beam_size=beam_size)
     m = Model(cfg)
     tmpl = {k: v for k, v in m.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
+    for k in tmpl:
+        assert tmpl[k].dtype in (torch.float32, torch.int64), k
     sd = synth.synth_state_dict(tmpl, seed=wseed, end_bias=end_bias)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.endswith("image_positional_encoder.pe") for k in missing), (missing, unexpected)

@@ -38,7 +38,7 @@ def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.D2TConfig) == 4 * len(names)
 
 
-@pytest.mark.parametrize("name", ["C2", "C1", "T2"])
+@pytest.mark.parametrize("name", ["C2", "C1", "T2", "C0", "S0"])
 def test_state_dict_keys_and_shapes_match_reference_manifest(manifests, name):
     m = Model(synth.make_config(name))
     sd = m.state_dict()
@@ -91,8 +91,8 @@ def test_constructor_mutates_config_like_reference():
 
 
 def test_unsupported_configs_raise():
-    cfg = synth.make_config("C2")
-    cfg["Prediction"]["name"] = "Attn"
+    cfg = synth.make_config("C0")
+    cfg["Prediction"]["params"]["attn_type"] = "luong"
     with pytest.raises(NotImplementedError):
         Model(cfg)
     cfg = synth.make_config("C2")
