@@ -119,7 +119,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
