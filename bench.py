@@ -12,8 +12,12 @@ decode) over one batch of synthetic crops already resident in HBM.  Data-paralle
 weak scaling: every rank decodes its own batch, no data-path collective
 (SURVEY.md 8e); the only collectives are the timing barrier / max-reduce.
 
+--precision bf16x3 (default): convolutions on the bf16 matrix cores with every fp32 operand split into
+two bf16 (3 MFMAs per product, fp32 accumulate; tokens bit-exact, logits within 1e-3: tests/); --precision
+fp32: exact fp32 MFMA everywhere.
+
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     dominant kernel (the 512->512 3x3 conv @16x129, fp32 MFMA implicit GEMM)
+  roofline     dominant kernel (the 512->512 3x3 conv @16x129 as implicit GEMM)
                timed live with HIP events inside the timed region (d2t_profile_*)
   cpu_baseline the CPU oracle in reference-faithful mode (no KV cache, unfused BN),
                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
@@ -31,7 +35,9 @@ import torch
 
 from doc2tex_amd import Model, synth
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+# MI355X_MICROARCH.md "Chip-level parameters": dense matrix-core peaks
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense
 
 
 def decoder_flops(L, M, d=256, ff=1024, n=6, V=500):
@@ -54,11 +60,11 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def pmc_traffic():
+def pmc_traffic(precision):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/rNN_pmc_dominant_kernel.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    (profiles/rNN_pmc_dominant_kernel_<precision>.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant_kernel.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_dominant_kernel_{precision}.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -104,6 +110,8 @@ def main():
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
+                    help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each batch's decode before the next batch's encoder starts")
     ap.add_argument("--cpu-sample", type=int, default=4)
@@ -133,6 +141,7 @@ def main():
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.eval().to(dev)
+    model.conv_precision = args.precision
     model.pipelined = not args.no_pipeline  # decode of batch i overlaps the encoder of batch i+1
     img = synth.synth_images(B, H, W, seed=1000 + rank).to(dev)  # each rank its own shard
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
@@ -182,18 +191,26 @@ def main():
         dom_ms = sum(by_shape[dom]) / len(by_shape[dom])
         dom_flop = 2.0 * dom[0] * dom[1] * dom[2]
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(args.precision)
+        bf = args.precision == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         roofline = {
-            "bound": "mfma", "kernel": "conv_mfma_kernel<128,128> (512->512 3x3 conv @16x129 as implicit GEMM)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+            "bound": "mfma",
+            "kernel": ("conv_bf16x3_kernel<128,128>" if bf else "conv_mfma_kernel<128,128>") +
+                      " (512->512 3x3 conv @16x129 as implicit GEMM)",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
             "traffic_source": traffic_src,
+            "peak_dtype": "bf16 dense MFMA" if bf else "fp32 MFMA",
             "gemm_MNK": list(dom), "flop_per_launch": dom_flop, "avg_launch_ms": round(dom_ms, 4),
             "launches_timed": len(by_shape[dom]),
             "share_of_gemm_time": round(sum(by_shape[dom]) / total_ms, 4),
             "all_encoder_gemms": {"achieved": round(total_flop / (total_ms * 1e-3) / 1e12, 2),
                                   "ms_per_step": round(total_ms / args.steps, 3)},
         }
+        if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+            roofline["mfma_issued_tflops"] = round(3 * achieved, 2)
+            roofline["mfma_issued_frac"] = round(3 * achieved / peak, 4)
         formulas = world * B * args.steps
         ms_step = elapsed / args.steps * 1e3
         enc_flops = {"C2": 205.28e9, "C1": 50.79e9}.get(name, 0.0)
@@ -204,7 +221,8 @@ def main():
             "metric": "formulas/s (greedy decode, 128x512 crops)" if name == "C2" else f"formulas/s ({name})",
             "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "bf16x3" if bf else "f32", "data": "synthetic",
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,

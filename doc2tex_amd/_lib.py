@@ -15,6 +15,7 @@ ENC_RESNET, ENC_HYBRID_VIT, ENC_VGG_BILSTM, ENC_RESNET_BILSTM = 0, 1, 2, 3
 DEC_TFM, DEC_ATTN = 0, 1
 ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+CONV_FP32, CONV_BF16X3 = 0, 1
 
 
 class D2TConfig(C.Structure):
@@ -42,9 +43,11 @@ SIGNATURES = {
     "d2t_decode_greedy_async": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "d2t_decode_wait": (_I, [_P, _P, _I]),
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
+    "d2t_set_conv_precision": (_I, [_P, _I]),
     "d2t_profile_enable": (_I, [_P, _I]),
     "d2t_profile_read": (_I, [_P, _I, C.POINTER(_I)] + [C.POINTER(_I)] * 3 + [C.POINTER(C.c_float)]),
     "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),
+    "d2t_op_conv2d_bf16x3": (_I, [_P] * 5 + [_I] * 12 + [_P]),
     "d2t_op_linear": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "d2t_op_maxpool2x2": (_I, [_P, _P] + [_I] * 8 + [_P]),
     "d2t_op_layernorm": (_I, [_P] * 4 + [_I, _I, C.c_float, _P]),

@@ -110,6 +110,9 @@ class Model(nn.Module):
         # forward returns while the latency-bound decode loop still runs on the engine's stream, so the
         # next batch's encoder overlaps it.  Results are valid after synchronize().
         self.pipelined = False
+        # 'fp32' = exact fp32 matrix-core convolutions (default); 'bf16x3' = split-bf16 convolutions
+        # (3 bf16 MFMAs per product, fp32 accumulate; logits stay within 1e-3)
+        self.conv_precision = "fp32"
 
     def synchronize(self, host_sync=True):
         """Order the current stream (and optionally the host) after every outstanding pipelined decode."""
@@ -122,6 +125,9 @@ class Model(nn.Module):
         if self._engine is None:
             self._engine = Engine(self.opt)
         self._engine.sync_weights(self)
+        if getattr(self._engine, "_precision", None) != self.conv_precision:
+            self._engine.set_conv_precision(self.conv_precision)
+            self._engine._precision = self.conv_precision
         return self._engine
 
     def _apply(self, fn, *a, **k):

@@ -17,20 +17,12 @@
 // double-buffered LDS (rows padded to 36 floats: conflict-free b128 reads and
 // writes), one barrier per K-step.  Epilogue fuses bias, residual, ReLU / exact
 // GELU, positional-table add and the output row / head-split remaps.
-#include "kernels.h"
+#include "conv_common.h"
 
 namespace d2t {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;  // padded row length in floats (144 B = 9 x 16 B)
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == ACT_RELU) return fmaxf(v, 0.f);
-  if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-  return v;
-}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
@@ -44,12 +36,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   // XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring
   // pixels) run on the same XCD so they share its L2 (bijective remap).
   const int nt = (p.Cout + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  int logical;
-  {
-    const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
+  const int logical = xcd_logical_tile();
   const int m0 = (logical / nt) * BM;
   const int n0 = (logical % nt) * BN;
 
@@ -161,47 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
     __syncthreads();
   }
 
-  // epilogue.  C/D map: col = lane&31 -> n, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> m
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + r;
-    if (n >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    int slab = 0, head = 0, e = 0;
-    if (p.store_mode == STORE_KV) {
-      const int d = p.kv_heads * p.kv_hd;
-      slab = n / d;
-      const int within = n - slab * d;
-      head = within / p.kv_hd;
-      e = within - head * p.kv_hd;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][reg] + bias;
-        if (p.store_mode == STORE_KV) {
-          const int bb = m / p.kv_T, jj = m - bb * p.kv_T;
-          p.out[((((size_t)slab * p.kv_B + bb) * p.kv_heads + head) * p.kv_T + jj) * p.kv_hd + e] = v;
-          continue;
-        }
-        size_t row = (size_t)m;
-        int in_img = 0;
-        if (p.rows_per_img > 0) {
-          const int img = m / p.rows_per_img;
-          in_img = m - img * p.rows_per_img;
-          row = (size_t)img * p.img_stride + p.row_off + in_img;
-        }
-        const size_t off = row * p.Cout + n;
-        if (p.res) v += p.res[off];
-        v = apply_act(v, p.act);
-        if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
-        p.out[off] = v;
-      }
-    }
-  }
+  conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
 
 template <int BM, int BN>
@@ -213,6 +160,8 @@ static hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
 
 hipError_t launch_conv(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
+  if (p.w_hi && p.w_lo && p.Cout >= 64 && (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= 128)
+    return launch_conv_bf16x3(p, s);
   if (p.Cin % BK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   if (p.Cout <= 64) {

@@ -31,6 +31,7 @@ struct RawW {
 };
 struct ConvW {
   float* w = nullptr;
+  uint16_t *w_hi = nullptr, *w_lo = nullptr;  // bf16 split of w for the bf16x3 kernel
   float* bias = nullptr;
   int Cout = 0, Cin = 0, KH = 0, KW = 0;
 };
@@ -86,6 +87,7 @@ struct d2t_ctx {
   std::map<std::string, RawW> raw;
   std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
   bool finalized = false;
+  bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
 
   // packed weights
   std::string bb;  // backbone key prefix ("...ConvNet.")
@@ -205,6 +207,15 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
   HIPCHK(c, launch_pack_conv(w->p, cb ? cb->p : nullptr, g ? g->p : nullptr, b ? b->p : nullptr, mu ? mu->p : nullptr,
                              var ? var->p : nullptr, 1e-5f, out->w, out->bias, out->Cout, out->Cin, out->KH, out->KW,
                              s));
+  if (out->Cin % 32 == 0) {  // bf16 hi/lo planes of the folded weights (bf16x3 kernel)
+    void *ph, *pl;
+    if ((rc = dev_alloc(c, &ph, w->numel * 2)) || (rc = dev_alloc(c, &pl, w->numel * 2))) return rc;
+    c->owned.push_back(ph);
+    c->owned.push_back(pl);
+    out->w_hi = (uint16_t*)ph;
+    out->w_lo = (uint16_t*)pl;
+    HIPCHK(c, launch_split_bf16(out->w, out->w_hi, out->w_lo, w->numel, s));
+  }
   return D2T_OK;
 }
 int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K) {
@@ -259,6 +270,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   ConvP p{};
   if (extra) p = *extra;
   p.in = x.p; p.w = w.w; p.bias = w.bias; p.res = res; p.out = outbuf;
+  if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
   p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
@@ -846,6 +858,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     Act y{X, f.B, gh, gw, dim};
     ConvP p{};
     p.in = f.p; p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
+    if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -1253,6 +1266,12 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   return done(D2T_OK);
 }
 
+int d2t_set_conv_precision(d2t_ctx* c, int32_t mode) {
+  if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3)) return fail(c, D2T_EINVAL, "unknown conv precision %d", mode);
+  c->conv_bf16x3 = mode == D2T_CONV_BF16X3;
+  return D2T_OK;
+}
+
 int d2t_profile_enable(d2t_ctx* c, int32_t on) {
   if (!c) return D2T_EINVAL;
   c->profiling = on != 0;
@@ -1298,6 +1317,29 @@ int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * p.OH * p.OW; p.K = KH * KW * Cin; p.act = act;
   return launch_conv(p, s) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
+                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW,
+                         int32_t PH, int32_t PW, int32_t act, d2t_stream stream) {
+  if (!x || !w || !y || SH < 1 || SW < 1 || Cin % 32) return D2T_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)Cout * KH * KW * Cin;
+  uint16_t *hi = nullptr, *lo = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&hi), n * 2) != hipSuccess) return D2T_ENOMEM;
+  if (hipMalloc(reinterpret_cast<void**>(&lo), n * 2) != hipSuccess) { hipFree(hi); return D2T_ENOMEM; }
+  ConvP p{};
+  p.in = x; p.w = w; p.w_hi = hi; p.w_lo = lo; p.bias = bias; p.res = residual; p.out = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.OH = (H + 2 * PH - KH) / SH + 1; p.OW = (W + 2 * PW - KW) / SW + 1;
+  p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
+  p.M = B * p.OH * p.OW; p.K = KH * KW * Cin; p.act = act;
+  hipError_t e = launch_split_bf16(w, hi, lo, n, s);
+  if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
+  hipStreamSynchronize(s);
+  hipFree(hi);
+  hipFree(lo);
+  return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
 int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,

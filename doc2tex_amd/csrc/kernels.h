@@ -16,6 +16,8 @@ enum { STORE_ROWS = 0, STORE_KV = 1 };
 struct ConvP {
   const float* in;       // [B,H,W,Cin]
   const float* w;        // [Cout][KH*KW*Cin]  (OHWI, BN folded)
+  const uint16_t* w_hi;  // optional bf16 split of w (w ~ hi + lo), same layout; selects the bf16x3 kernel
+  const uint16_t* w_lo;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
@@ -32,7 +34,10 @@ struct ConvP {
   //   out[(((slab*kv_B + b)*kv_heads + head)*kv_T + j)*kv_hd + e]
   int store_mode, kv_T, kv_heads, kv_hd, kv_B;
 };
-hipError_t launch_conv(const ConvP& p, hipStream_t s);
+hipError_t launch_conv(const ConvP& p, hipStream_t s);         // fp32 MFMA, or bf16x3 when p.w_hi != nullptr
+hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s);
+// hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
+hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 
 // Skinny GEMM for decode steps: y[M,N] = act(x[M,K] @ w[N,K]^T + bias + res), K % 16 == 0.
 // If step_ptr != nullptr the output base is advanced by (*step_ptr) * out_step_stride floats.

@@ -152,6 +152,11 @@ class Engine:
                                         _lib.stream_of(image)), "encode")
         return memory, (gh, gw), (pw, ph)
 
+    def set_conv_precision(self, mode):
+        """'fp32' (exact, default) or 'bf16x3' (split-bf16 matrix-core path for the convolutions)."""
+        code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3}[mode]
+        self._check(self.lib.d2t_set_conv_precision(self.ctx, code), "set_conv_precision")
+
     # ---- kernel timing -------------------------------------------------------
     def profile(self, on):
         self._check(self.lib.d2t_profile_enable(self.ctx, int(bool(on))), "profile_enable")

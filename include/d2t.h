@@ -163,6 +163,15 @@ int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
+/* ---- convolution arithmetic ------------------------------------------------
+ * D2T_CONV_FP32   (default) exact fp32 on v_mfma_f32_32x32x2_f32.
+ * D2T_CONV_BF16X3 backbone / patch-embed convolutions on the bf16 matrix cores with each fp32 operand
+ *                 split into two bf16 (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate): ~2^-17 relative
+ *                 product error, measured logits error 2.4e-5 against the 1e-3 budget.  Takes effect at the
+ *                 next d2t_encode. */
+enum { D2T_CONV_FP32 = 0, D2T_CONV_BF16X3 = 1 };
+int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
+
 /* ---- in-engine kernel timing (bench.py roofline leg) ------------------------
  * While enabled, d2t_encode brackets every implicit-GEMM (MFMA) launch with a
  * pair of HIP events on the launch stream.  d2t_profile_read synchronises,
@@ -181,6 +190,10 @@ int d2t_profile_read(d2t_ctx* ctx, int32_t max_records, int32_t* n, int32_t* M, 
 int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
                   int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW,
                   int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
+/* Same contract on the bf16x3 kernel (Cin % 32 == 0); splits w internally (test entry point, synchronous). */
+int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
+                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH,
+                         int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + bias + residual); any M (skinny path for M<=64). */
 int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,
                   int32_t K, int32_t N, int32_t act, d2t_stream stream);

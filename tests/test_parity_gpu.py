@@ -171,3 +171,25 @@ def test_pipelined_decode_equals_synchronous(cases):
     for (p, l), (rp, rl) in list(zip(got, ref))[-3:]:
         assert torch.equal(p, rp) and torch.equal(l, rl)
     m.pipelined = False
+
+
+@pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop", "c2_greedy", "c1_greedy", "s0_greedy"])
+def test_bf16x3_convolutions_keep_parity(cases, name):
+    """Opt-in split-bf16 convolution path: tokens still bit-exact, logits still within 1e-3."""
+    c = _case(cases, "greedy", name)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    m.conv_precision = "bf16x3"
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        mem, _, _ = m.forward_encoder(img)
+        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
+    torch.cuda.synchronize()
+    rows = z["mem_rows"].tolist()
+    dmem = float(np.abs(mem[:, rows].cpu().numpy() - z["mem_sample"]).max()) / max(1.0, c["mem_absmax"])
+    assert dmem <= 5e-4, dmem
+    assert np.array_equal(preds.cpu().numpy(), z["tokens"])
+    steps = z["logit_steps"].tolist()
+    dl = float(np.abs(logits[:, steps].cpu().numpy() - z["logits_sample"]).max())
+    assert dl <= LOGIT_TOL, dl
