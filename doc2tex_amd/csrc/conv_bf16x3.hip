@@ -14,6 +14,9 @@
 // the 16-lane groups of every ds_read_b128 touch all 64 banks exactly once.
 // MFMA operand map (32x32x16 bf16): lane l holds A[row l&31][k = 8*(l>>5) + j], j = 0..7, and the
 // same for B with its column: one 16-byte chunk per lane per k16-step.
+#include <cstdlib>
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace d2t {
@@ -40,12 +43,15 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
   lo.y = *reinterpret_cast<const unsigned*>(&l23);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+template <int BM, int BN, int WM, int WN, bool DEEP>  // block tile, wave grid (WM x WN waves), pipelining depth
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kernel(const ConvP p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 32, NJ = WTN / 32;
-  constexpr int AR = BM / 32;          // A rows per thread per K-step (one float4 each)
-  constexpr int BC = BN * 4 / 256;     // B 16-byte chunks per thread per plane
+  constexpr int RPP = NT / 8;          // A rows staged per pass (8 threads x float4 per row)
+  constexpr int AR = BM / RPP;         // A rows per thread per K-step (one float4 each)
+  constexpr int BC = BN * 4 / NT;      // B 16-byte chunks per thread per plane
+  static_assert(AR >= 1 && BC >= 1 && MI >= 1 && NJ >= 1, "tile too small for the wave grid");
   constexpr int PLANE_A = BM * XROW, PLANE_B = BN * XROW;
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
   const int ohow = p.OH * p.OW;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + RPP * i;
     if (m < p.M) {
       const int b = m / ohow, rem = m - b * ohow;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -79,69 +85,71 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
   bool b_ok[BC];
 #pragma unroll
   for (int j = 0; j < BC; ++j) {
-    const int q = tid + 256 * j, row = q >> 2, c = q & 3;
+    const int q = tid + NT * j, row = q >> 2, c = q & 3;
     const int n = n0 + row;
     b_ok[j] = n < p.Cout;
     b_off[j] = (size_t)(b_ok[j] ? n : 0) * p.K + c * 8;
   }
 
-  float4 ra[AR];
-  uint4 rbh[BC], rbl[BC];
+  // Two register sets for the staged K-steps: loads for K-step t+2 are issued at the top of
+  // iteration t, while the set fetched one iteration earlier (K-step t+1) is converted and written to
+  // LDS in small pieces BETWEEN the MFMAs of step t, so VALU / LDS-store issue hides under the matrix pipe.
+  float4 ra[2][AR];
+  uint4 rbh[2][BC], rbl[2][BC];
   int kh = 0, kw = 0, c0 = 0;
   const int KT = p.K / XBK;
 
-  auto fetch = [&](int kt) {
+  auto fetch = [&](int kt, float4 (&xa)[AR], uint4 (&xh)[BC], uint4 (&xl)[BC]) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
+      // branch-free: out-of-image taps read a valid address (the tensor base) and are zeroed by a select
       const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-      if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-        const float* src = p.in + (size_t)(a_pix[i] + ih * p.W + iw) * p.Cin + c0 + kq * 4;
-        ra[i] = *reinterpret_cast<const float4*>(src);
-      } else {
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const size_t off = ok ? (size_t)(a_pix[i] + ih * p.W + iw) * p.Cin + c0 + kq * 4 : (size_t)(kq * 4);
+      const float4 v = *reinterpret_cast<const float4*>(p.in + off);
+      const unsigned msk = ok ? 0xFFFFFFFFu : 0u;  // bit-mask instead of a select keeps the load unconditional
+      xa[i] = make_float4(__uint_as_float(__float_as_uint(v.x) & msk), __uint_as_float(__float_as_uint(v.y) & msk),
+                          __uint_as_float(__float_as_uint(v.z) & msk), __uint_as_float(__float_as_uint(v.w) & msk));
     }
 #pragma unroll
     for (int j = 0; j < BC; ++j) {
-      if (b_ok[j]) {
-        rbh[j] = *reinterpret_cast<const uint4*>(p.w_hi + b_off[j] + (size_t)kt * XBK);
-        rbl[j] = *reinterpret_cast<const uint4*>(p.w_lo + b_off[j] + (size_t)kt * XBK);
-      } else {
-        rbh[j] = make_uint4(0, 0, 0, 0);
-        rbl[j] = make_uint4(0, 0, 0, 0);
-      }
+      const uint4 vh = *reinterpret_cast<const uint4*>(p.w_hi + b_off[j] + (size_t)kt * XBK);
+      const uint4 vl = *reinterpret_cast<const uint4*>(p.w_lo + b_off[j] + (size_t)kt * XBK);
+      const unsigned msk = b_ok[j] ? 0xFFFFFFFFu : 0u;
+      xh[j] = make_uint4(vh.x & msk, vh.y & msk, vh.z & msk, vh.w & msk);
+      xl[j] = make_uint4(vl.x & msk, vl.y & msk, vl.z & msk, vl.w & msk);
     }
-    c0 += XBK;
-    if (c0 == p.Cin) {
-      c0 = 0;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    // next K-step: taps cycle fastest, then the 32-channel chunk -> the nine taps of a chunk re-read the
+    // same 128-byte channel slices of neighbouring pixels back to back (L2 / L1 hits instead of HBM)
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += 32; }
     }
   };
-  auto stage = [&](int buf) {
+  // piece q of the staging work of one K-step: q < AR -> A row group q, else B chunk q - AR
+  auto stage_piece = [&](int buf, int q, const float4 (&xa)[AR], const uint4 (&xh)[BC], const uint4 (&xl)[BC]) {
     unsigned char* ah = smem + buf * STAGE;
     unsigned char* al = ah + PLANE_A;
     unsigned char* bh = al + PLANE_A;
     unsigned char* bl = bh + PLANE_B;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int row = lrow + 32 * i;
+    if (q < AR) {
+      const int row = lrow + RPP * q;
       const int off = row * XROW + swz_chunk(row, kq >> 1) * 16 + (kq & 1) * 8;
       uint2 hi, lo;
-      split4(ra[i], hi, lo);
+      split4(xa[q], hi, lo);
       *reinterpret_cast<uint2*>(ah + off) = hi;
       *reinterpret_cast<uint2*>(al + off) = lo;
-    }
-#pragma unroll
-    for (int j = 0; j < BC; ++j) {
-      const int q = tid + 256 * j, row = q >> 2, c = q & 3;
+    } else if (q - AR < BC) {
+      const int j = q - AR;
+      const int qq = tid + NT * j, row = qq >> 2, c = qq & 3;
       const int off = row * XROW + swz_chunk(row, c) * 16;
-      *reinterpret_cast<uint4*>(bh + off) = rbh[j];
-      *reinterpret_cast<uint4*>(bl + off) = rbl[j];
+      *reinterpret_cast<uint4*>(bh + off) = xh[j];
+      *reinterpret_cast<uint4*>(bl + off) = xl[j];
     }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
   f32x16 acc[MI][NJ];
@@ -152,13 +160,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  fetch(0);
-  stage(0);
+  // prologue: K-step 0 -> LDS[0]; K-step 1 in flight in set 1
+  fetch(0, ra[0], rbh[0], rbl[0]);
+#pragma unroll
+  for (int q = 0; q < AR + BC; ++q) stage_piece(0, q, ra[0], rbh[0], rbl[0]);
+  if (KT > 1) fetch(1, ra[1], rbh[1], rbl[1]);
   __syncthreads();
 
-  for (int kt = 0; kt < KT; ++kt) {
+  constexpr int NPIECE = AR + BC;
+  // K-step kt from LDS[kt&1]; if STAGE_NEXT the set (sa,sh,sl) = K-step kt+1 is converted and written
+  // to the other LDS buffer one piece per MFMA triple, and (FETCH) K-step kt+2 is loaded into (na,nh,nl).
+  auto compute = [&](int kt, auto stage_next, auto fetch_next, const float4 (&sa)[AR], const uint4 (&sh)[BC],
+                     const uint4 (&sl)[BC], float4 (&na)[AR], uint4 (&nh)[BC], uint4 (&nl)[BC]) {
+    constexpr bool STAGE_NEXT = decltype(stage_next)::value, FETCH = decltype(fetch_next)::value;
     const int cur = kt & 1;
-    if (kt + 1 < KT) fetch(kt + 1);
     const unsigned char* ah = smem + cur * STAGE;
     const unsigned char* al = ah + PLANE_A;
     const unsigned char* bh = al + PLANE_A;
@@ -181,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
         fbh[j] = *reinterpret_cast<const bf16x8*>(bh + off);
         fbl[j] = *reinterpret_cast<const bf16x8*>(bl + off);
       }
+      if (FETCH && kk == 0) fetch(kt + 2, na, nh, nl);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -188,10 +204,49 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(const ConvP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+          const int piece = (kk * MI + i) * NJ + j;  // compile-time after unrolling
+          if (STAGE_NEXT && DEEP && piece < NPIECE) stage_piece(cur ^ 1, piece, sa, sh, sl);
         }
     }
-    if (kt + 1 < KT) stage(cur ^ 1);
+    if (STAGE_NEXT) {  // leftovers (or, without DEEP, the whole staging: the loads were issued this iteration)
+#pragma unroll
+      for (int piece = DEEP ? 2 * MI * NJ : 0; piece < NPIECE; ++piece) stage_piece(cur ^ 1, piece, sa, sh, sl);
+    }
     __syncthreads();
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  if constexpr (!DEEP) {
+    // occupancy-driven variant (4 waves per SIMD): one register set, K-step t+1 fetched at the top of
+    // iteration t and staged after its MFMAs; other waves cover the staging time
+    for (int kt2 = 0; kt2 < KT; ++kt2) {
+      if (kt2 + 1 < KT) {
+        if (kt2 > 0) fetch(kt2 + 1, ra[1], rbh[1], rbl[1]);  // (K-step 1 was fetched in the prologue)
+        compute(kt2, T_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+      } else {
+        compute(kt2, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+      }
+    }
+    conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+    return;
+  }
+  // steady state (K-steps kt+1 and kt+2 exist), unrolled by two so the register sets are static
+  int kt = 0;
+  for (; kt + 3 < KT; kt += 2) {
+    compute(kt, T_{}, T_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+    compute(kt + 1, T_{}, T_{}, ra[0], rbh[0], rbl[0], ra[1], rbh[1], rbl[1]);
+  }
+  // tail: at most three K-steps left; set parity continues from the loop (kt is even)
+  if (kt + 2 < KT) {        // three left: kt, kt+1, kt+2
+    compute(kt, T_{}, T_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+    compute(kt + 1, T_{}, F_{}, ra[0], rbh[0], rbl[0], ra[1], rbh[1], rbl[1]);
+    compute(kt + 2, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+  } else if (kt + 1 < KT) { // two left
+    compute(kt, T_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
+    compute(kt + 1, F_{}, F_{}, ra[0], rbh[0], rbl[0], ra[1], rbh[1], rbl[1]);
+  } else if (kt < KT) {     // one left
+    compute(kt, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
   }
   conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
@@ -200,10 +255,14 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
   if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;
+  static const int variant = getenv("D2T_BF16X3_WAVES") ? atoi(getenv("D2T_BF16X3_WAVES")) : 4;
   if (p.Cout <= 64) {
-    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64>), dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2, true>), dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
+  } else if (variant == 4) {
+    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2, true>), dim3(mt * ((p.Cout + 127) / 128)), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128>), dim3(mt * ((p.Cout + 127) / 128)), dim3(256), 0, s, p);
+    // 8 waves per 128x128 tile (wave tile 32x64): 4 waves per SIMD at 2 blocks/CU keep the matrix pipe fed
+    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 4, 2, false>), dim3(mt * ((p.Cout + 127) / 128)), dim3(512), 0, s, p);
   }
   return hipGetLastError();
 }

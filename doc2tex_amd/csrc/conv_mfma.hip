@@ -91,10 +91,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
       rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(b_ptr[i] + (size_t)kt * BK)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    c0 += BK;
-    if (c0 == p.Cin) {
-      c0 = 0;
-      if (++kw == p.KW) { kw = 0; ++kh; }
+    // next K-step: taps cycle fastest, then the 32-channel chunk -> the nine taps of a chunk re-read the
+    // same 128-byte channel slices of neighbouring pixels back to back (L2 / L1 hits instead of HBM)
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += 32; }
     }
   };
   auto stage = [&](int buf) {

@@ -1310,13 +1310,19 @@ int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float
     return launch_stem(x, w, bias, y, B, H, W, Cout, act, s) == hipSuccess ? D2T_OK : D2T_EHIP;
   }
   if (Cin % 32) return D2T_EINVAL;
+  float* wp = nullptr;  // the kernel's K order (test entry point: temporary repack, synchronous)
+  if (hipMalloc(reinterpret_cast<void**>(&wp), (size_t)Cout * KH * KW * Cin * 4) != hipSuccess) return D2T_ENOMEM;
   ConvP p{};
-  p.in = x; p.w = w; p.bias = bias; p.res = residual; p.out = y;
+  p.in = x; p.w = wp; p.bias = bias; p.res = residual; p.out = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.OH = (H + 2 * PH - KH) / SH + 1; p.OW = (W + 2 * PW - KW) / SW + 1;
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * p.OH * p.OW; p.K = KH * KW * Cin; p.act = act;
-  return launch_conv(p, s) == hipSuccess ? D2T_OK : D2T_EHIP;
+  hipError_t e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
+  if (e == hipSuccess) e = launch_conv(p, s);
+  hipStreamSynchronize(s);
+  hipFree(wp);
+  return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
 int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
@@ -1326,19 +1332,23 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)Cout * KH * KW * Cin;
   uint16_t *hi = nullptr, *lo = nullptr;
+  float* wp = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&hi), n * 2) != hipSuccess) return D2T_ENOMEM;
   if (hipMalloc(reinterpret_cast<void**>(&lo), n * 2) != hipSuccess) { hipFree(hi); return D2T_ENOMEM; }
+  if (hipMalloc(reinterpret_cast<void**>(&wp), n * 4) != hipSuccess) { hipFree(hi); hipFree(lo); return D2T_ENOMEM; }
   ConvP p{};
-  p.in = x; p.w = w; p.w_hi = hi; p.w_lo = lo; p.bias = bias; p.res = residual; p.out = y;
+  p.in = x; p.w = wp; p.w_hi = hi; p.w_lo = lo; p.bias = bias; p.res = residual; p.out = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.OH = (H + 2 * PH - KH) / SH + 1; p.OW = (W + 2 * PW - KW) / SW + 1;
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * p.OH * p.OW; p.K = KH * KW * Cin; p.act = act;
-  hipError_t e = launch_split_bf16(w, hi, lo, n, s);
+  hipError_t e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
+  if (e == hipSuccess) e = launch_split_bf16(wp, hi, lo, n, s);
   if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
   hipStreamSynchronize(s);
   hipFree(hi);
   hipFree(lo);
+  hipFree(wp);
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 

@@ -10,12 +10,12 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 enum { STORE_ROWS = 0, STORE_KV = 1 };
 
 // Implicit-GEMM convolution / linear layer:
-//   out[row(m)][n] = act( sum_{kh,kw,c} in[b, oh*SH-PH+kh, ow*SW-PW+kw, c] * w[n][(kh*KW+kw)*Cin+c]
+//   out[row(m)][n] = act( sum_{kh,kw,c} in[b, oh*SH-PH+kh, ow*SW-PW+kw, c] * w[n][((c/32)*KH*KW + kh*KW+kw)*32 + c%32]
 //                         + bias[n] + res[row(m)][n] ) + row_add[add_row(m)][n]
 // with m = (b*OH + oh)*OW + ow, out-of-range taps reading zero.
 struct ConvP {
   const float* in;       // [B,H,W,Cin]
-  const float* w;        // [Cout][KH*KW*Cin]  (OHWI, BN folded)
+  const float* w;        // [Cout][K], BN folded, K swept as (32-channel chunk, tap, channel-in-chunk)
   const uint16_t* w_hi;  // optional bf16 split of w (w ~ hi + lo), same layout; selects the bf16x3 kernel
   const uint16_t* w_lo;
   const float* bias;     // [Cout] or nullptr
@@ -163,6 +163,8 @@ hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, in
 hipError_t launch_pack_conv(const float* w_oihw, const float* conv_bias, const float* bn_w, const float* bn_b,
                             const float* bn_mean, const float* bn_var, float eps, float* w_out, float* bias_out,
                             int Cout, int Cin, int KH, int KW, hipStream_t s);
+// plain OHWI [Cout][KH][KW][Cin] -> the kernels' K order [Cout][Cin/32][KH*KW][32] (Cin % 32 == 0)
+hipError_t launch_repack_ohwi(const float* w_ohwi, float* w_out, int Cout, int KH, int KW, int Cin, hipStream_t s);
 hipError_t launch_copy(const float* src, float* dst, size_t n, hipStream_t s);
 hipError_t launch_add_rows(const float* a, const float* b, float* out, int n, hipStream_t s);  // out = a + b
 // out[b*img_stride*D + i] = row[i] for i < D  (cls-token row of every image)

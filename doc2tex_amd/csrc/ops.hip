@@ -272,7 +272,11 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
     const int kh = (int)((idx / ((long long)Cin * KW)) % KH);
     const int o = (int)(idx / ((long long)Cin * KW * KH));
     const float s = g ? g[o] / sqrtf(var[o] + eps) : 1.f;
-    wo[idx] = w[(((size_t)o * Cin + c) * KH + kh) * KW + kw] * s;
+    // K order of the packed weights = the order the conv kernels sweep K: 32-channel chunk outermost,
+    // filter tap inside it, channel within the chunk innermost (see conv_common.h: advance_k)
+    const size_t kdst = ((size_t)(c >> 5) * KH * KW + (size_t)kh * KW + kw) * 32 + (c & 31);
+    const size_t dst = Cin % 32 == 0 ? (size_t)o * Cin * KH * KW + kdst : (size_t)idx;
+    wo[dst] = w[(((size_t)o * Cin + c) * KH + kh) * KW + kw] * s;
     if (c == 0 && kw == 0 && kh == 0) {
       float bias = cb ? cb[o] * s : 0.f;
       if (g) bias += be[o] - mu[o] * s;
@@ -288,6 +292,23 @@ hipError_t launch_pack_conv(const float* w_oihw, const float* conv_bias, const f
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, conv_bias, bn_w, bn_b, bn_mean, bn_var,
                      eps, w_out, bias_out, Cout, Cin, KH, KW);
+  return hipGetLastError();
+}
+
+__global__ void repack_ohwi_kernel(const float* __restrict__ w, float* __restrict__ wo, int Cout, int KH, int KW, int Cin) {
+  const long long total = (long long)Cout * KH * KW * Cin;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cin);
+    const int tap = (int)((idx / Cin) % (KH * KW));
+    const long long o = idx / ((long long)Cin * KH * KW);
+    wo[o * Cin * KH * KW + ((size_t)(c >> 5) * KH * KW + tap) * 32 + (c & 31)] = w[idx];
+  }
+}
+hipError_t launch_repack_ohwi(const float* w_ohwi, float* w_out, int Cout, int KH, int KW, int Cin, hipStream_t s) {
+  const long long total = (long long)Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(repack_ohwi_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)),
+                     dim3(256), 0, s, w_ohwi, w_out, Cout, KH, KW, Cin);
   return hipGetLastError();
 }
 
