@@ -251,10 +251,185 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
   conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
 
+// ---------------------------------------------------------------------------
+// Split-activation kernel with LDS-DMA staging.  The input arrives as split-bf16 records written by the
+// producing layer's epilogue (conv_common.h plane_idx), so staging A is a pure 16-byte copy like B: no
+// conversion and almost no address arithmetic in the K loop (the on-the-fly variant above spends ~5 VALU
+// instructions per MFMA on it).  Per output row a 16-bit validity mask over the filter taps and a signed
+// element offset are computed once.  Both operands are pure copies, so every 16-byte chunk
+// goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write).  The LDS
+// destination of a wave instruction is linear (base + lane*16 = 16 rows x 64 B of one plane), so the
+// XOR swizzle of the k-chunk is applied to the per-lane SOURCE address and again on the ds_read side
+// (cdna guide rule 21).  Out-of-image taps / rows beyond Cout point the source at a zero page.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int BM, int BN, int WM>  // wave grid WM x 2
+__device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char* smem) {
+  constexpr int NW = WM * 2;
+  constexpr int WTM = BM / WM, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NJ = WTN / 32;
+  constexpr int AJ = BM / (16 * NW);  // 16-row (1 KiB) pieces per wave per A plane
+  constexpr int BJ = BN / (16 * NW);
+  static_assert(AJ >= 1 && BJ >= 1, "tile too small for the wave count");
+  constexpr int PLANE_A = BM * XROW, PLANE_B = BN * XROW;
+  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
+
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int logical = xcd_logical_tile();
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane >> 2, pos = lane & 3;
+
+  int a_off[AJ];
+  unsigned a_mask[AJ];
+  const int ohow = p.OH * p.OW;
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int row = (wave * AJ + j) * 16 + lr;
+    const int c = swz_chunk(row, pos);  // the chunk that belongs at LDS position `pos` of this row
+    const int m = m0 + row;
+    a_off[j] = 0;
+    a_mask[j] = 0;
+    if (m < p.M) {
+      const int b = m / ohow, rem = m - b * ohow;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+      a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cin * 2 + c * 8;
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W)
+            a_mask[j] |= 1u << (kh * p.KW + kw);
+    }
+  }
+  const uint16_t* b_hi[BJ];
+  const uint16_t* b_lo[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = (wave * BJ + j) * 16 + lr;
+    const int c = swz_chunk(row, pos);
+    const int n = n0 + row;
+    const bool ok = n < p.Cout;
+    b_hi[j] = ok ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
+    b_lo[j] = ok ? p.w_lo + (size_t)n * p.K + c * 8 : nullptr;
+  }
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+  int kh = 0, kw = 0, c0 = 0;
+  const int KT = p.K / XBK;
+
+  auto issue = [&](int kt, int buf) {
+    unsigned char* ah = smem + buf * STAGE;
+    unsigned char* al = ah + PLANE_A;
+    unsigned char* bh = al + PLANE_A;
+    unsigned char* bl = bh + PLANE_B;
+    const int tap = kh * p.KW + kw;
+    const int tapoff = ((kh * p.W + kw) * p.Cin + c0) * 2;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const bool ok = (a_mask[j] >> tap) & 1u;
+      const uint16_t* src = ok ? p.in_hi + (a_off[j] + tapoff) : zero;
+      const int piece = (wave * AJ + j) * 1024;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr)(ah + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ok ? src + 32 : zero, (lds_ptr)(al + piece), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int piece = (wave * BJ + j) * 1024;
+      __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * XBK : zero, (lds_ptr)(bh + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * XBK : zero, (lds_ptr)(bl + piece), 16, 0, 0);
+    }
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += 32; }
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, cur ^ 1);  // DMA for the next K-step flies under this step's MFMAs
+    __builtin_amdgcn_sched_barrier(0);         // keep the DMA issue ahead of the ds_reads / MFMAs
+    const unsigned char* ah = smem + cur * STAGE;
+    const unsigned char* al = ah + PLANE_A;
+    const unsigned char* bh = al + PLANE_A;
+    const unsigned char* bl = bh + PLANE_B;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = 2 * kk + h;
+      bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WTM + i * 32 + r;
+        const int off = row * XROW + swz_chunk(row, c) * 16;
+        fah[i] = *reinterpret_cast<const bf16x8*>(ah + off);
+        fal[i] = *reinterpret_cast<const bf16x8*>(al + off);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn * WTN + j * 32 + r;
+        const int off = row * XROW + swz_chunk(row, c) * 16;
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + off);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + off);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+    __syncthreads();                                   // ... and everyone else's; reads of `cur` are done
+  }
+  conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+}
+
+// non-template entry points (the host-side stub of a __global__ template using the LDS-DMA builtin is not emitted)
+__global__ __launch_bounds__(256, 2) void conv_bf16x3g_128x128(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
+  conv_bf16x3g_body<128, 128, 2>(p, smem);
+}
+__global__ __launch_bounds__(512, 4) void conv_bf16x3g_128x128_w8(const ConvP p) {  // 8 waves, wave tile 32x64
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
+  conv_bf16x3g_body<128, 128, 4>(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void conv_bf16x3g_128x64(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 64 * XROW)];
+  conv_bf16x3g_body<128, 64, 2>(p, smem);
+}
+
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
   if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;
+  if (p.in_hi) {  // split-bf16 input planes
+    if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (p.Cout <= 64) {
+      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
+    } else {
+      // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
+      static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
+      if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(mt * ((p.Cout + 127) / 128)), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(mt * ((p.Cout + 127) / 128)), dim3(512), 0, s, p);
+    }
+    return hipGetLastError();
+  }
   static const int variant = getenv("D2T_BF16X3_WAVES") ? atoi(getenv("D2T_BF16X3_WAVES")) : 4;
   if (p.Cout <= 64) {
     hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2, true>), dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
@@ -277,6 +452,36 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, uint16_t* __restr
     lo[i] = *reinterpret_cast<const uint16_t*>(&l);
   }
 }
+__global__ void split_act_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t rows, int C) {
+  const size_t n = rows * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint16_t hi, lo;
+    split_f32(x[i], hi, lo);
+    const size_t o = plane_idx(i / C, (int)(i % C), C);
+    planes[o] = hi;
+    planes[o + 32] = lo;
+  }
+}
+__global__ void merge_act_kernel(const uint16_t* __restrict__ planes, float* __restrict__ x, size_t rows, int C) {
+  const size_t n = rows * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = plane_idx(i / C, (int)(i % C), C);
+    x[i] = bf16_bits_to_f32(planes[o]) + bf16_bits_to_f32(planes[o + 32]);
+  }
+}
+hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s) {
+  const size_t n = rows * C;
+  hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+                     s, x, planes, rows, C);
+  return hipGetLastError();
+}
+hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s) {
+  const size_t n = rows * C;
+  hipLaunchKernelGGL(merge_act_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+                     s, planes, x, rows, C);
+  return hipGetLastError();
+}
+
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
                      s, w, hi, lo, n);

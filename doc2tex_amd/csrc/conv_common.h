@@ -12,6 +12,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// fp32 <-> split bf16 (hi = upper 16 bits, lo = bf16(x - hi), round to nearest even)
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ void split_f32(float x, uint16_t& hi, uint16_t& lo) {
+  const unsigned u = __float_as_uint(x);
+  hi = (uint16_t)(u >> 16);
+  const __bf16 l = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
+  lo = *reinterpret_cast<const uint16_t*>(&l);
+}
+
+// Split-activation layout ("planes"): per row and per 32-channel group one 128-byte record
+// [32 x hi | 32 x lo] (bf16), so both halves of a K-step's operand share a cache line.
+// Index (in uint16 units) of the hi part of element (row, c); the lo part sits 32 elements further.
+__device__ __forceinline__ size_t plane_idx(size_t row, int c, int C) {
+  return (row * C + (size_t)(c & ~31)) * 2 + (c & 31);
+}
+
 // XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring pixels) run on the
 // same XCD so they share its L2 (bijective remap, cdna guide T1).
 __device__ __forceinline__ int xcd_logical_tile() {
@@ -58,9 +74,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][
         }
         const size_t off = row * p.Cout + n;
         if (p.res) v += p.res[off];
+        if (p.res_hi) {
+          const size_t ri = plane_idx(row, n, p.Cout);
+          v += bf16_bits_to_f32(p.res_hi[ri]) + bf16_bits_to_f32(p.res_hi[ri + 32]);
+        }
         v = apply_act(v, p.act);
         if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
-        p.out[off] = v;
+        if (p.out_hi) {
+          uint16_t hi, lo;
+          split_f32(v, hi, lo);
+          const size_t oi = plane_idx(row, n, p.Cout);
+          p.out_hi[oi] = hi;
+          p.out_hi[oi + 32] = lo;
+        } else {
+          p.out[off] = v;
+        }
       }
     }
   }

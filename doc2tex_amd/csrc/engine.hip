@@ -76,7 +76,9 @@ struct AttnW {
 struct Act {
   float* p;
   int B, H, W, C;
+  bool split = false;  // two bf16 planes (hi | lo) in the same buffer instead of fp32
   size_t numel() const { return (size_t)B * H * W * C; }
+  uint16_t* planes() const { return reinterpret_cast<uint16_t*>(p); }
 };
 
 }  // namespace
@@ -127,6 +129,7 @@ struct d2t_ctx {
   int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]
   size_t dstate_cap = 0;
   int* h_pinned = nullptr;
+  void* zero_page = nullptr;  // 256 zero bytes: out-of-image taps of the split-bf16 convolution
   hipStream_t dstream = nullptr;
   hipEvent_t ev_in = nullptr;
   struct GraphKey { int B, T; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
@@ -264,13 +267,21 @@ hipError_t conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) {
   return e != hipSuccess ? e : e2;
 }
 
+// One convolution of the backbone.  `res` may be nullptr; `out_split` asks for split-bf16 output planes
+// (only meaningful on the bf16x3 path; the consumer must be another bf16x3 convolution or the split pool).
 Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& w, int sh, int sw, int ph, int pw,
-         int act, const float* res, float* outbuf, const ConvP* extra = nullptr) {
+         int act, const Act* res, float* outbuf, const ConvP* extra = nullptr, bool out_split = false) {
   Act y{outbuf, x.B, (x.H + 2 * ph - w.KH) / sh + 1, (x.W + 2 * pw - w.KW) / sw + 1, w.Cout};
+  y.split = out_split;
   ConvP p{};
   if (extra) p = *extra;
-  p.in = x.p; p.w = w.w; p.bias = w.bias; p.res = res; p.out = outbuf;
+  p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
+  if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; } else { p.in = x.p; }
+  if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
+  if (res) {
+    if (res->split) { p.res_hi = res->planes(); } else { p.res = res->p; }
+  }
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
   p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
@@ -307,42 +318,47 @@ float* pick(d2t_ctx* c, std::initializer_list<const float*> live) {
   return nullptr;
 }
 
+// ResNet.forward (feature_extractor/resnet.py:205-245).  On the bf16x3 path every activation between the
+// stem and the last convolution lives as split-bf16 planes; `final_split` says whether the returned map
+// does too (a bf16x3 consumer follows) or is fp32 (final_out / any other consumer).
 int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int W, Act* out, float* final_out,
-                 const ConvP* final_extra) {
+                 const ConvP* final_extra, bool final_split) {
   hipError_t err = hipSuccess;
+  const bool sp = c->conv_bf16x3;
   Act x{pick(c, {}), B, H, W, c->stem.Cout};
-  HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
-  x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x.split = sp;
+  if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s));
+  else HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
+  x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
     Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
-    hipError_t e = launch_maxpool(a.p, y.p, a.B, a.H, a.W, a.C, sh, sw, ph, pw, s);
+    y.split = a.split;
+    hipError_t e = a.split ? launch_maxpool_split(a.planes(), y.planes(), a.B, a.H, a.W, a.C, sh, sw, ph, pw, s)
+                           : launch_maxpool(a.p, y.p, a.B, a.H, a.W, a.C, sh, sw, ph, pw, s);
     if (e != hipSuccess && err == hipSuccess) err = e;
     return y;
   };
   auto stage = [&](int li) {
     for (const Block& b : c->layers[li]) {
-      Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
-      const float* res = x.p;
-      if (b.has_down) {
-        Act r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}));
-        res = r.p;
-      }
-      x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, res, pick(c, {x.p, t.p, res}));
+      Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
+      Act r = x;
+      if (b.has_down) r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}), nullptr, sp);
+      x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &r, pick(c, {x.p, t.p, r.p}), nullptr, sp);
     }
   };
   x = pool(x, 2, 2, 0, 0);
   stage(0);
-  x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = pool(x, 2, 2, 0, 0);
   stage(1);
-  x = conv(c, s, &err, x, c->conv2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = conv(c, s, &err, x, c->conv2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = pool(x, 2, 1, 0, 1);
   stage(2);
-  x = conv(c, s, &err, x, c->conv3, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = conv(c, s, &err, x, c->conv3, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   stage(3);
-  x = conv(c, s, &err, x, c->conv4_1, 2, 1, 0, 1, ACT_RELU, nullptr, pick(c, {x.p}));
+  x = conv(c, s, &err, x, c->conv4_1, 2, 1, 0, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = conv(c, s, &err, x, c->conv4_2, 1, 1, 0, 0, ACT_RELU, nullptr, final_out ? final_out : pick(c, {x.p}),
-           final_extra);
+           final_extra, sp && final_split && !final_out);
   if (err != hipSuccess) return fail(c, D2T_EHIP, "backbone launch: %s", hipGetErrorString(err));
   *out = x;
   return D2T_OK;
@@ -430,6 +446,8 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault));
+  HIPCHK(c, hipMalloc(&c->zero_page, 256));
+  HIPCHK(c, hipMemset(c->zero_page, 0, 256));
   return D2T_OK;
 }
 
@@ -452,6 +470,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->zero_page) hipFree(c->zero_page);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->dstream) hipStreamDestroy(c->dstream);
   delete c;
@@ -817,7 +836,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
       x = pool(x, 2, 1);
       f = conv(c, s, &err, x, c->vgg[6], 1, 1, 0, 0, ACT_RELU, nullptr, pick(c, {x.p}));
       if (err != hipSuccess) return fail(c, D2T_EHIP, "VGG launch: %s", hipGetErrorString(err));
-    } else if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr))) {
+    } else if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr, false))) {
       return rc;
     }
     if (f.W != T || f.C != 512) return fail(c, D2T_EINVAL, "unexpected feature map %dx%dx%d", f.H, f.W, f.C);
@@ -846,9 +865,9 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     if ((rc = get_pe2d(c, fh, fw, g.backbone_out, s, &pe))) return rc;
     ConvP ex{};
     ex.row_add = pe; ex.rows_per_img = fh * fw; ex.img_stride = fh * fw; ex.row_off = 0; ex.row_add_off = 0;
-    return run_backbone(c, s, image, B, H, W, &f, memory, &ex);
+    return run_backbone(c, s, image, B, H, W, &f, memory, &ex, false);
   }
-  if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr))) return rc;
+  if ((rc = run_backbone(c, s, image, B, H, W, &f, nullptr, nullptr, true))) return rc;
   // HybridEmbed.forward (patchembed.py:115-141): zero-pad right/bottom + Conv2d(k=s=patch) as one
   // implicit GEMM whose out-of-range taps read zero; epilogue adds pos_embed[1+i] (flat prefix
   // slice, vit_encoder.py:260) and leaves row 0 of every image for the cls token.
@@ -857,8 +876,9 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
   {
     Act y{X, f.B, gh, gw, dim};
     ConvP p{};
-    p.in = f.p; p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
+    p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
+    if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; } else { p.in = f.p; }
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -1349,6 +1369,45 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
   hipFree(hi);
   hipFree(lo);
   hipFree(wp);
+  return e == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
+int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                               int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream) {
+  // test entry for the split-activation kernel: input, residual and output travel as bf16 hi/lo records
+  if (!x || !w || !y || SH < 1 || SW < 1 || Cin % 32 || Cout % 32) return D2T_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+  const size_t nw = (size_t)Cout * KH * KW * Cin, rx = (size_t)B * H * W, ry = (size_t)B * OH * OW;
+  const size_t nx = rx * Cin, ny = ry * Cout;
+  void* buf = nullptr;
+  const size_t bytes = nw * 4 + nw * 4 + nx * 4 + ny * 4 + (residual ? ny * 4 : 0) + 256;
+  if (hipMalloc(&buf, bytes) != hipSuccess) return D2T_ENOMEM;
+  char* q = (char*)buf;
+  float* wp = (float*)q; q += nw * 4;
+  uint16_t* whi = (uint16_t*)q; q += nw * 2;
+  uint16_t* wlo = (uint16_t*)q; q += nw * 2;
+  uint16_t* xs = (uint16_t*)q; q += nx * 4;
+  uint16_t* ys = (uint16_t*)q; q += ny * 4;
+  uint16_t* rs = nullptr;
+  if (residual) { rs = (uint16_t*)q; q += ny * 4; }
+  void* zero = q;
+  ConvP p{};
+  p.w = wp; p.w_hi = whi; p.w_lo = wlo; p.bias = bias;
+  p.in_hi = xs; p.out_hi = ys; p.res_hi = rs; p.zero16 = zero;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
+  p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
+  p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
+  hipError_t e = hipMemsetAsync(zero, 0, 256, s);
+  if (e == hipSuccess) e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
+  if (e == hipSuccess) e = launch_split_bf16(wp, whi, wlo, nw, s);
+  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s);
+  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s);
+  if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
+  if (e == hipSuccess) e = launch_merge_act(ys, y, ry, Cout, s);
+  hipStreamSynchronize(s);
+  hipFree(buf);
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 

@@ -18,6 +18,14 @@ struct ConvP {
   const float* w;        // [Cout][K], BN folded, K swept as (32-channel chunk, tap, channel-in-chunk)
   const uint16_t* w_hi;  // optional bf16 split of w (w ~ hi + lo), same layout; selects the bf16x3 kernel
   const uint16_t* w_lo;
+  // split-bf16 activations (x ~ hi + lo): per row and 32-channel group a 128-byte record
+  // [32 x hi | 32 x lo] (conv_common.h plane_idx).  When in_hi != nullptr the bf16x3 kernel reads that
+  // instead of `in`; when out_hi != nullptr the epilogue writes it instead of `out`; a residual may come
+  // in the same form.  zero16 points at >= 16 zero bytes (out-of-image taps).
+  const uint16_t* in_hi;
+  uint16_t* out_hi;
+  const uint16_t* res_hi;
+  const void* zero16;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
@@ -57,8 +65,17 @@ hipError_t launch_skinny(const SkinnyP& p, hipStream_t s);
 // conv0_1: Cin = 1, 3x3, stride 1, pad 1, Cout % 4 == 0, fused bias + ReLU.  w [Cout][9].
 hipError_t launch_stem(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
                        int act, hipStream_t s);
+// same, writing split-bf16 planes
+hipError_t launch_stem_split(const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
+                             int Cout, int act, hipStream_t s);
+// fp32 [rows][C] <-> split-activation records (C % 32 == 0); used by the test entry point
+hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s);
+hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s);
 hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
                           hipStream_t s);  // 2x2 window
+// 2x2 max-pool on split-bf16 planes (reconstruct, max, re-split)
+hipError_t launch_maxpool_split(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, int SH, int SW, int PH,
+                                int PW, hipStream_t s);
 hipError_t launch_maxpool_k(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
                             int PH, int PW, hipStream_t s);
 // y[b][w][c] = mean_h x[b][h][w][c]   (AdaptiveAvgPool2d((None,1)) on the permuted map, build_feat.py:50-55)

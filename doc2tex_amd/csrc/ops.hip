@@ -1,7 +1,7 @@
 // Non-GEMM kernels of the recognizer path (gfx950, 64-wide wavefronts, fp32).
 // Each kernel names the reference op sequence it replaces (paths relative to
 // /root/reference/doc2tex/modules/component/).
-#include "kernels.h"
+#include "conv_common.h"
 
 namespace d2t {
 
@@ -55,6 +55,52 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   }
 }
 
+__global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                         int B, int H, int W, int Cout, int act) {
+  const int cq = Cout >> 2;
+  const long long total = (long long)B * H * W * cq;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq);
+    const long long pix = idx / cq;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    const float* im = img + b * H * W;
+    float v[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + kh - 1, xx = x + kw - 1;
+        v[kh * 3 + kw] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? im[(long long)yy * W + xx] : 0.f;
+      }
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int oc = c4 * 4 + c;
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(v[t], w[oc * 9 + t], a);
+      a += bias ? bias[oc] : 0.f;
+      split_f32(act == ACT_RELU ? fmaxf(a, 0.f) : a, hi[c], lo[c]);
+    }
+    const size_t o = plane_idx((size_t)pix, c4 * 4, Cout);
+    *reinterpret_cast<uint2*>(out + o) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+    *reinterpret_cast<uint2*>(out + o + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+  }
+}
+
+hipError_t launch_stem_split(const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
+                             int Cout, int act, hipStream_t s) {
+  if (Cout % 32) return hipErrorInvalidValue;
+  const long long total = (long long)B * H * W * (Cout / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(stem_split_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, out, B, H, W, Cout, act);
+  return hipGetLastError();
+}
+
 hipError_t launch_stem(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, int Cout,
                        int act, hipStream_t s) {
   if (Cout % 4) return hipErrorInvalidValue;
@@ -91,6 +137,53 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
       }
     *reinterpret_cast<float4*>(y + pix * C + c4 * 4) = m;
   }
+}
+
+__global__ __launch_bounds__(256) void maxpool_split_kernel(const uint16_t* __restrict__ xp, uint16_t* __restrict__ yp,
+                                                            int B, int H, int W, int C, int OH, int OW, int SH, int SW,
+                                                            int PH, int PW) {
+  const int cq = C >> 2;
+  const long long total = (long long)B * OH * OW * cq;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq);
+    const long long pix = idx / cq;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const long long b = pix / ((long long)OW * OH);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const size_t o = plane_idx((size_t)((b * H + ih) * W + iw), c4 * 4, C);
+          const uint2 h2 = *reinterpret_cast<const uint2*>(xp + o), l2 = *reinterpret_cast<const uint2*>(xp + o + 32);
+          const float v0 = __uint_as_float(h2.x << 16) + __uint_as_float(l2.x << 16);
+          const float v1 = __uint_as_float(h2.x & 0xFFFF0000u) + __uint_as_float(l2.x & 0xFFFF0000u);
+          const float v2 = __uint_as_float(h2.y << 16) + __uint_as_float(l2.y << 16);
+          const float v3 = __uint_as_float(h2.y & 0xFFFF0000u) + __uint_as_float(l2.y & 0xFFFF0000u);
+          m[0] = fmaxf(m[0], v0); m[1] = fmaxf(m[1], v1); m[2] = fmaxf(m[2], v2); m[3] = fmaxf(m[3], v3);
+        }
+      }
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) split_f32(m[c], hi[c], lo[c]);
+    const size_t o = plane_idx((size_t)pix, c4 * 4, C);
+    *reinterpret_cast<uint2*>(yp + o) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+    *reinterpret_cast<uint2*>(yp + o + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+  }
+}
+
+hipError_t launch_maxpool_split(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, int SH, int SW, int PH,
+                                int PW, hipStream_t s) {
+  if (C % 32) return hipErrorInvalidValue;
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+  const long long total = (long long)B * OH * OW * (C / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool_split_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, SH, SW, PH, PW);
+  return hipGetLastError();
 }
 
 hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,

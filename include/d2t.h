@@ -194,6 +194,11 @@ int d2t_op_conv2d(const float* x, const float* w, const float* bias, const float
 int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t B,
                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH,
                          int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
+/* Same again on the split-activation kernel: x, residual and y cross the kernel boundary as bf16 hi/lo
+ * planes (split / merged around the launch by this test entry point). */
+int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                               int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + bias + residual); any M (skinny path for M<=64). */
 int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,
                   int32_t K, int32_t N, int32_t act, d2t_stream stream);

@@ -174,6 +174,31 @@ def test_decode_attention_vs_torch(B, heads, hd, L, Lmax):
     assert float((y.cpu() - ref).abs().max()) <= 2e-6
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 32 == 0])
+def test_conv_bf16x3_split_planes_vs_torch(case):
+    """Split-activation variant: input / residual / output as bf16 hi+lo planes."""
+    lib = _lib.require_device()
+    B, Cin, H, W, Cout, k, stride, pad, act, use_res = case
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, *k, seed=2, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    bias = _rand(Cout, seed=3, scale=0.1)
+    OH = (H + 2 * pad[0] - k[0]) // stride[0] + 1
+    OW = (W + 2 * pad[1] - k[1]) // stride[1] + 1
+    res = _rand(B, Cout, OH, OW, seed=4) if use_res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+    bd = bias.to(DEV)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
+    rc = lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W, Cin,
+                                        Cout, k[0], k[1], stride[0], stride[1], pad[0], pad[1], act, _lib.stream_of(xd))
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = _ref_conv(x, w, bias, res, stride, pad, act)
+    err = float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= 4e-4, err
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 32 == 0 and c[4] >= 64])
 def test_conv_bf16x3_vs_torch(case):
     """Split-bf16 convolution (3 bf16 MFMAs per product): ~2^-17 relative product error, so the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run the dominant convolution (512->512 3x3 @16x129, B=64) a few times through the C-ABI op entry
-points, for rocprofv3 counter passes.  usage: prof_conv.py [bf16x3|fp32] [reps]"""
+points, for rocprofv3 counter passes.  usage: prof_conv.py [bf16x3|split|fp32] [reps]"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ x = torch.randn(B, H, W, C, generator=g).cuda()
 w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
 b = torch.randn(C, generator=g).cuda()
 y = torch.empty(B, H, W, C, device="cuda")
-fn = lib.d2t_op_conv2d_bf16x3 if mode == "bf16x3" else lib.d2t_op_conv2d
+fn = {"bf16x3": lib.d2t_op_conv2d_bf16x3, "split": lib.d2t_op_conv2d_bf16x3_split, "fp32": lib.d2t_op_conv2d}[mode]
 st = _lib.stream_of(x)
 for i in range(reps):
     t0 = time.perf_counter()
