@@ -132,7 +132,7 @@ struct d2t_ctx {
   void* zero_page = nullptr;  // 256 zero bytes: out-of-image taps of the split-bf16 convolution
   hipStream_t dstream = nullptr;
   hipEvent_t ev_in = nullptr;
-  struct GraphKey { int B, T; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
+  struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
   struct GraphEnt { GraphKey key; hipGraphExec_t exec; };
   std::vector<GraphEnt> graphs;  // small cache of captured decode steps (most recent last)
   // kernel timing log (d2t_profile_*)
@@ -1043,9 +1043,13 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   };
 
   const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
+  // With early exit the host polls between steps, so one captured graph = one step, replayed.  Without it
+  // (async, or is_test == 0) the whole max_seq_len+1 step loop is ONE graph: a single launch per batch keeps
+  // the host free to enqueue the next batch's encoder while this one decodes.
+  const int steps_per_graph = (!is_test) ? S : 1;
   hipGraphExec_t exec = nullptr;
   if (use_graph) {
-    d2t_ctx::GraphKey k{B, T, tokens, logits, c->ckv, c->dws, c->skv, c->dstate};
+    d2t_ctx::GraphKey k{B, T, steps_per_graph, tokens, logits, c->ckv, c->dws, c->skv, c->dstate};
     for (size_t i = 0; i < c->graphs.size(); ++i)
       if (memcmp(&k, &c->graphs[i].key, sizeof k) == 0) {
         exec = c->graphs[i].exec;
@@ -1055,7 +1059,8 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
     if (!exec) {
       hipGraph_t gr = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      hipError_t e = one_step(s);
+      hipError_t e = hipSuccess;
+      for (int t = 0; t < steps_per_graph && e == hipSuccess; ++t) e = one_step(s);
       hipError_t e2 = hipStreamEndCapture(s, &gr);
       if (e != hipSuccess || e2 != hipSuccess) {
         if (gr) hipGraphDestroy(gr);
@@ -1073,7 +1078,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
     }
   }
   int steps = S;
-  for (int t = 0; t < S; ++t) {
+  for (int t = 0; t < S; t += (use_graph ? steps_per_graph : 1)) {
     if (use_graph) HIPCHK(c, hipGraphLaunch(exec, s));
     else HIPCHK(c, one_step(s));
     if (!async && is_test && ((t & 7) == 7 || t == S - 1)) {
