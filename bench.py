@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
+    ap.add_argument("--reserve", type=int, default=64,
+                    help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each batch's decode before the next batch's encoder starts")
     ap.add_argument("--cpu-sample", type=int, default=4)
@@ -142,7 +144,8 @@ def main():
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.eval().to(dev)
     model.conv_precision = args.precision
-    model.pipelined = not args.no_pipeline  # decode of batch i overlaps the encoder of batch i+1
+    model.pipelined = not args.no_pipeline
+    model.reserved_blocks = args.reserve  # decode of batch i overlaps the encoder of batch i+1
     img = synth.synth_images(B, H, W, seed=1000 + rank).to(dev)  # each rank its own shard
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
 
@@ -227,7 +230,7 @@ def main():
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
                        "parallelism": f"dp{world} (batch-sharded, no collective)",
-                       "pipelined": bool(model.pipelined)},
+                       "pipelined": bool(model.pipelined), "reserved_blocks": model.reserved_blocks if model.pipelined else 0},
             "algorithmic_gflop_per_formula": round(algo / 1e9, 2),
             "e2e_tflops": round(algo * formulas / elapsed / 1e12, 2),
             "roofline": roofline,

@@ -110,6 +110,8 @@ class Model(nn.Module):
         # forward returns while the latency-bound decode loop still runs on the engine's stream, so the
         # next batch's encoder overlaps it.  Results are valid after synchronize().
         self.pipelined = False
+        # pipelined mode: block slots the persistent convolution leaves free for the decode stream
+        self.reserved_blocks = 64
         # 'fp32' = exact fp32 matrix-core convolutions (default); 'bf16x3' = split-bf16 convolutions
         # (3 bf16 MFMAs per product, fp32 accumulate; logits stay within 1e-3)
         self.conv_precision = "fp32"
@@ -125,6 +127,10 @@ class Model(nn.Module):
         if self._engine is None:
             self._engine = Engine(self.opt)
         self._engine.sync_weights(self)
+        want = self.reserved_blocks if self.pipelined else 0
+        if getattr(self._engine, "_reserved", None) != want:
+            self._engine.set_reserved_blocks(want)
+            self._engine._reserved = want
         if getattr(self._engine, "_precision", None) != self.conv_precision:
             self._engine.set_conv_precision(self.conv_precision)
             self._engine._precision = self.conv_precision

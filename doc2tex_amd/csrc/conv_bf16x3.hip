@@ -276,11 +276,19 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
 
   const int nt = (p.Cout + BN - 1) / BN;
-  const int logical = xcd_logical_tile();
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
+  const int ntiles = nt * ((p.M + BM - 1) / BM);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane >> 2, pos = lane & 3;
+  // Persistent over tiles: the grid may be smaller than the tile count (p.max_blocks), which leaves
+  // block slots free for the latency-bound decode kernels of the previous batch (pipelined mode).
+  // Tile order: in every round the blocks that share an XCD (blockIdx % 8) take consecutive tiles.
+  const int G = gridDim.x, gx = G >> 3;
+  for (int tile0 = 0; tile0 < ntiles; tile0 += G) {
+  int logical = tile0 + blockIdx.x;
+  if ((G & 7) == 0) logical = tile0 + (blockIdx.x & 7) * gx + (blockIdx.x >> 3);
+  if (logical >= ntiles) break;  // block-uniform
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
 
   int a_off[AJ];
   unsigned a_mask[AJ];
@@ -398,6 +406,7 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
     __syncthreads();                                   // ... and everyone else's; reads of `cur` are done
   }
   conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+  }  // tile loop
 }
 
 // non-template entry points (the host-side stub of a __global__ template using the LDS-DMA builtin is not emitted)
@@ -420,13 +429,15 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes
     if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;
+    int tiles = mt * ((p.Cout + (p.Cout <= 64 ? 63 : 127)) / (p.Cout <= 64 ? 64 : 128));
+    const int grid = (p.max_blocks > 0 && tiles > p.max_blocks) ? p.max_blocks : tiles;
     if (p.Cout <= 64) {
-      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
+      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid), dim3(256), 0, s, p);
     } else {
       // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
       static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
-      if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(mt * ((p.Cout + 127) / 128)), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(mt * ((p.Cout + 127) / 128)), dim3(512), 0, s, p);
+      if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(grid), dim3(512), 0, s, p);
     }
     return hipGetLastError();
   }

@@ -90,6 +90,8 @@ struct d2t_ctx {
   std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
   bool finalized = false;
   bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
+  int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
+  int num_cus = 0;
 
   // packed weights
   std::string bb;  // backbone key prefix ("...ConvNet.")
@@ -277,7 +279,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   if (extra) p = *extra;
   p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
-  if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; } else { p.in = x.p; }
+  if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
   if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
   if (res) {
     if (res->split) { p.res_hi = res->planes(); } else { p.res = res->p; }
@@ -442,7 +444,12 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
     return fail(c, D2T_EINVAL, "unknown decoder %d", cfg->decoder);
   }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
-  HIPCHK(c, hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking));
+  {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
+     // workgroups are placed first whenever the encoder of the next batch is filling the chip
+    int lo = 0, hi = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->dstream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
+  }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault));
@@ -878,7 +885,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     ConvP p{};
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
-    if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; } else { p.in = f.p; }
+    if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -1289,6 +1296,21 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   *len_out = n;
   *score_out = bh.score;
   return done(D2T_OK);
+}
+
+int d2t_set_reserved_blocks(d2t_ctx* c, int32_t blocks) {
+  if (!c || blocks < 0) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->num_cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIPCHK(c, hipGetDevice(&dev));
+    HIPCHK(c, hipGetDeviceProperties(&prop, dev));
+    c->num_cus = prop.multiProcessorCount;
+  }
+  const int slots = 2 * c->num_cus;  // the convolution runs two blocks per CU
+  if (blocks >= slots) return fail(c, D2T_EINVAL, "cannot reserve %d of %d block slots", blocks, slots);
+  c->conv_max_blocks = blocks ? slots - blocks : 0;
+  return D2T_OK;
 }
 
 int d2t_set_conv_precision(d2t_ctx* c, int32_t mode) {

@@ -26,6 +26,7 @@ struct ConvP {
   uint16_t* out_hi;
   const uint16_t* res_hi;
   const void* zero16;
+  int max_blocks;        // > 0: launch at most this many (persistent) blocks of the split-bf16 kernel
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation

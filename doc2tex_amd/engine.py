@@ -157,6 +157,9 @@ class Engine:
         code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3}[mode]
         self._check(self.lib.d2t_set_conv_precision(self.ctx, code), "set_conv_precision")
 
+    def set_reserved_blocks(self, blocks):
+        self._check(self.lib.d2t_set_reserved_blocks(self.ctx, int(blocks)), "set_reserved_blocks")
+
     # ---- kernel timing -------------------------------------------------------
     def profile(self, on):
         self._check(self.lib.d2t_profile_enable(self.ctx, int(bool(on))), "profile_enable")

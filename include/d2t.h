@@ -172,6 +172,12 @@ int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t be
 enum { D2T_CONV_FP32 = 0, D2T_CONV_BF16X3 = 1 };
 int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
 
+/* Pipelined serving: the split-bf16 convolution is a persistent kernel; capping its grid at
+ * (2 x CUs - blocks) leaves `blocks` block slots free at all times, into which the latency-bound decode
+ * kernels of the previous batch (running on the engine's high-priority stream) are placed without waiting
+ * for a convolution block to retire.  0 (default) = use every slot. */
+int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
+
 /* ---- in-engine kernel timing (bench.py roofline leg) ------------------------
  * While enabled, d2t_encode brackets every implicit-GEMM (MFMA) launch with a
  * pair of HIP events on the launch stream.  d2t_profile_read synchronises,
