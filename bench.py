@@ -114,6 +114,8 @@ def main():
                     help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--reserve", type=int, default=64,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
+    ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
+                    help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each batch's decode before the next batch's encoder starts")
     ap.add_argument("--cpu-sample", type=int, default=4)
@@ -145,6 +147,7 @@ def main():
     model.eval().to(dev)
     model.conv_precision = args.precision
     model.pipelined = not args.no_pipeline
+    model.decode_chains = args.chains
     model.reserved_blocks = args.reserve  # decode of batch i overlaps the encoder of batch i+1
     img = synth.synth_images(B, H, W, seed=1000 + rank).to(dev)  # each rank its own shard
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
@@ -230,7 +233,8 @@ def main():
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
                        "parallelism": f"dp{world} (batch-sharded, no collective)",
-                       "pipelined": bool(model.pipelined), "reserved_blocks": model.reserved_blocks if model.pipelined else 0},
+                       "pipelined": bool(model.pipelined), "reserved_blocks": model.reserved_blocks if model.pipelined else 0,
+                       "decode_chains": model.decode_chains if model.pipelined else 1},
             "algorithmic_gflop_per_formula": round(algo / 1e9, 2),
             "e2e_tflops": round(algo * formulas / elapsed / 1e12, 2),
             "roofline": roofline,

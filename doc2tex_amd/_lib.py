@@ -45,6 +45,7 @@ SIGNATURES = {
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_set_conv_precision": (_I, [_P, _I]),
     "d2t_set_reserved_blocks": (_I, [_P, _I]),
+    "d2t_set_decode_chains": (_I, [_P, _I]),
     "d2t_profile_enable": (_I, [_P, _I]),
     "d2t_profile_read": (_I, [_P, _I, C.POINTER(_I)] + [C.POINTER(_I)] * 3 + [C.POINTER(C.c_float)]),
     "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),

@@ -112,6 +112,8 @@ class Model(nn.Module):
         self.pipelined = False
         # pipelined mode: block slots the persistent convolution leaves free for the decode stream
         self.reserved_blocks = 64
+        # pipelined mode: decode loops in flight side by side (1 or 2)
+        self.decode_chains = 1
         # 'fp32' = exact fp32 matrix-core convolutions (default); 'bf16x3' = split-bf16 convolutions
         # (3 bf16 MFMAs per product, fp32 accumulate; logits stay within 1e-3)
         self.conv_precision = "fp32"
@@ -131,6 +133,9 @@ class Model(nn.Module):
         if getattr(self._engine, "_reserved", None) != want:
             self._engine.set_reserved_blocks(want)
             self._engine._reserved = want
+        if getattr(self._engine, "_chains", None) != self.decode_chains:
+            self._engine.set_decode_chains(self.decode_chains)
+            self._engine._chains = self.decode_chains
         if getattr(self._engine, "_precision", None) != self.conv_precision:
             self._engine.set_conv_precision(self.conv_precision)
             self._engine._precision = self.conv_precision

@@ -133,6 +133,12 @@ struct d2t_ctx {
   int* h_pinned = nullptr;
   void* zero_page = nullptr;  // 256 zero bytes: out-of-image taps of the split-bf16 convolution
   hipStream_t dstream = nullptr;
+  // Second decode chain (own stream, self-attention cache, workspace, state): with two chains the decode
+  // loops of consecutive async batches run side by side.  The members above are the ACTIVE chain; the
+  // inactive one is parked here (select_chain swaps them).
+  struct Chain { hipStream_t stream = nullptr; float* skv = nullptr; size_t skv_cap = 0; float* dws = nullptr;
+                 size_t dws_cap = 0; int* dstate = nullptr; size_t dstate_cap = 0; } parked;
+  int active_chain = 0, n_chains = 1;
   hipEvent_t ev_in = nullptr;
   struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
   struct GraphEnt { GraphKey key; hipGraphExec_t exec; };
@@ -449,6 +455,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->dstream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->parked.stream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
   }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
@@ -480,6 +487,10 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->zero_page) hipFree(c->zero_page);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->dstream) hipStreamDestroy(c->dstream);
+  if (c->parked.skv) hipFree(c->parked.skv);
+  if (c->parked.dws) hipFree(c->parked.dws);
+  if (c->parked.dstate) hipFree(c->parked.dstate);
+  if (c->parked.stream) hipStreamDestroy(c->parked.stream);
   delete c;
 }
 
@@ -922,6 +933,17 @@ struct DecBufs {
   float *qkv, *q2, *a, *f;
 };
 
+// make chain i the active one (c->dstream / skv / dws / dstate)
+void select_chain(d2t_ctx* c, int i) {
+  if (c->active_chain == i) return;
+  d2t_ctx::Chain cur{c->dstream, c->skv, c->skv_cap, c->dws, c->dws_cap, c->dstate, c->dstate_cap};
+  const d2t_ctx::Chain& o = c->parked;
+  c->dstream = o.stream; c->skv = o.skv; c->skv_cap = o.skv_cap; c->dws = o.dws; c->dws_cap = o.dws_cap;
+  c->dstate = o.dstate; c->dstate_cap = o.dstate_cap;
+  c->parked = cur;
+  c->active_chain = i;
+}
+
 int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, Lmax = g.max_seq_len + 2;
@@ -1019,12 +1041,14 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
                 int64_t* tokens, float* logits, int* steps_out, hipStream_t user, bool async) {
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab;
+  const int slot = (int)(c->decode_seq++ & 1u);
+  // async decodes alternate between the two chains (chain == K/V slot); everything else runs on chain 0
+  select_chain(c, (async && c->n_chains > 1) ? slot : 0);
   hipStream_t s = c->dstream;
   DecBufs bf;
   int rc = dec_prepare(c, B, T, &bf);
   if (rc) return rc;
   c->skv_cur = c->skv;
-  const int slot = (int)(c->decode_seq++ & 1u);
   c->ckv = c->ckv2[slot];
   // the decode that last read this K/V slot must be finished before it is overwritten
   if (c->ev_done_valid[slot]) HIPCHK(c, hipStreamWaitEvent(user, c->ev_done[slot], 0));
@@ -1076,8 +1100,9 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
       e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
       hipGraphDestroy(gr);
       if (e != hipSuccess) return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      if (c->graphs.size() >= 8) {  // evict the least recently used; it may still be queued on the stream
-        HIPCHK(c, hipStreamSynchronize(s));
+      if (c->graphs.size() >= 8) {  // evict the least recently used; it may still be queued on a decode stream
+        HIPCHK(c, hipStreamSynchronize(c->dstream));
+        HIPCHK(c, hipStreamSynchronize(c->parked.stream));
         hipGraphExecDestroy(c->graphs.front().exec);
         c->graphs.erase(c->graphs.begin());
       }
@@ -1171,7 +1196,10 @@ int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
   if (!c) return D2T_EINVAL;
   for (int i = 0; i < 2; ++i)
     if (c->ev_done_valid[i]) HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_done[i], 0));
-  if (host_sync) HIPCHK(c, hipStreamSynchronize(c->dstream));
+  if (host_sync) {
+    HIPCHK(c, hipStreamSynchronize(c->dstream));
+    HIPCHK(c, hipStreamSynchronize(c->parked.stream));
+  }
   return D2T_OK;
 }
 
@@ -1190,6 +1218,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = beam_size;
   const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   if ((long long)cap * V > 16 * 4096) return fail(c, D2T_EINVAL, "beam_size * vocab too large");
+  select_chain(c, 0);
   hipStream_t user = (hipStream_t)stream, s = c->dstream;
   DecBufs bf;
   int rc = dec_prepare(c, cap, T, &bf);
@@ -1310,6 +1339,12 @@ int d2t_set_reserved_blocks(d2t_ctx* c, int32_t blocks) {
   const int slots = 2 * c->num_cus;  // the convolution runs two blocks per CU
   if (blocks >= slots) return fail(c, D2T_EINVAL, "cannot reserve %d of %d block slots", blocks, slots);
   c->conv_max_blocks = blocks ? slots - blocks : 0;
+  return D2T_OK;
+}
+
+int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
+  if (!c || chains < 1 || chains > 2) return fail(c, D2T_EINVAL, "decode chains must be 1 or 2");
+  c->n_chains = chains;
   return D2T_OK;
 }
 

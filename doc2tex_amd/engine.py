@@ -160,6 +160,9 @@ class Engine:
     def set_reserved_blocks(self, blocks):
         self._check(self.lib.d2t_set_reserved_blocks(self.ctx, int(blocks)), "set_reserved_blocks")
 
+    def set_decode_chains(self, chains):
+        self._check(self.lib.d2t_set_decode_chains(self.ctx, int(chains)), "set_decode_chains")
+
     # ---- kernel timing -------------------------------------------------------
     def profile(self, on):
         self._check(self.lib.d2t_profile_enable(self.ctx, int(bool(on))), "profile_enable")
@@ -200,7 +203,7 @@ class Engine:
                                                     _lib.stream_of(memory)), "decode_attn_greedy")
         return tokens, probs
 
-    def decode_greedy_async(self, memory, start_tokens, ring=3):
+    def decode_greedy_async(self, memory, start_tokens, ring=4):
         """Pipelined greedy decode (always max_seq_len+1 steps): returns views of engine-held
         ring buffers that become valid after decode_wait(); at most `ring` - 1 later calls may be
         issued before the result is consumed."""

@@ -178,6 +178,11 @@ int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
  * for a convolution block to retire.  0 (default) = use every slot. */
 int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
 
+/* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
+ * its own stream, self-attention cache and workspace, so with 2 the step loops of two consecutive batches
+ * run side by side (the loop is a dependent chain of small kernels that cannot fill the chip alone). */
+int d2t_set_decode_chains(d2t_ctx* ctx, int32_t chains);
+
 /* ---- in-engine kernel timing (bench.py roofline leg) ------------------------
  * While enabled, d2t_encode brackets every implicit-GEMM (MFMA) launch with a
  * pair of HIP events on the launch stream.  d2t_profile_read synchronises,

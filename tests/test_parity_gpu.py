@@ -148,17 +148,20 @@ def test_beam_rejects_batches():
         m(img, torch.ones(2, 1, dtype=torch.long, device="cuda"), is_train=False, is_test=True)
 
 
-def test_pipelined_decode_equals_synchronous(cases):
-    """Opt-in cross-batch pipelining (decode of batch i overlaps the encoder of batch i+1)
-    returns exactly what the synchronous path returns."""
+@pytest.mark.parametrize("chains,precision", [(1, "fp32"), (2, "fp32"), (2, "bf16x3")])
+def test_pipelined_decode_equals_synchronous(cases, chains, precision):
+    """Opt-in cross-batch pipelining (decode of batch i overlaps the encoder of batch i+1; with two decode
+    chains also the decode of batch i-1) returns exactly what the synchronous path returns."""
     c = _case(cases, "greedy", "t2_greedy")
     cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
-    imgs = [synth.synth_images(3, c["H"], c["W"], seed=900 + i).cuda() for i in range(5)]
+    m.conv_precision = precision
+    imgs = [synth.synth_images(3, c["H"], c["W"], seed=900 + i).cuda() for i in range(7)]
     text = torch.full((3, 1), R.GO, dtype=torch.long, device="cuda")
     with torch.no_grad():
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
         m.pipelined = True
+        m.decode_chains = chains
         got = []
         for x in imgs:
             p, l, _ = m(x, text, is_train=False)
@@ -167,10 +170,14 @@ def test_pipelined_decode_equals_synchronous(cases):
                 m.synchronize(host_sync=False)
         m.synchronize()
         torch.cuda.synchronize()
-    # ring depth 3: only the last three results are still resident
-    for (p, l), (rp, rl) in list(zip(got, ref))[-3:]:
+    # ring depth 4: only the last four results are still resident
+    for (p, l), (rp, rl) in list(zip(got, ref))[-4:]:
         assert torch.equal(p, rp) and torch.equal(l, rl)
     m.pipelined = False
+    # a synchronous call right after pipelined ones still matches
+    with torch.no_grad():
+        p, l, _ = m(imgs[0], text, is_train=False)
+    assert torch.equal(p, ref[0][0]) and torch.equal(l, ref[0][1])
 
 
 @pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop", "c2_greedy", "c1_greedy", "s0_greedy"])
