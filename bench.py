@@ -105,8 +105,8 @@ def cpu_baseline(cfg_name, H, W, max_len, sample_b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +118,7 @@ def main():
                     help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each batch's decode before the next batch's encoder starts")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=24, help="crops in the CPU-baseline sample (~10-30 s of CPU work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -418,6 +418,12 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x3g_128x128_w8(const ConvP p)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
   conv_bf16x3g_body<128, 128, 4>(p, smem);
 }
+// same code under its own symbol for the dominant GEMM shape (512 -> 512 channels, 3x3: K = 4608), so that
+// rocprofv3's per-kernel rows separate it from the other layers
+__global__ __launch_bounds__(512, 4) void conv_bf16x3g_128x128_w8_k4608(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
+  conv_bf16x3g_body<128, 128, 4>(p, smem);
+}
 __global__ __launch_bounds__(256, 2) void conv_bf16x3g_128x64(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 64 * XROW)];
   conv_bf16x3g_body<128, 64, 2>(p, smem);
@@ -437,6 +443,7 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
       // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
       static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
       if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(grid), dim3(256), 0, s, p);
+      else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3g_128x128_w8_k4608, dim3(grid), dim3(512), 0, s, p);
       else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(grid), dim3(512), 0, s, p);
     }
     return hipGetLastError();

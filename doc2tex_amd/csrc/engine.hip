@@ -137,7 +137,11 @@ struct d2t_ctx {
   // loops of consecutive async batches run side by side.  The members above are the ACTIVE chain; the
   // inactive one is parked here (select_chain swaps them).
   struct Chain { hipStream_t stream = nullptr; float* skv = nullptr; size_t skv_cap = 0; float* dws = nullptr;
-                 size_t dws_cap = 0; int* dstate = nullptr; size_t dstate_cap = 0; } parked;
+                 size_t dws_cap = 0; int* dstate = nullptr; size_t dstate_cap = 0;
+                 float* out = nullptr; size_t out_cap = 0; } parked;
+  // async decodes write tokens / logits here (fixed addresses, so one captured graph per chain serves every
+  // caller buffer) and copy them out afterwards
+  float* dout = nullptr; size_t dout_cap = 0;
   int active_chain = 0, n_chains = 1;
   hipEvent_t ev_in = nullptr;
   struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
@@ -490,6 +494,8 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->parked.skv) hipFree(c->parked.skv);
   if (c->parked.dws) hipFree(c->parked.dws);
   if (c->parked.dstate) hipFree(c->parked.dstate);
+  if (c->parked.out) hipFree(c->parked.out);
+  if (c->dout) hipFree(c->dout);
   if (c->parked.stream) hipStreamDestroy(c->parked.stream);
   delete c;
 }
@@ -936,10 +942,10 @@ struct DecBufs {
 // make chain i the active one (c->dstream / skv / dws / dstate)
 void select_chain(d2t_ctx* c, int i) {
   if (c->active_chain == i) return;
-  d2t_ctx::Chain cur{c->dstream, c->skv, c->skv_cap, c->dws, c->dws_cap, c->dstate, c->dstate_cap};
+  d2t_ctx::Chain cur{c->dstream, c->skv, c->skv_cap, c->dws, c->dws_cap, c->dstate, c->dstate_cap, c->dout, c->dout_cap};
   const d2t_ctx::Chain& o = c->parked;
   c->dstream = o.stream; c->skv = o.skv; c->skv_cap = o.skv_cap; c->dws = o.dws; c->dws_cap = o.dws_cap;
-  c->dstate = o.dstate; c->dstate_cap = o.dstate_cap;
+  c->dstate = o.dstate; c->dstate_cap = o.dstate_cap; c->dout = o.out; c->dout_cap = o.out_cap;
   c->parked = cur;
   c->active_chain = i;
 }
@@ -1050,6 +1056,15 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   if (rc) return rc;
   c->skv_cur = c->skv;
   c->ckv = c->ckv2[slot];
+  const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
+  int64_t* const user_tokens = tokens;
+  float* const user_logits = logits;
+  const size_t tok_bytes = (size_t)B * S * sizeof(int64_t), log_bytes = (size_t)B * S * V * sizeof(float);
+  if (async && use_graph) {  // engine-owned staging: [logits | tokens]
+    if ((rc = ensure(c, &c->dout, &c->dout_cap, log_bytes + tok_bytes))) return rc;
+    logits = c->dout;
+    tokens = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(c->dout) + log_bytes);
+  }
   // the decode that last read this K/V slot must be finished before it is overwritten
   if (c->ev_done_valid[slot]) HIPCHK(c, hipStreamWaitEvent(user, c->ev_done[slot], 0));
   HIPCHK(c, cross_kv(c, user, memory, B, T));
@@ -1073,7 +1088,6 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
     return launch_argmax_embed(am, st);
   };
 
-  const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
   // With early exit the host polls between steps, so one captured graph = one step, replayed.  Without it
   // (async, or is_test == 0) the whole max_seq_len+1 step loop is ONE graph: a single launch per batch keeps
   // the host free to enqueue the next batch's encoder while this one decodes.
@@ -1118,6 +1132,10 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
       HIPCHK(c, hipStreamSynchronize(s));
       if (c->h_pinned[0] > 0) { steps = c->h_pinned[0]; break; }
     }
+  }
+  if (tokens != user_tokens) {
+    HIPCHK(c, hipMemcpyAsync(user_logits, logits, log_bytes, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(user_tokens, tokens, tok_bytes, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(c, hipEventRecord(c->ev_done[slot], s));
   c->ev_done_valid[slot] = true;
