@@ -202,7 +202,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
-            "kernel": ("conv_bf16x3_kernel<128,128>" if bf else "conv_mfma_kernel<128,128>") +
+            "kernel": ("conv_bf16x3g_128x128_w8_k4608" if bf else "conv_mfma_kernel<128,128>") +
                       " (512->512 3x3 conv @16x129 as implicit GEMM)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
