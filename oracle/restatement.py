@@ -36,10 +36,17 @@ RESNET_LAYERS = (1, 2, 5, 3)  # feature_extractor/resnet.py:262
 # ---------------------------------------------------------------------------
 # ResNet backbone  (modules/component/feature_extractor/resnet.py)
 # ---------------------------------------------------------------------------
-def _bn(x, sd, p, eps=1e-5):
-    # nn.BatchNorm2d in eval mode: running statistics
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+def _bn(x, sd, p, eps=1e-5, bn_train=None):
+    # nn.BatchNorm2d.  Eval mode: running statistics.  Train mode (bn_train is a dict): batch statistics
+    # (biased variance) and the running-statistics update with momentum 0.1 / unbiased variance, whose new
+    # values are left in bn_train[<buffer key>] (module.train() semantics, engine/training.py:94-164).
+    if bn_train is None:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                            sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
+    rm, rv = sd[p + ".running_mean"].detach().clone(), sd[p + ".running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, eps)
+    bn_train[p + ".running_mean"], bn_train[p + ".running_var"] = rm, rv
+    return y
 
 
 def fold_bn(w, sd, p, eps=1e-5):
@@ -48,42 +55,42 @@ def fold_bn(w, sd, p, eps=1e-5):
     return w * s.view(-1, 1, 1, 1), sd[p + ".bias"] - sd[p + ".running_mean"] * s
 
 
-def _conv_bn(x, sd, conv, bn, stride=1, padding=0, faithful=True):
+def _conv_bn(x, sd, conv, bn, stride=1, padding=0, faithful=True, bn_train=None):
     w = sd[conv + ".weight"]
-    if faithful:
-        return _bn(F.conv2d(x, w, None, stride, padding), sd, bn)
+    if faithful or bn_train is not None:
+        return _bn(F.conv2d(x, w, None, stride, padding), sd, bn, bn_train=bn_train)
     wf, bf = fold_bn(w, sd, bn)
     return F.conv2d(x, wf, bf, stride, padding)
 
 
-def _basic_block(x, sd, p, faithful):
+def _basic_block(x, sd, p, faithful, bn_train=None):
     # BasicBlock.forward, resnet.py:32-48 (ReLU after the residual add, :45-46)
-    out = F.relu(_conv_bn(x, sd, p + ".conv1", p + ".bn1", 1, 1, faithful))
-    out = _conv_bn(out, sd, p + ".conv2", p + ".bn2", 1, 1, faithful)
+    out = F.relu(_conv_bn(x, sd, p + ".conv1", p + ".bn1", 1, 1, faithful, bn_train))
+    out = _conv_bn(out, sd, p + ".conv2", p + ".bn2", 1, 1, faithful, bn_train)
     if (p + ".downsample.0.weight") in sd:  # 1x1 conv + BN, resnet.py:181-192
-        x = _conv_bn(x, sd, p + ".downsample.0", p + ".downsample.1", 1, 0, faithful)
+        x = _conv_bn(x, sd, p + ".downsample.0", p + ".downsample.1", 1, 0, faithful, bn_train)
     return F.relu(out + x)
 
 
-def resnet(x, sd, p, faithful=True):
+def resnet(x, sd, p, faithful=True, bn_train=None):
     """ResNet.forward, resnet.py:205-245.  x [B,1,H,W] -> [B,512,H',W'] (NCHW)."""
-    cb = lambda x, c, b, s=1, pd=1: F.relu(_conv_bn(x, sd, p + c, p + b, s, pd, faithful))
+    cb = lambda x, c, b, s=1, pd=1: F.relu(_conv_bn(x, sd, p + c, p + b, s, pd, faithful, bn_train))
     x = cb(x, "conv0_1", "bn0_1")
     x = cb(x, "conv0_2", "bn0_2")
     x = F.max_pool2d(x, 2, 2, 0)  # :94
     for i in range(RESNET_LAYERS[0]):
-        x = _basic_block(x, sd, f"{p}layer1.{i}", faithful)
+        x = _basic_block(x, sd, f"{p}layer1.{i}", faithful, bn_train)
     x = cb(x, "conv1", "bn1")
     x = F.max_pool2d(x, 2, 2, 0)  # :106
     for i in range(RESNET_LAYERS[1]):
-        x = _basic_block(x, sd, f"{p}layer2.{i}", faithful)
+        x = _basic_block(x, sd, f"{p}layer2.{i}", faithful, bn_train)
     x = cb(x, "conv2", "bn2")
     x = F.max_pool2d(x, 2, (2, 1), (0, 1))  # :120, implicit -inf padding
     for i in range(RESNET_LAYERS[2]):
-        x = _basic_block(x, sd, f"{p}layer3.{i}", faithful)
+        x = _basic_block(x, sd, f"{p}layer3.{i}", faithful, bn_train)
     x = cb(x, "conv3", "bn3")
     for i in range(RESNET_LAYERS[3]):
-        x = _basic_block(x, sd, f"{p}layer4.{i}", faithful)
+        x = _basic_block(x, sd, f"{p}layer4.{i}", faithful, bn_train)
     x = cb(x, "conv4_1", "bn4_1", (2, 1), (0, 1))  # :139-147
     x = cb(x, "conv4_2", "bn4_2", 1, 0)  # :149-157
     return x
@@ -157,9 +164,9 @@ def posenc2d_crop(d_model, h, w):
 # ---------------------------------------------------------------------------
 # HybridViT encoder
 # ---------------------------------------------------------------------------
-def hybrid_embed(x, sd, p, patch=(2, 2), faithful=True):
+def hybrid_embed(x, sd, p, patch=(2, 2), faithful=True, bn_train=None):
     """HybridEmbed.forward, seq_modeling/addon_module/patchembed.py:115-141."""
-    x = resnet(x, sd, p + "backbone.ConvNet.", faithful)
+    x = resnet(x, sd, p + "backbone.ConvNet.", faithful, bn_train)
     fh, fw = x.shape[2:]
     pad_h = (-fh) % patch[0]
     pad_w = (-fw) % patch[1]
@@ -184,9 +191,9 @@ def _vit_block(x, sd, p, heads):
     return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
 
 
-def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None):
+def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None, bn_train=None):
     """ViTEncoderV3.forward, seq_modeling/vit_encoder.py:249-268."""
-    x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful)
+    x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful, bn_train)
     if taps is not None:
         taps["patch"] = x
     B, n, C = x.shape
@@ -474,13 +481,13 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
 # ---------------------------------------------------------------------------
 # Model.forward  (modules/build_model.py:36-79)
 # ---------------------------------------------------------------------------
-def forward_encoder(cfg, sd, image, faithful=True, taps=None):
+def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None):
     """Model.forward_encoder: returns (contextual_feature [B,T,d], output_shape, feat_pad)."""
     seq = cfg["SequenceModeling"]
     if seq["name"] == "ViT":
         sp = seq["params"]
         x, pad_info, size = vit_encoder_v3(image, sd, "seqmodeler.SequenceModeling.", sp["depth"],
-                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps)
+                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps, bn_train)
         shape = (size["height"] // sp["patch_size"][0], size["width"] // sp["patch_size"][1])
         return x, shape, pad_info
     if seq["name"] == "BiLSTM":
@@ -495,7 +502,7 @@ def forward_encoder(cfg, sd, image, faithful=True, taps=None):
         return x, None, None
     # Feat=ResNet, Seq=None, Pred=TFM: PositionalEncoding2D add then B,C,H,W -> B,HW,C
     # (recognizers/build_seq.py:69-76)
-    f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful)
+    f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful, bn_train)
     if taps is not None:
         taps["backbone"] = f
     f = f + posenc2d_crop(f.shape[1], f.shape[2], f.shape[3])
@@ -531,3 +538,36 @@ def ce_loss(logits, target):
     CrossEntropyLoss(ignore_index=PAD, reduction='none') then .mean() over ALL B*L."""
     V = logits.shape[-1]
     return F.cross_entropy(logits.reshape(-1, V), target.reshape(-1), ignore_index=PAD, reduction="none").mean()
+
+
+# ---------------------------------------------------------------------------
+# Training step (engine/training.py:76-164): module.train() forward + CE + backward
+# ---------------------------------------------------------------------------
+def is_trainable(key):
+    """state_dict keys that are nn.Parameters with requires_grad=True in the reference: everything except
+    BatchNorm buffers, the sinusoid tables and the frozen sincos pos_embed (vit_encoder.py:235-237)."""
+    tail = key.rsplit(".", 1)[-1]
+    return tail not in ("running_mean", "running_var", "num_batches_tracked", "pe", "pos_embed")
+
+
+def train_forward(cfg, sd, image, text_in, bn_train):
+    """Model.forward under module.train() for the TFM head: BatchNorm on batch statistics (their running
+    updates are left in `bn_train`), teacher-forced decoder pass with causal + PAD key-padding masks
+    (tfm.py:103-118).  Dropout is 0 in every parity config.  Returns logits [B,L,V]."""
+    pp = cfg["Prediction"]["params"]
+    mem, _, _ = forward_encoder(cfg, sd, image, faithful=True, bn_train=bn_train)
+    return tfm_full_pass(text_in, mem, sd, "predicter.Prediction.", pp["num_decoder_layers"], pp["nhead"],
+                         key_padding=True)
+
+
+def train_step_grads(cfg, sd, image, text):
+    """forward_step + loss.backward() (engine/training.py:83-88,126,137): text [B,L+1] with [GO] first;
+    the model sees text[:, :-1], the target is text[:, 1:].  Returns (loss, logits, {key: grad}, bn_train)."""
+    params = {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and is_trainable(k)) else v)
+              for k, v in sd.items()}
+    bn_train = {}
+    logits = train_forward(cfg, params, image, text[:, :-1], bn_train)
+    loss = ce_loss(logits, text[:, 1:])
+    names = [k for k, v in params.items() if v.is_floating_point() and v.requires_grad]
+    grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    return loss.detach(), logits.detach(), {k: g for k, g in zip(names, grads)}, bn_train

@@ -91,3 +91,43 @@ def test_tables_match_reference_checksums(cases):
     assert abs(float(R.word_pos_table(256).double().sum()) - c["pe_sum"]) < 1e-6
     c1 = _case(cases, "greedy", "c1_greedy")
     assert abs(float(R.posenc2d_crop(512, 9, 80).double().sum()) - c1["pe2d_crop_sum"]) < 1e-6
+
+
+def _grad_sample_index(key, numel, n=48):
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+    return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def train_step_labels(c):
+    """The label tensor tools/make_golden.py fed to the reference for a train_step case."""
+    L = c["max_seq_len"]
+    text = synth.synth_labels(c["B"], max_len=L, seed=c["iseed"])
+    text[0, L // 2:] = 0
+    text[0, L // 2 - 1] = R.END
+    return text
+
+
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step"])
+def test_train_step_matches_reference_fixture(cases, manifests, name):
+    """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
+    reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""
+    c = _case(cases, "train_step", name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    assert np.array_equal(text.numpy(), z["text"])
+    loss, logits, grads, bn = R.train_step_grads(cfg, sd, img, text)
+    assert abs(float(loss) - c["loss"]) <= 1e-5 * max(1.0, abs(c["loss"]))
+    assert np.abs(logits.numpy() - z["logits"]).max() <= 2e-4
+    assert sorted(grads) == sorted(c["grad_norms"])
+    assert not any(k in grads for k in c["frozen"])
+    for k, g in grads.items():
+        norm, total = c["grad_norms"][k]
+        assert abs(float(g.double().norm()) - norm) <= 1e-4 * max(norm, 1e-6) + 1e-9, k
+        idx = _grad_sample_index(k, g.numel())
+        ref = z["g:" + k]
+        assert np.abs(g.reshape(-1)[idx].numpy() - ref).max() <= 5e-4 * max(float(np.abs(ref).max()), norm / g.numel() ** 0.5, 1e-7), k
+    for k, v in bn.items():
+        assert np.abs(v.numpy() - z["bn:" + k]).max() <= 1e-5 * max(1.0, float(np.abs(z["bn:" + k]).max())), k

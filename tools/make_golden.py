@@ -61,6 +61,9 @@ BEAM_CASES = [
     ("t2_beam3_nofinish", "T2", 48, 64, 6, 1234, 1012, 0.0, 3),
 ]
 TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
+# full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
+TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031)]
+GRAD_SAMPLES = 48
 
 
 def build_ref(cfg_name, max_seq_len, beam_size=None, wseed=1234, end_bias=0.0):
@@ -230,11 +233,73 @@ def run_train(case):
     return rep
 
 
+def grad_sample_index(key, numel):
+    """Fixed pseudo-random positions of a tensor whose values are stored in the fixture."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
+    return torch.randint(0, numel, (min(GRAD_SAMPLES, numel),), generator=g)
+
+
+def run_train_step(case):
+    """forward_step + loss.backward() of the REFERENCE in module.train() mode (engine/training.py:76-91,126,137);
+    checks the oracle's train_step_grads against it and stores loss, logits / gradient samples, gradient norms and
+    the BatchNorm running statistics after the step."""
+    name, cname, B, H, W, L, wseed, iseed = case
+    cfg, m, sd = build_ref(cname, L, wseed=wseed)
+    m.train()
+    img = synth.synth_images(B, H, W, seed=iseed)
+    text = synth.synth_labels(B, max_len=L, seed=iseed)
+    text[0, L // 2:] = 0
+    text[0, L // 2 - 1] = R.END  # one short label so PAD masking / ignore_index are exercised
+    t0 = time.time()
+    _, preds, _ = m(img, text[:, :-1])  # is_train defaults to True (training.py:88)
+    cost = torch.nn.functional.cross_entropy(preds.view(-1, preds.shape[-1]), text[:, 1:].contiguous().view(-1),
+                                             ignore_index=0, reduction="none")
+    loss = cost.mean()
+    loss.backward()
+    ref_grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    ref_frozen = [k for k, p in m.named_parameters() if p.grad is None]
+    after = {k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    oloss, ologits, ograds, obn = R.train_step_grads(cfg, slim_sd(sd), img, text)
+    assert abs(float(oloss) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (float(oloss), float(loss))
+    assert maxdiff(ologits, preds.detach()) <= TOL
+    assert sorted(ograds) == sorted(ref_grads), (set(ograds) ^ set(ref_grads), ref_frozen)
+    worst = 0.0
+    for k, g in ref_grads.items():
+        worst = max(worst, float((ograds[k].double() - g.double()).abs().max() / max(1e-6, float(g.double().abs().max()))))
+    assert worst <= 5e-4, worst
+    for k, v in after.items():
+        assert maxdiff(obn[k], v) <= 1e-5, k
+    arrays = {"logits": preds.detach().numpy(), "text": text.numpy()}
+    norms = {}
+    for k, g in ref_grads.items():
+        idx = grad_sample_index(k, g.numel())
+        arrays["g:" + k] = g.reshape(-1)[idx].numpy()
+        norms[k] = [float(g.double().norm()), float(g.double().sum())]
+    for k, v in after.items():
+        arrays["bn:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
+    return {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
+            "loss": float(loss), "oracle_worst_rel_grad_diff": worst, "n_grads": len(ref_grads), "frozen": ref_frozen,
+            "grad_norms": norms, "seconds": round(time.time() - t0, 1), "torch": torch.__version__}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    summary = {"greedy": [], "beam": [], "train": []}
+    summary = {"greedy": [], "beam": [], "train": [], "train_step": []}
     manifests = {}
+    if os.environ.get("GOLDEN_ONLY") == "train_step":  # refresh only the training fixtures
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        summary["train_step"] = []
+        for case in TRAIN_STEP_CASES:
+            rep = run_train_step(case)
+            summary["train_step"].append(rep)
+            print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        return
     for case in GREEDY_CASES:
         rep, man, cname = run_greedy(case)
         manifests[cname] = man
@@ -249,6 +314,10 @@ def main():
         rep = run_train(case)
         summary["train"].append(rep)
         print("train", rep["case"], rep["loss"], rep["diff_logits"], flush=True)
+    for case in TRAIN_STEP_CASES:
+        rep = run_train_step(case)
+        summary["train_step"].append(rep)
+        print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
     with open(os.path.join(GOLD, "cases.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(GOLD, "manifests.json"), "w") as f:
