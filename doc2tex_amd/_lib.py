@@ -46,6 +46,11 @@ SIGNATURES = {
     "d2t_set_conv_precision": (_I, [_P, _I]),
     "d2t_set_reserved_blocks": (_I, [_P, _I]),
     "d2t_set_decode_chains": (_I, [_P, _I]),
+    "d2t_train_forward": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
+    "d2t_train_backward": (_I, [_P, _P, _P]),
+    "d2t_train_grad": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "d2t_read_weight": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "d2t_train_release": (None, [_P]),
     "d2t_profile_enable": (_I, [_P, _I]),
     "d2t_profile_read": (_I, [_P, _I, C.POINTER(_I)] + [C.POINTER(_I)] * 3 + [C.POINTER(C.c_float)]),
     "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),

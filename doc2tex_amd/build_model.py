@@ -124,11 +124,11 @@ class Model(nn.Module):
             self._engine.decode_wait(host_sync=host_sync)
 
     # -- engine plumbing -----------------------------------------------------
-    def engine(self):
-        """The libd2t context of this model, with the current weights packed."""
+    def engine(self, finalize=True):
+        """The libd2t context of this model, with the current weights uploaded (and packed for inference)."""
         if self._engine is None:
             self._engine = Engine(self.opt)
-        self._engine.sync_weights(self)
+        self._engine.sync_weights(self, finalize=finalize)
         want = self.reserved_blocks if self.pipelined else 0
         if getattr(self._engine, "_reserved", None) != want:
             self._engine.set_reserved_blocks(want)
@@ -185,6 +185,16 @@ class Model(nn.Module):
         return prediction, logits, None, {}
 
     def forward(self, input, text, is_train=True, is_test=False, rtl_text=None):
+        if self.training and self.stages["Pred"] == "TFM":
+            # module.train(): teacher-forced pass with BatchNorm on batch statistics (tfm.py:103-118), one autograd
+            # node over the whole network so that loss.backward() (engine/training.py:137) fills every .grad
+            from .train import train_forward
+            if self.stages["Seq"] != "ViT":
+                raise NotImplementedError("the training step is implemented for the HybridViT + TFM stack")
+            if self.opt["Prediction"]["params"].get("dropout", 0.0) != 0.0:
+                raise NotImplementedError("training with dropout > 0 is not implemented in the HIP engine")
+            logits = train_forward(self, input, text)
+            return logits.argmax(dim=2), logits, {}
         contextual_feature, output_shape, feat_pad = self.forward_encoder(input)
         prediction, logits, decoder_attn, addition_outputs = self.forward_decoder(
             contextual_feature, text=text, is_train=is_train, is_test=is_test, rtl_text=rtl_text)

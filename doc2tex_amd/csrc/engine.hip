@@ -2,204 +2,9 @@
 // the C-ABI declared in include/d2t.h.  Host code only launches the kernels of
 // conv_mfma.hip / ops.hip on the caller's HIP stream; there is no CPU compute
 // path and no fallback.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/d2t.h"
-#include "kernels.h"
-
-using namespace d2t;
+#include "ctx.h"
 
 namespace {
-
-constexpr int TOK_PAD = 0, TOK_GO = 1, TOK_END = 2;  // converter/tfm_converter.py:8
-const int RESNET_LAYERS[4] = {1, 2, 5, 3};           // feature_extractor/resnet.py:262
-
-struct RawW {
-  float* p = nullptr;
-  std::vector<int64_t> shape;
-  size_t numel = 0;
-};
-struct ConvW {
-  float* w = nullptr;
-  uint16_t *w_hi = nullptr, *w_lo = nullptr;  // bf16 split of w for the bf16x3 kernel
-  float* bias = nullptr;
-  int Cout = 0, Cin = 0, KH = 0, KW = 0;
-};
-struct LinW {
-  const float* w = nullptr;
-  const float* b = nullptr;
-  int N = 0, K = 0;
-};
-struct LNW {
-  const float* g = nullptr;
-  const float* b = nullptr;
-};
-struct VitBlock {
-  LNW n1, n2;
-  LinW qkv, proj, fc1, fc2;
-};
-struct DecLayer {
-  LinW sa_in, sa_out, ca_q, ca_out, l1, l2;
-  LNW n1, n2, n3;
-  float *sa_out_t = nullptr, *ca_q_t = nullptr, *ca_out_t = nullptr;  // [k][n] copies for the row kernel
-};
-struct Block {
-  ConvW c1, c2, down;
-  bool has_down = false;
-};
-struct BiLstmW {
-  float* wih_cat = nullptr;   // [2*4H][in]  forward rows then reverse rows
-  float* bias_cat = nullptr;  // [2*4H]      b_ih + b_hh
-  float* whh_t = nullptr;     // [2][H][4H]
-  LinW lin;                   // Linear(2H -> out)
-  int in = 0;
-};
-struct AttnW {
-  const float* emb = nullptr;
-  LinW key;                    // key_proj
-  float *wq_t = nullptr, *wloc = nullptr, *bloc = nullptr, *wx_t = nullptr, *bx = nullptr, *wg_t = nullptr;
-  float *wih_t = nullptr, *wic_t = nullptr;
-  const float *bq = nullptr, *wscore = nullptr, *bg = nullptr, *bih = nullptr, *bic = nullptr;
-  float bscore = 0.f;
-  int taps = 0;
-};
-struct Act {
-  float* p;
-  int B, H, W, C;
-  bool split = false;  // two bf16 planes (hi | lo) in the same buffer instead of fp32
-  size_t numel() const { return (size_t)B * H * W * C; }
-  uint16_t* planes() const { return reinterpret_cast<uint16_t*>(p); }
-};
-
-}  // namespace
-
-struct d2t_ctx {
-  d2t_config cfg;
-  std::string err;
-  std::map<std::string, RawW> raw;
-  std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
-  bool finalized = false;
-  bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
-  int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
-  int num_cus = 0;
-
-  // packed weights
-  std::string bb;  // backbone key prefix ("...ConvNet.")
-  ConvW stem, conv0_2, conv1, conv2, conv3, conv4_1, conv4_2, patch;
-  ConvW vgg[7];      // VGG convs 0,3,6,8,11(+bn12),14(+bn15),18 (feature_extractor/vgg.py:16-41)
-  BiLstmW lstm[2];   // seq_modeling/bilstm.py
-  AttnW attn;        // prediction_head/seq2seq.py
-  std::vector<Block> layers[4];
-  const float* pos_embed = nullptr;  // [1+gh*gw][dim]
-  int pos_rows = 0;
-  float* cls_row = nullptr;  // cls_token + pos_embed[0]
-  std::vector<VitBlock> vit;
-  LNW vit_norm;
-  const float* word_embed = nullptr;
-  const float* word_pe = nullptr;
-  int word_pe_rows = 0;
-  std::vector<DecLayer> dec;
-  float* ckv_w = nullptr;  // [layers*2*d][d] cross-attention K,V projections of every layer
-  float* ckv_b = nullptr;
-  LinW out_proj;
-
-  // workspace
-  float* act[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t act_cap = 0;
-  std::map<std::pair<int, int>, float*> pe2d;  // PositionalEncoding2D crops [h*w][C]
-  // decoder state
-  float* ckv2[2] = {nullptr, nullptr}; size_t ckv2_cap[2] = {0, 0};  // cross K/V, double-buffered across decodes
-  float* ckv = nullptr;                                              // the slot the current decode reads
-  hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
-  bool ev_done_valid[2] = {false, false};
-  unsigned decode_seq = 0;
-  float* skv = nullptr; size_t skv_cap = 0;
-  float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
-  float* skv_cur = nullptr;                          // cache decode_step reads / appends
-  float* beam_ws = nullptr; size_t beam_ws_cap = 0;  // beam logits / scores / tokens / top-k
-  float* dws = nullptr; size_t dws_cap = 0;
-  int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]
-  size_t dstate_cap = 0;
-  int* h_pinned = nullptr;
-  void* zero_page = nullptr;  // 256 zero bytes: out-of-image taps of the split-bf16 convolution
-  hipStream_t dstream = nullptr;
-  // Second decode chain (own stream, self-attention cache, workspace, state): with two chains the decode
-  // loops of consecutive async batches run side by side.  The members above are the ACTIVE chain; the
-  // inactive one is parked here (select_chain swaps them).
-  struct Chain { hipStream_t stream = nullptr; float* skv = nullptr; size_t skv_cap = 0; float* dws = nullptr;
-                 size_t dws_cap = 0; int* dstate = nullptr; size_t dstate_cap = 0;
-                 float* out = nullptr; size_t out_cap = 0; } parked;
-  // async decodes write tokens / logits here (fixed addresses, so one captured graph per chain serves every
-  // caller buffer) and copy them out afterwards
-  float* dout = nullptr; size_t dout_cap = 0;
-  int active_chain = 0, n_chains = 1;
-  hipEvent_t ev_in = nullptr;
-  struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
-  struct GraphEnt { GraphKey key; hipGraphExec_t exec; };
-  std::vector<GraphEnt> graphs;  // small cache of captured decode steps (most recent last)
-  // kernel timing log (d2t_profile_*)
-  bool profiling = false;
-  struct ProfRec { int M, N, K; hipEvent_t a, b; };
-  std::vector<ProfRec> prof;
-};
-
-namespace {
-
-int fail(d2t_ctx* c, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c) c->err = buf;
-  return code;
-}
-#define HIPCHK(c, expr)                                                                        \
-  do {                                                                                         \
-    hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess) return fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
-  } while (0)
-
-int dev_alloc(d2t_ctx* c, void** p, size_t bytes) {
-  if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return fail(c, D2T_ENOMEM, "hipMalloc(%zu) failed", bytes);
-  return D2T_OK;
-}
-// grow-only buffer; growing synchronises the device (never during graph capture)
-template <typename T>
-int ensure(d2t_ctx* c, T** p, size_t* cap, size_t bytes) {
-  if (*cap >= bytes && *p) return D2T_OK;
-  if (*p) { hipDeviceSynchronize(); hipFree(*p); *p = nullptr; }
-  int rc = dev_alloc(c, reinterpret_cast<void**>(p), bytes);
-  if (rc) return rc;
-  *cap = bytes;
-  return D2T_OK;
-}
-
-const RawW* find(d2t_ctx* c, const std::string& k) {
-  auto it = c->raw.find(k);
-  return it == c->raw.end() ? nullptr : &it->second;
-}
-int need(d2t_ctx* c, const std::string& k, const RawW** out, std::vector<int64_t> shape = {}) {
-  const RawW* r = find(c, k);
-  if (!r) return fail(c, D2T_ESTATE, "missing weight '%s'", k.c_str());
-  if (!shape.empty() && r->shape != shape) {
-    std::string s;
-    for (auto v : r->shape) s += std::to_string(v) + ",";
-    return fail(c, D2T_EINVAL, "weight '%s' has shape [%s]", k.c_str(), s.c_str());
-  }
-  *out = r;
-  return D2T_OK;
-}
 
 int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW* out, hipStream_t s) {
   const RawW *w, *g = nullptr, *b = nullptr, *mu = nullptr, *var = nullptr;
@@ -472,6 +277,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
 void d2t_destroy(d2t_ctx* c) {
   if (!c) return;
   hipDeviceSynchronize();
+  d2t_train_release(c);
   for (auto& ge : c->graphs) hipGraphExecDestroy(ge.exec);
   c->graphs.clear();
   free_packed(c);

@@ -188,4 +188,73 @@ hipError_t launch_add_rows(const float* a, const float* b, float* out, int n, hi
 // out[b*img_stride*D + i] = row[i] for i < D  (cls-token row of every image)
 hipError_t launch_fill_cls(const float* row, float* out, int B, long long img_stride_floats, int D, hipStream_t s);
 
+// ---- training step (train_kernels.hip) --------------------------------------
+// Weight gradient ("TN" GEMM, optional filter taps): part[z][tap][m][n] = sum_{p in chunk z} a[p][m] * x[src(p,tap)][n]
+struct WgradP {
+  const float* a;   // [P][lda]: upstream gradient rows (dz of a convolution / dy of a Linear)
+  const float* b;   // geom: NHWC input [B,H,W,ldb];  else [P][ldb]
+  float* part;      // [S][taps][M][N]
+  long long P;      // rows of a (= B*OH*OW)
+  int M, N, lda, ldb;
+  int taps, geom;   // geom != 0: rows are output pixels of a convolution with the geometry below
+  int H, W, OH, OW, KW, SH, SW, PH, PW;
+  int S, chunk;     // split over row chunks of `chunk` rows
+};
+hipError_t launch_wgrad(const WgradP& p, hipStream_t s);
+hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
+                               hipStream_t s);
+enum { CR_SUM = 0, CR_SUM_SQ = 1, CR_BN_BWD = 2, CR_LN_BWD = 3 };
+struct ColRedP {
+  const float* a;     // [R][C]
+  const float* y;     // CR_BN_BWD: post-ReLU output (nullable = no ReLU)
+  const float* z;     // CR_BN_BWD: pre-BN values;  CR_LN_BWD: LayerNorm input
+  const float* mean;  // per channel (BN) / per row (LN)
+  const float* rstd;
+  float* part;        // [chunks][2][C]
+  long long R;
+  int C, mode;
+};
+int colreduce_chunks(long long R);
+hipError_t launch_colreduce(const ColRedP& p, hipStream_t s);
+hipError_t launch_colreduce_final(const float* part, int chunks, int C, float* out0, float* out1, int accumulate,
+                                  hipStream_t s);
+hipError_t launch_bn_finalize(const float* part, int chunks, int C, long long R, float eps, float momentum, float* mean,
+                              float* rstd, float* run_mean, float* run_var, hipStream_t s);
+hipError_t launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* g, const float* b,
+                           const float* res, float* y, long long R, int C, int relu, hipStream_t s);
+hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                               const float* gamma, const float* s0, const float* s1, float* dz, float* gout, long long R,
+                               int C, hipStream_t s);
+enum { EW_COPY = 0, EW_ADD = 1, EW_RELU_BWD = 2, EW_GELU = 3, EW_GELU_BWD = 4 };
+hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int op, hipStream_t s);
+hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
+                              int PW, hipStream_t s);
+hipError_t launch_ln_train(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
+                           int D, float eps, hipStream_t s);
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
+                         const float* add, float* dx, int rows, int D, hipStream_t s);
+struct AttnTrainP {
+  const float *q, *k, *v;  // row (b*L + i), stride ld*, head offset head*hd
+  float* o;                // forward: output;  backward: dO (read)
+  float* probs;            // [B][heads][Lq][Lk]; the backward pass overwrites it with dS
+  float *dq, *dk, *dv;     // backward outputs (q / k / v strides)
+  const int64_t* keytok;   // optional [B][Lk]: keys whose token == pad_id are masked
+  int B, heads, hd, Lq, Lk, ldq, ldk, ldv, ldo, causal, pad_id;
+};
+hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s);
+hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s);
+hipError_t launch_embed_train(const float* E, const float* pe, const int64_t* tok, float* x, int rows, int L, int D,
+                              float scale, hipStream_t s);
+hipError_t launch_embed_bwd(const float* dx, const int64_t* tok, float* dE, int rows, int V, int D, float scale, int pad_id,
+                            hipStream_t s);
+hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s);
+hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
+                         int offw, hipStream_t s);
+hipError_t launch_flip_oihw(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
+hipError_t launch_token_rows(const float* src, float* dst, int B, int n, int skip, int D, int scatter, hipStream_t s);
+hipError_t launch_sum_rows_strided(const float* x, float* out, int B, long long stride_rows, int row, int D, hipStream_t s);
+hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, int H, int W, int Cout, hipStream_t s);
+hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int B, int H, int W, int Cout, int chunk,
+                             int nchunks, hipStream_t s);
+
 }  // namespace d2t

@@ -1,0 +1,713 @@
+// Training step of the recognizer: Model.forward under module.train() and its backward.
+//
+//   d2t_train_forward   image, teacher tokens -> logits [B][L][V]; BatchNorm on batch statistics (running statistics
+//                       updated in the engine's copies), teacher-forced decoder pass with causal + PAD key-padding
+//                       masks (prediction_head/tfm.py:103-118); every intermediate the backward needs stays on a tape
+//   d2t_train_backward  dlogits -> gradient of every trainable parameter (what loss.backward() leaves in .grad,
+//                       engine/training.py:137); read back with d2t_train_grad
+//
+// Supported stack: HybridViT (ResNet backbone + ViTEncoderV3) or ResNet+None encoders with the TFM head; dropout 0.
+// All arithmetic fp32: GEMMs and convolutions (forward and data gradients) on the fp32-MFMA implicit-GEMM kernel
+// (conv_mfma.hip), weight gradients on the fp32-MFMA TN kernel (train_kernels.hip).  The network is recorded as a
+// tape of nodes over row-major [rows][cols] tensors (NHWC maps are [B*H*W][C]); the backward walks it in reverse and
+// accumulates into tensor gradients, so residual fan-out needs no special cases.
+#include "ctx.h"
+
+namespace {
+
+const int RESNET_BLOCKS[4] = {1, 2, 5, 3};  // feature_extractor/resnet.py:262
+
+struct Arena {
+  struct Blk { char* p; size_t cap; };
+  std::vector<Blk> blks;
+  size_t cur = 0, off = 0;
+  void reset() { cur = 0; off = 0; }
+  float* alloc(size_t floats) {
+    const size_t bytes = (floats * 4 + 255) & ~(size_t)255;
+    while (cur < blks.size() && off + bytes > blks[cur].cap) { ++cur; off = 0; }
+    if (cur == blks.size()) {
+      const size_t cap = std::max(bytes, (size_t)256 << 20);
+      void* q = nullptr;
+      if (hipMalloc(&q, cap) != hipSuccess) return nullptr;
+      blks.push_back({(char*)q, cap});
+      off = 0;
+    }
+    float* r = reinterpret_cast<float*>(blks[cur].p + off);
+    off += bytes;
+    return r;
+  }
+  void release() {
+    for (auto& b : blks) hipFree(b.p);
+    blks.clear();
+    reset();
+  }
+};
+
+struct TT {  // tensor on the tape
+  float* p = nullptr;
+  long long rows = 0;
+  int cols = 0;
+  int B = 0, H = 0, W = 0;  // NHWC maps: rows = B*H*W
+  float* grad = nullptr;
+};
+
+enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS };
+
+struct Node {
+  Kind kind;
+  int in = -1, in2 = -1, out = -1;  // tensor ids (in2: residual / second operand)
+  // N_CONV: conv (+ BatchNorm) (+ residual in2) (+ ReLU)
+  std::string wkey, bnkey;
+  int KH = 0, KW = 0, SH = 1, SW = 1, PH = 0, PW = 0;
+  float *z = nullptr, *mean = nullptr, *rstd = nullptr;
+  bool relu = false, stem = false;
+  // N_LINEAR: out = act(in @ W[woff : woff+N]^T + b) (+ in2)
+  std::string bkey;
+  int N = 0, K = 0, woff = 0;
+  // N_LN
+  std::string gkey;
+  float eps = 0.f;
+  // N_ATTN: q / k / v column offsets inside tensors in (q) and in2 (k, v)
+  int qoff = 0, koff = 0, voff = 0, heads = 0, hd = 0, Lq = 0, Lk = 0, nb = 0, causal = 0;
+  const int64_t* keytok = nullptr;
+  float* probs = nullptr;
+  // N_TOKENS: out[b][0] = cls + pos[0], out[b][1+i] = in[b][i] + pos[1+i]   (in = patch tokens)
+  int ntok = 0;
+};
+
+}  // namespace
+
+struct d2t_train_state {
+  Arena tape;
+  std::vector<TT> t;
+  std::vector<Node> nodes;
+  std::map<std::string, float*> grads;  // persistent, one buffer per trainable parameter
+  float* part = nullptr; size_t part_cap = 0;   // wgrad / column-reduction partial sums
+  float* scratch = nullptr; size_t scratch_cap = 0;
+  const int64_t* tgt = nullptr;
+  const float* image = nullptr;
+  int B = 0, H = 0, W = 0, L = 0;
+  int logits_id = -1;
+  bool have_forward = false;
+  ~d2t_train_state() {
+    tape.release();
+    for (auto& kv : grads) hipFree(kv.second);
+    if (part) hipFree(part);
+    if (scratch) hipFree(scratch);
+  }
+};
+
+namespace {
+
+#define TCHK(expr)                                                                               \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_));      \
+  } while (0)
+#define RC(expr)            \
+  do {                      \
+    int rc_ = (expr);       \
+    if (rc_) return rc_;    \
+  } while (0)
+
+struct Tr {  // builder / runner bound to one context and stream
+  d2t_ctx* c;
+  d2t_train_state* st;
+  hipStream_t s;
+
+  int alloc(float** p, size_t floats) {
+    *p = st->tape.alloc(floats);
+    return *p ? D2T_OK : fail(c, D2T_ENOMEM, "training tape: hipMalloc failed");
+  }
+  int new_tensor(long long rows, int cols, int* id, int B = 0, int H = 0, int W = 0, float* into = nullptr) {
+    TT x;
+    x.rows = rows; x.cols = cols; x.B = B; x.H = H; x.W = W;
+    if (into) x.p = into; else RC(alloc(&x.p, (size_t)rows * cols));
+    st->t.push_back(x);
+    *id = (int)st->t.size() - 1;
+    return D2T_OK;
+  }
+  int raw(const std::string& k, const float** p, size_t numel = 0) {
+    const RawW* r;
+    RC(need(c, k, &r));
+    if (numel && r->numel != numel) return fail(c, D2T_EINVAL, "weight '%s' has %zu elements, expected %zu", k.c_str(), r->numel, numel);
+    *p = r->p;
+    return D2T_OK;
+  }
+  int grad_buf(const std::string& k, float** p) {
+    auto it = st->grads.find(k);
+    if (it != st->grads.end()) { *p = it->second; return D2T_OK; }
+    const RawW* r;
+    RC(need(c, k, &r));
+    void* q;
+    RC(dev_alloc(c, &q, r->numel * 4));
+    TCHK(hipMemsetAsync(q, 0, r->numel * 4, s));
+    st->grads[k] = (float*)q;
+    *p = (float*)q;
+    return D2T_OK;
+  }
+  int ensure_part(size_t floats) { return ensure(c, &st->part, &st->part_cap, floats * 4); }
+  int ensure_scratch(size_t floats) { return ensure(c, &st->scratch, &st->scratch_cap, floats * 4); }
+
+  // out[M][N] = act(a[M][K] @ w[N][K]^T + bias) + res      (fp32 MFMA GEMM; K % 32 == 0)
+  int gemm_nt(const float* a, const float* w, const float* bias, const float* res, float* out, long long M, int N, int K,
+              int act) {
+    ConvP p{};
+    p.in = a; p.w = w; p.bias = bias; p.res = res; p.out = out;
+    p.B = 1; p.H = 1; p.W = (int)M; p.Cin = K; p.OH = 1; p.OW = (int)M; p.Cout = N;
+    p.KH = p.KW = p.SH = p.SW = 1; p.M = (int)M; p.K = K; p.act = act;
+    TCHK(launch_conv(p, s));
+    return D2T_OK;
+  }
+  // dst[c] (+)= column sums of a[R][C]
+  int colsum(const float* a, long long R, int C, float* dst) {
+    const int chunks = colreduce_chunks(R);
+    RC(ensure_part((size_t)chunks * 2 * C));
+    ColRedP p{};
+    p.a = a; p.part = st->part; p.R = R; p.C = C; p.mode = CR_SUM;
+    TCHK(launch_colreduce(p, s));
+    TCHK(launch_colreduce_final(st->part, chunks, C, dst, nullptr, 0, s));
+    return D2T_OK;
+  }
+  // dW[M][N](taps) = a^T (x) b  with the split-K two-pass reduction
+  int wgrad(const float* a, int lda, const float* b, int ldb, long long P, int M, int N, int taps, const Node* geom,
+            const TT* xin, const TT* yout, float* dst, int layout) {
+    const int tile = (M <= 64 || N <= 64) ? 64 : 128;
+    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps;
+    long long S = std::max<long long>(1, std::min<long long>((P + 511) / 512, (1536 + tiles - 1) / tiles));
+    long long chunk = ((P + S - 1) / S + 31) / 32 * 32;
+    S = (P + chunk - 1) / chunk;
+    RC(ensure_part((size_t)S * taps * M * N));
+    WgradP p{};
+    p.a = a; p.b = b; p.part = st->part; p.P = P; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.taps = taps;
+    p.KW = 1; p.S = (int)S; p.chunk = (int)chunk;
+    if (geom) {
+      p.geom = 1; p.H = xin->H; p.W = xin->W; p.OH = yout->H; p.OW = yout->W;
+      p.KW = geom->KW; p.SH = geom->SH; p.SW = geom->SW; p.PH = geom->PH; p.PW = geom->PW;
+    }
+    TCHK(launch_wgrad(p, s));
+    TCHK(launch_wgrad_reduce(st->part, dst, (int)S, taps, M, N, layout, 0, s));
+    return D2T_OK;
+  }
+  // tensor gradient accumulation: first contribution takes the buffer, later ones add
+  int add_grad(int id, float* g) {
+    TT& x = st->t[id];
+    if (!x.grad) { x.grad = g; return D2T_OK; }
+    TCHK(launch_ew(x.grad, g, x.grad, (size_t)x.rows * x.cols, EW_ADD, s));
+    return D2T_OK;
+  }
+  int own_grad(int id) {  // make sure tensor `id` has a gradient buffer (contents unspecified)
+    TT& x = st->t[id];
+    if (!x.grad) RC(alloc(&x.grad, (size_t)x.rows * x.cols));
+    return D2T_OK;
+  }
+
+  // ---------------- forward builders ----------------
+  // conv (+BN batch stats) (+res) (+relu).  bnkey empty: bias from wkey + ".bias", no normalisation.
+  int conv_bn(int in, const std::string& wkey, const std::string& bnkey, int Cout, int KH, int KW, int SH, int SW, int PH,
+              int PW, bool relu, int res, int* out, int OH = -1, int OW = -1) {
+    const TT x = st->t[in];
+    if (OH < 0) { OH = (x.H + 2 * PH - KH) / SH + 1; OW = (x.W + 2 * PW - KW) / SW + 1; }
+    const long long P = (long long)x.B * OH * OW;
+    Node n;
+    n.kind = N_CONV; n.in = in; n.in2 = res; n.wkey = wkey; n.bnkey = bnkey;
+    n.KH = KH; n.KW = KW; n.SH = SH; n.SW = SW; n.PH = PH; n.PW = PW; n.relu = relu; n.N = Cout; n.K = KH * KW * x.cols;
+    const float* w;
+    RC(raw(wkey + ".weight", &w, (size_t)Cout * x.cols * KH * KW));
+    // raw OIHW -> the kernel's packed OHWI order (no BN folding in training mode)
+    RC(ensure_scratch((size_t)Cout * n.K + Cout));
+    float* wp = st->scratch;
+    const float* bias = nullptr;
+    if (bnkey.empty()) RC(raw(wkey + ".bias", &bias, Cout));
+    TCHK(launch_pack_conv(w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, wp, wp + (size_t)Cout * n.K, Cout, x.cols, KH, KW, s));
+    RC(alloc(&n.z, (size_t)P * Cout));
+    ConvP p{};
+    p.in = x.p; p.w = wp; p.bias = bias; p.out = n.z;
+    p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
+    TCHK(launch_conv(p, s));
+    if (bnkey.empty()) {
+      RC(new_tensor(P, Cout, out, x.B, OH, OW, n.z));
+    } else {
+      RC(bn_forward(n, P, Cout, res));
+      RC(new_tensor(P, Cout, out, x.B, OH, OW));
+      const float *g, *b;
+      RC(raw(bnkey + ".weight", &g, Cout));
+      RC(raw(bnkey + ".bias", &b, Cout));
+      TCHK(launch_bn_apply(n.z, n.mean, n.rstd, g, b, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, P, Cout, relu, s));
+    }
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int bn_forward(Node& n, long long P, int C, int /*res*/) {
+    RC(alloc(&n.mean, C));
+    RC(alloc(&n.rstd, C));
+    const int chunks = colreduce_chunks(P);
+    RC(ensure_part((size_t)chunks * 2 * C));
+    ColRedP p{};
+    p.a = n.z; p.part = st->part; p.R = P; p.C = C; p.mode = CR_SUM_SQ;
+    TCHK(launch_colreduce(p, s));
+    const RawW *rm, *rv;
+    RC(need(c, n.bnkey + ".running_mean", &rm));
+    RC(need(c, n.bnkey + ".running_var", &rv));
+    TCHK(launch_bn_finalize(st->part, chunks, C, P, 1e-5f, 0.1f, n.mean, n.rstd, rm->p, rv->p, s));
+    return D2T_OK;
+  }
+  int stem(const float* img, int B, int H, int W, const std::string& wkey, const std::string& bnkey, int* out) {
+    const int Cout = 32;
+    const long long P = (long long)B * H * W;
+    Node n;
+    n.kind = N_CONV; n.stem = true; n.wkey = wkey; n.bnkey = bnkey; n.relu = true; n.N = Cout; n.K = 9;
+    n.KH = n.KW = 3; n.PH = n.PW = 1;
+    const float* w;
+    RC(raw(wkey + ".weight", &w, (size_t)Cout * 9));
+    RC(alloc(&n.z, (size_t)P * Cout));
+    TCHK(launch_stem_raw(img, w, n.z, B, H, W, Cout, s));
+    RC(bn_forward(n, P, Cout, -1));
+    RC(new_tensor(P, Cout, out, B, H, W));
+    const float *g, *b;
+    RC(raw(bnkey + ".weight", &g, Cout));
+    RC(raw(bnkey + ".bias", &b, Cout));
+    TCHK(launch_bn_apply(n.z, n.mean, n.rstd, g, b, nullptr, st->t[*out].p, P, Cout, 1, s));
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int pool(int in, int SH, int SW, int PH, int PW, int* out) {
+    const TT x = st->t[in];
+    const int OH = (x.H + 2 * PH - 2) / SH + 1, OW = (x.W + 2 * PW - 2) / SW + 1;
+    RC(new_tensor((long long)x.B * OH * OW, x.cols, out, x.B, OH, OW));
+    TCHK(launch_maxpool(x.p, st->t[*out].p, x.B, x.H, x.W, x.cols, SH, SW, PH, PW, s));
+    Node n;
+    n.kind = N_POOL; n.in = in; n.out = *out; n.SH = SH; n.SW = SW; n.PH = PH; n.PW = PW;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int backbone(const float* img, int B, int H, int W, const std::string& p, int* out) {
+    int x;
+    RC(stem(img, B, H, W, p + "conv0_1", p + "bn0_1", &x));
+    RC(conv_bn(x, p + "conv0_2", p + "bn0_2", 64, 3, 3, 1, 1, 1, 1, true, -1, &x));
+    RC(pool(x, 2, 2, 0, 0, &x));
+    const int chans[4] = {128, 256, 512, 512};
+    auto stage = [&](int li) -> int {
+      for (int i = 0; i < RESNET_BLOCKS[li]; ++i) {
+        const std::string bp = p + "layer" + std::to_string(li + 1) + "." + std::to_string(i);
+        int t, r = x;
+        RC(conv_bn(x, bp + ".conv1", bp + ".bn1", chans[li], 3, 3, 1, 1, 1, 1, true, -1, &t));
+        if (find(c, bp + ".downsample.0.weight"))
+          RC(conv_bn(x, bp + ".downsample.0", bp + ".downsample.1", chans[li], 1, 1, 1, 1, 0, 0, false, -1, &r));
+        RC(conv_bn(t, bp + ".conv2", bp + ".bn2", chans[li], 3, 3, 1, 1, 1, 1, true, r, &x));
+      }
+      return D2T_OK;
+    };
+    RC(stage(0));
+    RC(conv_bn(x, p + "conv1", p + "bn1", 128, 3, 3, 1, 1, 1, 1, true, -1, &x));
+    RC(pool(x, 2, 2, 0, 0, &x));
+    RC(stage(1));
+    RC(conv_bn(x, p + "conv2", p + "bn2", 256, 3, 3, 1, 1, 1, 1, true, -1, &x));
+    RC(pool(x, 2, 1, 0, 1, &x));
+    RC(stage(2));
+    RC(conv_bn(x, p + "conv3", p + "bn3", 512, 3, 3, 1, 1, 1, 1, true, -1, &x));
+    RC(stage(3));
+    RC(conv_bn(x, p + "conv4_1", p + "bn4_1", 512, 2, 2, 2, 1, 0, 1, true, -1, &x));
+    RC(conv_bn(x, p + "conv4_2", p + "bn4_2", 512, 2, 2, 1, 1, 0, 0, true, -1, &x));
+    *out = x;
+    return D2T_OK;
+  }
+
+  // out = act(in @ W[woff:woff+N]^T + b[woff:woff+N]) + res;  `into`: write the result into caller memory
+  int linear(int in, const std::string& key, int N, int K, int woff, int act, int res, int* out, float* into = nullptr) {
+    const TT x = st->t[in];
+    if (x.cols != K) return fail(c, D2T_EINVAL, "linear '%s': input has %d columns, expected %d", key.c_str(), x.cols, K);
+    const float *w, *b;
+    RC(raw(key + (key.find("in_proj") != std::string::npos ? "_weight" : ".weight"), &w));
+    RC(raw(key + (key.find("in_proj") != std::string::npos ? "_bias" : ".bias"), &b));
+    RC(new_tensor(x.rows, N, out, 0, 0, 0, into));
+    RC(gemm_nt(x.p, w + (size_t)woff * K, b + woff, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, x.rows, N, K, act));
+    Node n;
+    n.kind = N_LINEAR; n.in = in; n.in2 = res; n.out = *out; n.wkey = key; n.N = N; n.K = K; n.woff = woff; n.relu = act == ACT_RELU;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int layernorm(int in, const std::string& key, float eps, int* out, float* into = nullptr) {
+    const TT x = st->t[in];
+    const float *g, *b;
+    RC(raw(key + ".weight", &g, x.cols));
+    RC(raw(key + ".bias", &b, x.cols));
+    Node n;
+    n.kind = N_LN; n.in = in; n.gkey = key; n.eps = eps;
+    RC(alloc(&n.mean, x.rows));
+    RC(alloc(&n.rstd, x.rows));
+    RC(new_tensor(x.rows, x.cols, out, 0, 0, 0, into));
+    TCHK(launch_ln_train(x.p, g, b, st->t[*out].p, n.mean, n.rstd, (int)x.rows, x.cols, eps, s));
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int attention(int qt, int qoff, int kvt, int koff, int voff, int nb, int Lq, int Lk, int heads, int hd, int causal,
+                const int64_t* keytok, int* out) {
+    Node n;
+    n.kind = N_ATTN; n.in = qt; n.in2 = kvt; n.qoff = qoff; n.koff = koff; n.voff = voff; n.nb = nb; n.Lq = Lq; n.Lk = Lk;
+    n.heads = heads; n.hd = hd; n.causal = causal; n.keytok = keytok;
+    RC(alloc(&n.probs, (size_t)nb * heads * Lq * Lk));
+    RC(new_tensor((long long)nb * Lq, heads * hd, out));
+    AttnTrainP p{};
+    p.q = st->t[qt].p + qoff; p.k = st->t[kvt].p + koff; p.v = st->t[kvt].p + voff; p.o = st->t[*out].p; p.probs = n.probs;
+    p.keytok = keytok; p.B = nb; p.heads = heads; p.hd = hd; p.Lq = Lq; p.Lk = Lk;
+    p.ldq = st->t[qt].cols; p.ldk = p.ldv = st->t[kvt].cols; p.ldo = heads * hd; p.causal = causal; p.pad_id = 0;
+    TCHK(launch_attn_train_fwd(p, s));
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int gelu(int in, int* out) {
+    const TT x = st->t[in];
+    RC(new_tensor(x.rows, x.cols, out));
+    TCHK(launch_ew(x.p, nullptr, st->t[*out].p, (size_t)x.rows * x.cols, EW_GELU, s));
+    Node n;
+    n.kind = N_GELU; n.in = in; n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+
+  // ViTEncoderV3 on top of the backbone (vit_encoder.py:249-268, patchembed.py:115-141)
+  int vit(int feat, const std::string& p, int* out, float* into) {
+    const d2t_config& g = c->cfg;
+    const TT f = st->t[feat];
+    const int D = g.vit_dim, gh = (f.H + g.patch_h - 1) / g.patch_h, gw = (f.W + g.patch_w - 1) / g.patch_w, n = gh * gw;
+    int patch;
+    // zero padding right / bottom = out-of-image taps of the strided convolution
+    RC(conv_bn(feat, p + "patch_embed.proj", "", D, g.patch_h, g.patch_w, g.patch_h, g.patch_w, 0, 0, false, -1, &patch, gh, gw));
+    // tokens: [cls + pos[0] | patch + pos[1:]]
+    const float *cls, *pos;
+    RC(raw(p + "cls_token", &cls, D));
+    const RawW* pr;
+    RC(need(c, p + "pos_embed", &pr));
+    pos = pr->p;
+    if ((long long)pr->numel < (long long)(n + 1) * D) return fail(c, D2T_EINVAL, "pos_embed too small for %d tokens", n + 1);
+    int x;
+    RC(new_tensor((long long)f.B * (n + 1), D, &x));
+    TCHK(launch_token_rows(st->t[patch].p, st->t[x].p, f.B, n, 1, D, 1, s));          // scatter, cls rows zero
+    TCHK(launch_fill_cls(cls, st->t[x].p, f.B, (long long)(n + 1) * D, D, s));
+    {  // + pos_embed[:, :n+1] (flat prefix slice, vit_encoder.py:260), broadcast over the batch
+      for (int b = 0; b < f.B; ++b)
+        TCHK(launch_add_rows(st->t[x].p + (size_t)b * (n + 1) * D, pos, st->t[x].p + (size_t)b * (n + 1) * D, (n + 1) * D, s));
+    }
+    Node tn;
+    tn.kind = N_TOKENS; tn.in = patch; tn.out = x; tn.ntok = n; tn.wkey = p + "cls_token";
+    st->nodes.push_back(tn);
+    const int rows_b = n + 1;
+    for (int i = 0; i < g.vit_depth; ++i) {
+      const std::string bp = p + "blocks." + std::to_string(i) + ".";
+      int h, qkv, a, x1, h2, u, ge, x2;
+      RC(layernorm(x, bp + "norm1", 1e-6f, &h));
+      RC(linear(h, bp + "attn.qkv", 3 * D, D, 0, ACT_NONE, -1, &qkv));
+      RC(attention(qkv, 0, qkv, D, 2 * D, f.B, rows_b, rows_b, g.vit_heads, D / g.vit_heads, 0, nullptr, &a));
+      RC(linear(a, bp + "attn.proj", D, D, 0, ACT_NONE, x, &x1));
+      RC(layernorm(x1, bp + "norm2", 1e-6f, &h2));
+      RC(linear(h2, bp + "mlp.fc1", 4 * D, D, 0, ACT_NONE, -1, &u));
+      RC(gelu(u, &ge));
+      RC(linear(ge, bp + "mlp.fc2", D, 4 * D, 0, ACT_NONE, x1, &x2));
+      x = x2;
+    }
+    RC(layernorm(x, p + "norm", 1e-6f, out, into));
+    return D2T_OK;
+  }
+
+  // TransformerPrediction teacher-forced pass (tfm.py:103-118), post-norm nn.TransformerDecoderLayer
+  int decoder(int mem, const int64_t* tgt, int B, int L, const std::string& p, float* logits, int* out) {
+    const d2t_config& g = c->cfg;
+    const int D = g.dec_dim, heads = g.dec_heads, hd = D / heads, T = (int)(st->t[mem].rows / B);
+    const float *E, *pe;
+    RC(raw(p + "word_embed.weight", &E, (size_t)g.vocab * D));
+    RC(raw(p + "pos_enc.pe", &pe));
+    int x;
+    RC(new_tensor((long long)B * L, D, &x));
+    TCHK(launch_embed_train(E, pe, tgt, st->t[x].p, B * L, L, D, sqrtf((float)D), s));
+    Node en;
+    en.kind = N_EMBED; en.out = x; en.wkey = p + "word_embed.weight";
+    st->nodes.push_back(en);
+    for (int l = 0; l < g.dec_layers; ++l) {
+      const std::string lp = p + "model.layers." + std::to_string(l) + ".";
+      int qkv, a, y1, x1, q2, kv, a2, y2, x2, f, y3, x3;
+      RC(linear(x, lp + "self_attn.in_proj", 3 * D, D, 0, ACT_NONE, -1, &qkv));
+      RC(attention(qkv, 0, qkv, D, 2 * D, B, L, L, heads, hd, 1, tgt, &a));
+      RC(linear(a, lp + "self_attn.out_proj", D, D, 0, ACT_NONE, x, &y1));
+      RC(layernorm(y1, lp + "norm1", 1e-5f, &x1));
+      RC(linear(x1, lp + "multihead_attn.in_proj", D, D, 0, ACT_NONE, -1, &q2));
+      RC(linear(mem, lp + "multihead_attn.in_proj", 2 * D, D, D, ACT_NONE, -1, &kv));
+      RC(attention(q2, 0, kv, 0, D, B, L, T, heads, hd, 0, nullptr, &a2));
+      RC(linear(a2, lp + "multihead_attn.out_proj", D, D, 0, ACT_NONE, x1, &y2));
+      RC(layernorm(y2, lp + "norm2", 1e-5f, &x2));
+      RC(linear(x2, lp + "linear1", g.dec_ff, D, 0, ACT_RELU, -1, &f));
+      RC(linear(f, lp + "linear2", D, g.dec_ff, 0, ACT_NONE, x2, &y3));
+      RC(layernorm(y3, lp + "norm3", 1e-5f, &x3));
+      x = x3;
+    }
+    RC(linear(x, p + "proj", g.vocab, D, 0, ACT_NONE, -1, out, logits));
+    return D2T_OK;
+  }
+
+  // ---------------- backward ----------------
+  int bwd_linear(const Node& n) {
+    const TT& y = st->t[n.out];
+    const TT& x = st->t[n.in];
+    const float* g = y.grad;
+    if (n.in2 >= 0) RC(add_grad(n.in2, y.grad));  // the residual branch takes the incoming gradient as is
+    if (n.relu) {
+      float* m;
+      RC(alloc(&m, (size_t)y.rows * y.cols));
+      TCHK(launch_ew(y.grad, y.p, m, (size_t)y.rows * y.cols, EW_RELU_BWD, s));
+      g = m;
+    }
+    const bool inproj = n.wkey.find("in_proj") != std::string::npos;
+    const std::string wk = n.wkey + (inproj ? "_weight" : ".weight"), bk = n.wkey + (inproj ? "_bias" : ".bias");
+    float *dW, *db;
+    RC(grad_buf(wk, &dW));
+    RC(grad_buf(bk, &db));
+    RC(colsum(g, y.rows, n.N, db + n.woff));
+    RC(wgrad(g, n.N, x.p, n.K, y.rows, n.N, n.K, 1, nullptr, nullptr, nullptr, dW + (size_t)n.woff * n.K, 0));
+    // dx = g @ W  ->  NT GEMM against W^T [K][N]; the reduction dimension N must be a multiple of 32
+    const float* w;
+    RC(raw(wk, &w));
+    w += (size_t)n.woff * n.K;
+    const int Np = (n.N + 31) / 32 * 32;
+    float *wt, *dx;
+    RC(alloc(&wt, (size_t)n.K * Np));
+    const float* gp = g;
+    if (Np != n.N) {  // vocabulary projection: pad the reduction dimension with zeros
+      float *wpad, *gpad;
+      RC(alloc(&wpad, (size_t)Np * n.K));
+      TCHK(hipMemsetAsync(wpad, 0, (size_t)Np * n.K * 4, s));
+      TCHK(launch_copy(w, wpad, (size_t)n.N * n.K, s));
+      TCHK(launch_transpose(wpad, wt, Np, n.K, s));
+      RC(alloc(&gpad, (size_t)y.rows * Np));
+      TCHK(launch_pad_cols(g, gpad, (size_t)y.rows, n.N, Np, s));
+      gp = gpad;
+    } else {
+      TCHK(launch_transpose(w, wt, n.N, n.K, s));
+    }
+    RC(alloc(&dx, (size_t)x.rows * x.cols));
+    RC(gemm_nt(gp, wt, nullptr, nullptr, dx, y.rows, n.K, Np, ACT_NONE));
+    return add_grad(n.in, dx);
+  }
+  int bwd_ln(const Node& n) {
+    const TT& y = st->t[n.out];
+    const TT& x = st->t[n.in];
+    const float* g;
+    RC(raw(n.gkey + ".weight", &g));
+    float *dg, *db;
+    RC(grad_buf(n.gkey + ".weight", &dg));
+    RC(grad_buf(n.gkey + ".bias", &db));
+    const int chunks = colreduce_chunks(x.rows);
+    RC(ensure_part((size_t)chunks * 2 * x.cols));
+    ColRedP p{};
+    p.a = y.grad; p.z = x.p; p.mean = n.mean; p.rstd = n.rstd; p.part = st->part; p.R = x.rows; p.C = x.cols; p.mode = CR_LN_BWD;
+    TCHK(launch_colreduce(p, s));
+    TCHK(launch_colreduce_final(st->part, chunks, x.cols, db, dg, 0, s));
+    float* dx;
+    RC(alloc(&dx, (size_t)x.rows * x.cols));
+    TCHK(launch_ln_bwd(y.grad, x.p, n.mean, n.rstd, g, nullptr, dx, (int)x.rows, x.cols, s));
+    return add_grad(n.in, dx);
+  }
+  int bwd_attn(const Node& n) {
+    RC(own_grad(n.in));
+    RC(own_grad(n.in2));
+    const TT& y = st->t[n.out];
+    AttnTrainP p{};
+    p.q = st->t[n.in].p + n.qoff; p.k = st->t[n.in2].p + n.koff; p.v = st->t[n.in2].p + n.voff;
+    p.o = y.grad; p.probs = n.probs;
+    p.dq = st->t[n.in].grad + n.qoff; p.dk = st->t[n.in2].grad + n.koff; p.dv = st->t[n.in2].grad + n.voff;
+    p.B = n.nb; p.heads = n.heads; p.hd = n.hd; p.Lq = n.Lq; p.Lk = n.Lk;
+    p.ldq = st->t[n.in].cols; p.ldk = p.ldv = st->t[n.in2].cols; p.ldo = n.heads * n.hd;
+    TCHK(launch_attn_train_bwd(p, s));
+    return D2T_OK;
+  }
+  int bwd_conv(const Node& n) {
+    const TT& y = st->t[n.out];
+    const long long P = y.rows;
+    const int Cout = n.N;
+    const float* dz = y.grad;
+    float *dW;
+    RC(grad_buf(n.wkey + ".weight", &dW));
+    if (!n.bnkey.empty()) {
+      const float* gamma;
+      RC(raw(n.bnkey + ".weight", &gamma));
+      float *dgam, *dbet, *s0, *s1, *dzb, *gres = nullptr;
+      RC(grad_buf(n.bnkey + ".weight", &dgam));
+      RC(grad_buf(n.bnkey + ".bias", &dbet));
+      const int chunks = colreduce_chunks(P);
+      RC(ensure_part((size_t)chunks * 2 * Cout));
+      ColRedP p{};
+      p.a = y.grad; p.y = n.relu ? y.p : nullptr; p.z = n.z; p.mean = n.mean; p.rstd = n.rstd; p.part = st->part;
+      p.R = P; p.C = Cout; p.mode = CR_BN_BWD;
+      TCHK(launch_colreduce(p, s));
+      TCHK(launch_colreduce_final(st->part, chunks, Cout, dbet, dgam, 0, s));
+      s0 = dbet; s1 = dgam;
+      RC(alloc(&dzb, (size_t)P * Cout));
+      if (n.in2 >= 0) RC(alloc(&gres, (size_t)P * Cout));
+      TCHK(launch_bn_bwd_apply(y.grad, n.relu ? y.p : nullptr, n.z, n.mean, n.rstd, gamma, s0, s1, dzb, gres, P, Cout, s));
+      if (n.in2 >= 0) RC(add_grad(n.in2, gres));
+      dz = dzb;
+    } else {
+      float* db;
+      RC(grad_buf(n.wkey + ".bias", &db));
+      RC(colsum(dz, P, Cout, db));
+    }
+    if (n.stem) {
+      const int chunk = 4096, nch = (int)((P + chunk - 1) / chunk);
+      RC(ensure_part((size_t)nch * 9 * Cout));
+      TCHK(launch_stem_wgrad(st->image, dz, st->part, st->B, st->H, st->W, Cout, chunk, nch, s));
+      TCHK(launch_wgrad_reduce(st->part, dW, nch, 9, Cout, 1, 1, 0, s));
+      return D2T_OK;
+    }
+    const TT& x = st->t[n.in];
+    RC(wgrad(dz, Cout, x.p, x.cols, P, Cout, x.cols, n.KH * n.KW, &n, &x, &y, dW, 1));
+    // data gradient: stride-1 convolution of the (zero-dilated) dz with the flipped, transposed filter
+    const float* w;
+    RC(raw(n.wkey + ".weight", &w));
+    const int Cin = x.cols, Kd = n.KH * n.KW * Cout;
+    float *wf, *wp, *dx;
+    RC(alloc(&wf, (size_t)Cin * Kd));
+    RC(alloc(&wp, (size_t)Cin * Kd + Cin));
+    TCHK(launch_flip_oihw(w, wf, Cout, Cin, n.KH, n.KW, s));                      // [Cin][Cout][KH][KW]
+    TCHK(launch_pack_conv(wf, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, wp, wp + (size_t)Cin * Kd, Cin, Cout, n.KH, n.KW, s));
+    const float* src = dz;
+    int DH = y.H, DW = y.W;
+    if (n.SH != 1 || n.SW != 1 || DH != x.H + 2 * n.PH - n.KH + 1 || DW != x.W + 2 * n.PW - n.KW + 1) {
+      DH = std::max(x.H + 2 * n.PH - n.KH + 1, (y.H - 1) * n.SH + 1);
+      DW = std::max(x.W + 2 * n.PW - n.KW + 1, (y.W - 1) * n.SW + 1);
+      float* dil;
+      RC(alloc(&dil, (size_t)x.B * DH * DW * Cout));
+      TCHK(launch_dilate(dz, dil, x.B, y.H, y.W, Cout, DH, DW, n.SH, n.SW, 0, 0, s));
+      src = dil;
+    }
+    RC(alloc(&dx, (size_t)x.rows * Cin));
+    ConvP p{};
+    p.in = src; p.w = wp; p.out = dx;
+    p.B = x.B; p.H = DH; p.W = DW; p.Cin = Cout; p.OH = x.H; p.OW = x.W; p.Cout = Cin;
+    p.KH = n.KH; p.KW = n.KW; p.SH = p.SW = 1; p.PH = n.KH - 1 - n.PH; p.PW = n.KW - 1 - n.PW;
+    p.M = (int)x.rows; p.K = Kd; p.act = ACT_NONE;
+    TCHK(launch_conv(p, s));
+    return add_grad(n.in, dx);
+  }
+  int bwd_pool(const Node& n) {
+    const TT& x = st->t[n.in];
+    float* dx;
+    RC(alloc(&dx, (size_t)x.rows * x.cols));
+    TCHK(launch_maxpool_bwd(x.p, st->t[n.out].grad, dx, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, s));
+    return add_grad(n.in, dx);
+  }
+  int bwd_tokens(const Node& n) {
+    const TT& y = st->t[n.out];
+    const TT& x = st->t[n.in];
+    const int D = y.cols, nb = (int)(y.rows / (n.ntok + 1));
+    float *dcls, *dx;
+    RC(grad_buf(n.wkey, &dcls));
+    TCHK(launch_sum_rows_strided(y.grad, dcls, nb, n.ntok + 1, 0, D, s));
+    RC(alloc(&dx, (size_t)x.rows * D));
+    TCHK(launch_token_rows(y.grad, dx, nb, n.ntok, 1, D, 0, s));
+    return add_grad(n.in, dx);
+  }
+  int backward() {
+    for (int i = (int)st->nodes.size() - 1; i >= 0; --i) {
+      const Node& n = st->nodes[i];
+      if (!st->t[n.out].grad) continue;
+      switch (n.kind) {
+        case N_LINEAR: RC(bwd_linear(n)); break;
+        case N_LN: RC(bwd_ln(n)); break;
+        case N_ATTN: RC(bwd_attn(n)); break;
+        case N_CONV: RC(bwd_conv(n)); break;
+        case N_POOL: RC(bwd_pool(n)); break;
+        case N_TOKENS: RC(bwd_tokens(n)); break;
+        case N_GELU: {
+          const TT& x = st->t[n.in];
+          float* dx;
+          RC(alloc(&dx, (size_t)x.rows * x.cols));
+          TCHK(launch_ew(st->t[n.out].grad, x.p, dx, (size_t)x.rows * x.cols, EW_GELU_BWD, s));
+          RC(add_grad(n.in, dx));
+          break;
+        }
+        case N_EMBED: {
+          float* dE;
+          RC(grad_buf(n.wkey, &dE));
+          const d2t_config& g = c->cfg;
+          TCHK(launch_embed_bwd(st->t[n.out].grad, st->tgt, dE, st->B * st->L, g.vocab, g.dec_dim, sqrtf((float)g.dec_dim), 0, s));
+          break;
+        }
+      }
+    }
+    return D2T_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, const int64_t* tgt, int32_t L,
+                      float* logits, d2t_stream stream) {
+  if (!c || !image || !tgt || !logits || B < 1 || H < 1 || W < 1 || L < 1) return fail(c, D2T_EINVAL, "bad argument");
+  const d2t_config& g = c->cfg;
+  if (g.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "the training step is implemented for the TFM head only");
+  if (g.encoder != D2T_ENC_HYBRID_VIT) return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT encoder only");
+  if (L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
+  if (!c->train) c->train = new d2t_train_state();
+  d2t_train_state* st = c->train;
+  st->tape.reset();
+  st->t.clear();
+  st->nodes.clear();
+  st->have_forward = false;
+  st->tgt = tgt; st->image = image; st->B = B; st->H = H; st->W = W; st->L = L;
+  Tr tr{c, st, (hipStream_t)stream};
+  int feat, mem, out;
+  const std::string sp = "seqmodeler.SequenceModeling.";
+  RC(tr.backbone(image, B, H, W, sp + "patch_embed.backbone.ConvNet.", &feat));
+  RC(tr.vit(feat, sp, &mem, nullptr));
+  RC(tr.decoder(mem, tgt, B, L, "predicter.Prediction.", logits, &out));
+  st->logits_id = out;
+  st->have_forward = true;
+  return D2T_OK;
+}
+
+int d2t_train_backward(d2t_ctx* c, const float* dlogits, d2t_stream stream) {
+  if (!c || !dlogits) return fail(c, D2T_EINVAL, "bad argument");
+  d2t_train_state* st = c->train;
+  if (!st || !st->have_forward) return fail(c, D2T_ESTATE, "d2t_train_backward without a preceding d2t_train_forward");
+  Tr tr{c, st, (hipStream_t)stream};
+  st->t[st->logits_id].grad = const_cast<float*>(dlogits);
+  st->have_forward = false;  // the tape is consumed (the attention probabilities are overwritten)
+  return tr.backward();
+}
+
+int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_stream stream) {
+  if (!c || !name || !dst) return fail(c, D2T_EINVAL, "bad argument");
+  d2t_train_state* st = c->train;
+  if (!st) return fail(c, D2T_ESTATE, "no training step has run");
+  auto it = st->grads.find(name);
+  if (it == st->grads.end()) return fail(c, D2T_ESTATE, "no gradient for '%s'", name);
+  const RawW* r = find(c, name);
+  if (!r || (int64_t)r->numel != numel) return fail(c, D2T_EINVAL, "gradient '%s': size mismatch", name);
+  HIPCHK(c, hipMemcpyAsync(dst, it->second, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return D2T_OK;
+}
+
+int d2t_read_weight(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_stream stream) {
+  if (!c || !name || !dst) return fail(c, D2T_EINVAL, "bad argument");
+  const RawW* r = find(c, name);
+  if (!r) return fail(c, D2T_ESTATE, "unknown tensor '%s'", name);
+  if ((int64_t)r->numel != numel) return fail(c, D2T_EINVAL, "tensor '%s': size mismatch", name);
+  HIPCHK(c, hipMemcpyAsync(dst, r->p, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return D2T_OK;
+}
+
+void d2t_train_release(d2t_ctx* c) {
+  if (c && c->train) {
+    hipDeviceSynchronize();
+    delete c->train;
+    c->train = nullptr;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,858 @@
+// Kernels of the training step (train.hip): everything module.train() + loss.backward() needs beyond the
+// forward GEMM/convolution kernel, all fp32.
+//
+//   wgrad_kernel        weight gradients of Conv2d / Linear: the "TN" GEMM  dW[co][tap][ci] = sum_p dz[p][co] * x[p+tap][ci]
+//                       on the fp32 MFMA, split over pixel chunks (deterministic two-pass reduction)
+//   colreduce_kernel    per-channel sums over rows: BatchNorm batch statistics, BatchNorm / LayerNorm parameter
+//                       gradients, bias gradients
+//   bn_*                BatchNorm2d in training mode (batch statistics, running-statistics update, backward)
+//   ln_*                LayerNorm forward with saved statistics, backward
+//   attn_*              softmax attention forward (saving the probabilities) and backward, causal / key-padding masks
+//   maxpool_bwd, relu/gelu backward, embedding backward, small data-movement helpers
+//
+// Reference semantics: torch autograd of feature_extractor/resnet.py:205-245, seq_modeling/vit/vision_transformer.py:26-122,
+// prediction_head/tfm.py:103-118 as driven by engine/training.py:76-164.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "conv_common.h"
+#include "kernels.h"
+
+namespace d2t {
+
+namespace {
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+constexpr int EW_THREADS = 256;
+inline int ew_grid(size_t n4) { return (int)std::min<size_t>((n4 + EW_THREADS - 1) / EW_THREADS, 65535u * 16u); }
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// wgrad: out[z][tap][m][n] = sum_{p in chunk z} A[p][m] * X[src(p, tap)][n]
+// Block tile BM x BN, 4 waves (2x2), K-step = 32 rows; both operand tiles are stored [k][col] in LDS exactly as
+// they lie in memory (rows = pixels, contiguous channels), and v_mfma_f32_32x32x2_f32 wants A[i][k] / B[k][j] with
+// i, j = lane & 31: consecutive lanes read consecutive floats of one LDS row -> conflict-free ds_read_b32.
+// ---------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradP p) {
+  constexpr int BK = 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NJ = WTN / 32;
+  constexpr int AV = BM / 4, BV = BN / 4;               // float4 per tile row
+  constexpr int ALD = (BK * AV) / 256, BLD = (BK * BV) / 256;  // float4 loads per thread per stage
+  static_assert(ALD >= 1 && BLD >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int tap = blockIdx.y, kh = tap / p.KW, kw = tap % p.KW;
+  const int z = blockIdx.z;
+  const long long r_begin = (long long)z * p.chunk;
+  const long long r_end = r_begin + p.chunk < p.P ? r_begin + p.chunk : p.P;
+  const int ohow = p.OH * p.OW;
+
+  float4 ra[ALD], rb[BLD];
+  auto fetch = [&](long long r0) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      const int idx = tid + i * 256, row = idx / AV, c4 = (idx % AV) * 4;
+      const long long r = r0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r_end && m0 + c4 < p.M) v = *reinterpret_cast<const float4*>(p.a + r * p.lda + m0 + c4);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) {
+      const int idx = tid + i * 256, row = idx / BV, c4 = (idx % BV) * 4;
+      const long long r = r0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r_end && n0 + c4 < p.N) {
+        long long src = r;
+        bool ok = true;
+        if (p.geom) {
+          const int b = (int)(r / ohow), rem = (int)(r - (long long)b * ohow);
+          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+          const int ih = oh * p.SH - p.PH + kh, iw = ow * p.SW - p.PW + kw;
+          ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          src = ((long long)b * p.H + ih) * p.W + iw;
+        }
+        if (ok) v = *reinterpret_cast<const float4*>(p.b + src * p.ldb + n0 + c4);
+      }
+      rb[i] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      const int idx = tid + i * 256, row = idx / AV, c4 = (idx % AV) * 4;
+      *reinterpret_cast<float4*>(&As[buf][row][c4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) {
+      const int idx = tid + i * 256, row = idx / BV, c4 = (idx % BV) * 4;
+      *reinterpret_cast<float4*>(&Bs[buf][row][c4]) = rb[i];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int steps = (int)((r_end - r_begin + BK - 1) / BK);
+  if (steps > 0) {
+    fetch(r_begin);
+    stash(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < steps) fetch(r_begin + (long long)(st + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float fa[MI], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = As[cur][2 * kk + h][wm * WTM + i * 32 + r];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = Bs[cur][2 * kk + h][wn * WTN + j * 32 + r];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < steps) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float* out = p.part + ((size_t)z * p.taps + tap) * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (m < p.M) out[(size_t)m * p.N + n] = acc[i][j][reg];
+      }
+    }
+}
+
+hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.P <= 0) return hipSuccess;
+  if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
+  if (p.M <= 64 || p.N <= 64) {
+    dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.taps, p.S);
+    hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(((p.M + 127) / 128) * ((p.N + 127) / 128), p.taps, p.S);
+    hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+// dst = (accumulate ? dst : 0) + sum_z part[z][tap][m][n];  layout 0: dst[m][n] (taps == 1);  layout 1: OIHW dst[m][n][tap]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int S, int taps, int M, int N,
+                                    int layout, int accumulate) {
+  const size_t total = (size_t)taps * M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += part[(size_t)z * total + i];
+    const int n = (int)(i % N), m = (int)((i / N) % M), tap = (int)(i / ((size_t)M * N));
+    const size_t o = layout == 1 ? ((size_t)m * N + n) * taps + tap : (size_t)m * N + n;
+    dst[o] = accumulate ? dst[o] + v : v;
+  }
+}
+hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
+                               hipStream_t s) {
+  const size_t total = (size_t)taps * M * N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, part,
+                     dst, S, taps, M, N, layout, accumulate);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Column reductions over the rows of row-major [R][C] matrices -> part[chunk][2][C]
+// ---------------------------------------------------------------------------
+constexpr int CR_ROWS = 2048;  // rows per block
+__global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p) {
+  __shared__ float red[16][2][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  const long long r0 = (long long)blockIdx.y * CR_ROWS;
+  const long long r1 = r0 + CR_ROWS < p.R ? r0 + CR_ROWS : p.R;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < p.C) {
+    float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+    if (p.mode == CR_BN_BWD) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mu[k] = p.mean[c + k]; rs[k] = p.rstd[c + k]; }
+    }
+    for (long long r = r0 + ty; r < r1; r += 16) {
+      const size_t off = (size_t)r * p.C + c;
+      const float4 a4 = *reinterpret_cast<const float4*>(p.a + off);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (p.mode == CR_SUM) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s0[k] += a[k];
+      } else if (p.mode == CR_SUM_SQ) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += a[k]; s1[k] = fmaf(a[k], a[k], s1[k]); }
+      } else if (p.mode == CR_BN_BWD) {  // a = dy, y = post-activation output (nullable), z = pre-BN conv output
+        const float4 z4 = *reinterpret_cast<const float4*>(p.z + off);
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+        float g[4] = {a[0], a[1], a[2], a[3]};
+        if (p.y) {
+          const float4 y4 = *reinterpret_cast<const float4*>(p.y + off);
+          const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += g[k]; s1[k] = fmaf(g[k], (z[k] - mu[k]) * rs[k], s1[k]); }
+      } else {  // CR_LN_BWD: a = dy, z = LayerNorm input, mean / rstd per ROW
+        const float4 z4 = *reinterpret_cast<const float4*>(p.z + off);
+        const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+        const float m = p.mean[r], q = p.rstd[r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += a[k]; s1[k] = fmaf(a[k], (z[k] - m) * q, s1[k]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[ty][0][tx * 4 + k] = s0[k]; red[ty][1][tx * 4 + k] = s1[k]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v += red[t][which][col];
+    const int cc = blockIdx.x * 64 + col;
+    if (cc < p.C) p.part[((size_t)blockIdx.y * 2 + which) * p.C + cc] = v;
+  }
+}
+int colreduce_chunks(long long R) { return (int)((R + CR_ROWS - 1) / CR_ROWS); }
+hipError_t launch_colreduce(const ColRedP& p, hipStream_t s) {
+  if (p.C % 4 || p.R <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((p.C + 63) / 64, colreduce_chunks(p.R)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+// out0[c] = (acc ? out0[c] : 0) + sum_chunks part[.][0][c];  out1 likewise (nullable)
+__global__ void colreduce_final_kernel(const float* __restrict__ part, int chunks, int C, float* out0, float* out1,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < chunks; ++k) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+  if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)a;
+  if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)b;
+}
+hipError_t launch_colreduce_final(const float* part, int chunks, int C, float* out0, float* out1, int accumulate,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, chunks, C, out0, out1, accumulate);
+  return hipGetLastError();
+}
+// BatchNorm batch statistics from (sum, sum of squares) partials; running statistics updated in place
+// (momentum 0.1, unbiased variance: nn.BatchNorm2d defaults used by resnet.py).
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, int C, long long R, float eps, float momentum,
+                                   float* mean, float* rstd, float* run_mean, float* run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < chunks; ++k) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+  const double m = a / (double)R;
+  double var = b / (double)R - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+    run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+  }
+}
+hipError_t launch_bn_finalize(const float* part, int chunks, int C, long long R, float eps, float momentum, float* mean,
+                              float* rstd, float* run_mean, float* run_var, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, chunks, C, R, eps, momentum, mean,
+                     rstd, run_mean, run_var);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm apply (train forward) and backward apply, float4 over [R][C]
+// ---------------------------------------------------------------------------
+__global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ res,
+                                float* __restrict__ y, size_t n4, int C, int relu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    float o[4] = {v.x, v.y, v.z, v.w};
+    float r4[4] = {0, 0, 0, 0};
+    if (res) { const float4 t = reinterpret_cast<const float4*>(res)[i]; r4[0] = t.x; r4[1] = t.y; r4[2] = t.z; r4[3] = t.w; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = (o[k] - mean[c + k]) * rstd[c + k] * g[c + k] + b[c + k] + r4[k];
+      o[k] = relu ? fmaxf(t, 0.f) : t;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+hipError_t launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* g, const float* b,
+                           const float* res, float* y, long long R, int C, int relu, hipStream_t s) {
+  const size_t n4 = (size_t)R * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, z, mean, rstd, g, b, res, y, n4, C, relu);
+  return hipGetLastError();
+}
+// dz = gamma*rstd * (g - s0/R - xhat * s1/R),  g = dy * (y > 0) (y nullable = no ReLU);  gout (nullable) receives g
+// (the gradient of the residual branch that was added before the ReLU).
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ s0,
+                                    const float* __restrict__ s1, float invR, float* __restrict__ dz,
+                                    float* __restrict__ gout, size_t n4, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 d4 = reinterpret_cast<const float4*>(dy)[i];
+    const float4 z4 = reinterpret_cast<const float4*>(z)[i];
+    float g[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    if (y) {
+      const float4 y4 = reinterpret_cast<const float4*>(y)[i];
+      const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (zz[k] - mean[c + k]) * rstd[c + k];
+      o[k] = gamma[c + k] * rstd[c + k] * (g[k] - s0[c + k] * invR - xh * s1[c + k] * invR);
+    }
+    reinterpret_cast<float4*>(dz)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
+                               const float* gamma, const float* s0, const float* s1, float* dz, float* gout, long long R,
+                               int C, hipStream_t s) {
+  const size_t n4 = (size_t)R * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, dy, y, z, mean, rstd, gamma, s0, s1,
+                     1.f / (float)R, dz, gout, n4, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise: out = f(a, b)
+// ---------------------------------------------------------------------------
+__global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n4,
+                          int op) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x4 = reinterpret_cast<const float4*>(a)[i];
+    float x[4] = {x4.x, x4.y, x4.z, x4.w}, y[4] = {0, 0, 0, 0}, o[4];
+    if (b) { const float4 y4 = reinterpret_cast<const float4*>(b)[i]; y[0] = y4.x; y[1] = y4.y; y[2] = y4.z; y[3] = y4.w; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      switch (op) {
+        case EW_ADD: o[k] = x[k] + y[k]; break;
+        case EW_RELU_BWD: o[k] = y[k] > 0.f ? x[k] : 0.f; break;  // a = dy, b = forward output
+        case EW_GELU: o[k] = 0.5f * x[k] * (1.f + erff(x[k] * 0.70710678118654752440f)); break;
+        case EW_GELU_BWD: {  // a = dy, b = pre-activation u: d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+          const float u = y[k];
+          const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752440f));
+          const float pdf = 0.3989422804014327f * expf(-0.5f * u * u);
+          o[k] = x[k] * (cdf + u * pdf);
+          break;
+        }
+        default: o[k] = x[k];
+      }
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int op, hipStream_t s) {
+  if (n % 4) return hipErrorInvalidValue;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(ew_kernel, dim3(ew_grid(n / 4)), dim3(EW_THREADS), 0, s, a, b, out, n / 4, op);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool2d(k=2) backward, gather form (deterministic): every input pixel collects dy of the windows whose
+// FIRST maximum (scan order kh, kw; padding = -inf) it is -- the rule of torch's max_pool2d_with_indices.
+// ---------------------------------------------------------------------------
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                   int H, int W, int C, int OH, int OW, int SH, int SW, int PH, int PW) {
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W), h = (int)((i / ((size_t)C * W)) % H), b = (int)(i / ((size_t)C * W * H));
+    float acc = 0.f;
+    // windows (oh, ow) that contain (h, w): oh*SH - PH <= h <= oh*SH - PH + 1
+    const int oh_lo = h + PH - 1 > 0 ? (h + PH - 1 + SH - 1) / SH : 0, oh_hi = min((h + PH) / SH, OH - 1);
+    const int ow_lo = w + PW - 1 > 0 ? (w + PW - 1 + SW - 1) / SW : 0, ow_hi = min((w + PW) / SW, OW - 1);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        float best = -INFINITY;
+        int bh = -1, bw = -1;
+        for (int kh = 0; kh < 2; ++kh)
+          for (int kw = 0; kw < 2; ++kw) {
+            const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
+            if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+            const float v = x[(((size_t)b * H + ih) * W + iw) * C + c];
+            if (v > best || bh < 0) { best = v; bh = ih; bw = iw; }
+          }
+        if (bh == h && bw == w) acc += dy[(((size_t)b * OH + oh) * OW + ow) * C + c];
+      }
+    dx[i] = acc;
+  }
+}
+hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
+                              int PW, hipStream_t s) {
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+  const size_t total = (size_t)B * H * W * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, x,
+                     dy, dx, B, H, W, C, OH, OW, SH, SW, PH, PW);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm with saved statistics / backward.  One wave per row, D = 256 or 512.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void ln_train_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                       float eps) {
+  constexpr int PER = D / 64;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[PER], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { v[k] = x[(size_t)row * D + lane + 64 * k]; s += v[k]; }
+  const float m = wsum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) q = fmaf(v[k] - m, v[k] - m, q);
+  const float r = rsqrtf(wsum(q) / D + eps);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = lane + 64 * k;
+    y[(size_t)row * D + c] = (v[k] - m) * r * g[c] + b[c];
+  }
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+hipError_t launch_ln_train(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
+                           int D, float eps, hipStream_t s) {
+  if (D == 256) hipLaunchKernelGGL(ln_train_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
+  else if (D == 512) hipLaunchKernelGGL(ln_train_kernel<512>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+// dx = rstd * (dyg - mean_c(dyg) - xhat * mean_c(dyg * xhat)) (+ add),  dyg = dy * gamma
+template <int D>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ g, const float* __restrict__ add,
+                                                     float* __restrict__ dx, int rows) {
+  constexpr int PER = D / 64;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float m = mean[row], r = rstd[row];
+  float dg[PER], xh[PER], a = 0.f, bsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = lane + 64 * k;
+    dg[k] = dy[(size_t)row * D + c] * g[c];
+    xh[k] = (x[(size_t)row * D + c] - m) * r;
+    a += dg[k];
+    bsum = fmaf(dg[k], xh[k], bsum);
+  }
+  a = wsum(a) / D;
+  bsum = wsum(bsum) / D;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = lane + 64 * k;
+    float o = r * (dg[k] - a - xh[k] * bsum);
+    if (add) o += add[(size_t)row * D + c];
+    dx[(size_t)row * D + c] = o;
+  }
+}
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
+                         const float* add, float* dx, int rows, int D, hipStream_t s) {
+  if (D == 256) hipLaunchKernelGGL(ln_bwd_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
+  else if (D == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Attention with saved probabilities.  q/k/v/o are addressed as  base + (b*L + i)*ld + head*HD ; one block per
+// (batch, head); K and V of the head live in LDS.  mask: causal (key j <= query i) and/or key padding
+// (keytok[b][j] == pad_id masked) -- nn.MultiheadAttention's additive -inf masks (tfm.py:74-91).
+// probs [B][heads][Lq][Lk] is written for the backward pass.
+// ---------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_train_fwd_kernel(const AttnTrainP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;                          // [Lk][HD+1]
+  float* Vs = Ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD]
+  float* Ps = Vs + (size_t)p.Lk * HD;        // [4 waves][Lk]
+  const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < p.Lk * HD; i += 256) {
+    const int j = i / HD, c = i % HD;
+    Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
+    Vs[j * HD + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  float* P = Ps + (size_t)wave * p.Lk;
+  for (int i = wave; i < p.Lq; i += 4) {
+    const float* qp = p.q + ((size_t)b * p.Lq + i) * p.ldq + hh * HD;
+    float q[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) q[c] = qp[c];
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Lk; j += 64) {
+      bool ok = !(p.causal && j > i);
+      if (ok && p.keytok) ok = p.keytok[(size_t)b * p.Lk + j] != p.pad_id;
+      float a = -INFINITY;
+      if (ok) {
+        a = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) a = fmaf(q[c], Ks[j * (HD + 1) + c], a);
+        a *= scale;
+      }
+      P[j] = a;
+      mx = fmaxf(mx, a);
+    }
+    mx = wmax(mx);
+    float sum = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) {
+      const float e = P[j] == -INFINITY ? 0.f : expf(P[j] - mx);
+      P[j] = e;
+      sum += e;
+    }
+    sum = wsum(sum);
+    const float inv = 1.f / sum;
+    float* prow = p.probs + (((size_t)b * p.heads + hh) * p.Lq + i) * p.Lk;
+    for (int j = lane; j < p.Lk; j += 64) {
+      const float w = P[j] * inv;
+      P[j] = w;
+      prow[j] = w;
+    }
+    // o[c] = sum_j P[j] * V[j][c]: lane -> (c = lane % HD, key phase = lane / HD)
+    constexpr int PH = 64 / HD;
+    const int c = lane % HD, ph = lane / HD;
+    float o = 0.f;
+    for (int j = ph; j < p.Lk; j += PH) o = fmaf(P[j], Vs[j * HD + c], o);
+    if (PH == 2) o += __shfl_xor(o, 32, 64);
+    if (lane < HD) p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c] = o;
+  }
+}
+static hipError_t attn_lds(const void* fn, size_t lds) {
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s) {
+  const size_t lds = ((size_t)p.Lk * (p.hd + 1) + (size_t)p.Lk * p.hd + 4 * (size_t)p.Lk) * 4;
+  hipError_t e;
+  if (p.hd == 32) {
+    if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<32>), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_train_fwd_kernel<32>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+  } else if (p.hd == 64) {
+    if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<64>), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_train_fwd_kernel<64>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// Backward: dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(dP * P));  dQ = scale * dS K;  dK = scale * dS^T Q.
+// One block per (batch, head); dS overwrites the saved probabilities in place (phase 2), phases separated by
+// block barriers.  p.o carries dO; p.dq / p.dk / p.dv use the q / k / v strides.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;                            // [Lk][HD+1]
+  float* Vs = Ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD+1]
+  float* Ds = Vs + (size_t)p.Lk * (HD + 1);  // [4 waves][Lk]: the dS row a wave is working on
+  const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < p.Lk * HD; i += 256) {
+    const int j = i / HD, c = i % HD;
+    Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
+    Vs[j * (HD + 1) + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+  }
+  float* probs = p.probs + ((size_t)b * p.heads + hh) * p.Lq * p.Lk;
+  constexpr int PH = 64 / HD;
+  const int c = lane % HD, ph = lane / HD;
+  // phase 1: dV[j][c] = sum_i P[i][j] * dO[i][c]   (wave per key)
+  for (int j = wave; j < p.Lk; j += 4) {
+    float a = 0.f;
+    for (int i = ph; i < p.Lq; i += PH) a = fmaf(probs[(size_t)i * p.Lk + j], p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c], a);
+    if (PH == 2) a += __shfl_xor(a, 32, 64);
+    if (lane < HD) p.dv[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c] = a;
+  }
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  // phase 2: per query row: dS, dQ (wave per query)
+  for (int i = wave; i < p.Lq; i += 4) {
+    const float* dop = p.o + ((size_t)b * p.Lq + i) * p.ldo + hh * HD;
+    float d_o[HD];
+#pragma unroll
+    for (int cc = 0; cc < HD; ++cc) d_o[cc] = dop[cc];
+    float* prow = probs + (size_t)i * p.Lk;
+    float dsum = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float dp = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      dsum = fmaf(dp, prow[j], dsum);
+    }
+    dsum = wsum(dsum);
+    for (int j = lane; j < p.Lk; j += 64) {
+      float dp = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      const float ds = prow[j] * (dp - dsum);
+      prow[j] = ds;  // read again by phase 3 (after the block barrier)
+      Ds[wave * p.Lk + j] = ds;
+    }
+    float a = 0.f;
+    for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[j * (HD + 1) + c], a);
+    if (PH == 2) a += __shfl_xor(a, 32, 64);
+    if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
+  }
+  __syncthreads();
+  // phase 3: dK[j][c] = scale * sum_i dS[i][j] * Q[i][c]   (wave per key)
+  for (int j = wave; j < p.Lk; j += 4) {
+    float a = 0.f;
+    for (int i = ph; i < p.Lq; i += PH) a = fmaf(probs[(size_t)i * p.Lk + j], p.q[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c], a);
+    if (PH == 2) a += __shfl_xor(a, 32, 64);
+    if (lane < HD) p.dk[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c] = a * scale;
+  }
+}
+hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s) {
+  const size_t lds = ((size_t)2 * p.Lk * (p.hd + 1) + 4 * (size_t)p.Lk) * 4;
+  hipError_t e;
+  if (p.hd == 32) {
+    if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<32>), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_train_bwd_kernel<32>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+  } else if (p.hd == 64) {
+    if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<64>), lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_train_bwd_kernel<64>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Embedding: x[r][:] = E[tok[r]][:] * scale + pe[r % L][:];  backward (deterministic, block per vocabulary row):
+// dE[v][:] = scale * sum_{r: tok[r] == v} dx[r][:], zero for the padding row (nn.Embedding padding_idx).
+// ---------------------------------------------------------------------------
+__global__ void embed_train_kernel(const float* __restrict__ E, const float* __restrict__ pe, const int64_t* __restrict__ tok,
+                                   float* __restrict__ x, int rows, int L, int D, float scale) {
+  const int r = blockIdx.x;
+  const int64_t t = tok[r];
+  for (int c = threadIdx.x; c < D; c += blockDim.x) x[(size_t)r * D + c] = E[(size_t)t * D + c] * scale + pe[(size_t)(r % L) * D + c];
+}
+hipError_t launch_embed_train(const float* E, const float* pe, const int64_t* tok, float* x, int rows, int L, int D,
+                              float scale, hipStream_t s) {
+  hipLaunchKernelGGL(embed_train_kernel, dim3(rows), dim3(256), 0, s, E, pe, tok, x, rows, L, D, scale);
+  return hipGetLastError();
+}
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok, float* __restrict__ dE,
+                                 int rows, int D, float scale, int pad_id) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float a = 0.f;
+    if (v != pad_id)
+      for (int r = 0; r < rows; ++r)
+        if (tok[r] == v) a += dx[(size_t)r * D + c];
+    dE[(size_t)v * D + c] = a * scale;
+  }
+}
+hipError_t launch_embed_bwd(const float* dx, const int64_t* tok, float* dE, int rows, int V, int D, float scale, int pad_id,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, s, dx, tok, dE, rows, D, scale, pad_id);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Data movement
+// ---------------------------------------------------------------------------
+// dst[r][0..Cd) = src[r][0..Cs) zero-padded on the right (Cd >= Cs)
+__global__ void pad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int Cs, int Cd) {
+  const size_t total = rows * Cd;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cd);
+    const size_t r = i / Cd;
+    dst[i] = c < Cs ? src[r * Cs + c] : 0.f;
+  }
+}
+hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s) {
+  const size_t total = rows * Cd;
+  hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, dst,
+                     rows, Cs, Cd);
+  return hipGetLastError();
+}
+// Zero-dilated, zero-padded copy of an NHWC map: dst[b][oh*SH + OFFH][ow*SW + OFFW][c] = src[b][oh][ow][c], rest 0.
+// (input of the stride-1 convolution that evaluates the data gradient of a strided convolution)
+__global__ void dilate_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int OH, int OW, int C, int DH,
+                              int DW, int SH, int SW, int offh, int offw) {
+  const size_t total = (size_t)B * DH * DW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % DW), h = (int)((i / ((size_t)C * DW)) % DH), b = (int)(i / ((size_t)C * DW * DH));
+    const int hh = h - offh, ww = w - offw;
+    float v = 0.f;
+    if (hh >= 0 && ww >= 0 && hh % SH == 0 && ww % SW == 0 && hh / SH < OH && ww / SW < OW)
+      v = src[(((size_t)b * OH + hh / SH) * OW + ww / SW) * C + c];
+    dst[i] = v;
+  }
+}
+hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
+                         int offw, hipStream_t s) {
+  const size_t total = (size_t)B * DH * DW * C;
+  hipLaunchKernelGGL(dilate_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, dst, B,
+                     OH, OW, C, DH, DW, SH, SW, offh, offw);
+  return hipGetLastError();
+}
+// Weights of the data-gradient convolution: out[ci][co][kh][kw] = w[co][ci][KH-1-kh][KW-1-kw]  (OIHW -> flipped IOHW)
+__global__ void flip_oihw_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW) {
+  const size_t total = (size_t)Cout * Cin * KH * KW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kw = (int)(i % KW), kh = (int)((i / KW) % KH), co = (int)((i / ((size_t)KW * KH)) % Cout);
+    const int ci = (int)(i / ((size_t)KW * KH * Cout));
+    out[i] = w[(((size_t)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+  }
+}
+hipError_t launch_flip_oihw(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s) {
+  const size_t total = (size_t)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(flip_oihw_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, out, Cout,
+                     Cin, KH, KW);
+  return hipGetLastError();
+}
+// rows gather / scatter between a [B][n+skip] token layout and the compact [B][n] one:
+// dst[b*n + i][:] = src[(b*(n+skip) + skip + i)][:]  (gather)  or the inverse with zero skip rows (scatter)
+__global__ void token_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int n, int skip, int D,
+                                  int scatter) {
+  const size_t total = (size_t)B * (scatter ? n + skip : n) * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const size_t row = i / D;
+    if (!scatter) {
+      const size_t b = row / n, t = row % n;
+      dst[i] = src[((b * (n + skip)) + skip + t) * D + c];
+    } else {
+      const size_t b = row / (n + skip), t = row % (n + skip);
+      dst[i] = t < (size_t)skip ? 0.f : src[(b * n + (t - skip)) * D + c];
+    }
+  }
+}
+hipError_t launch_token_rows(const float* src, float* dst, int B, int n, int skip, int D, int scatter, hipStream_t s) {
+  const size_t total = (size_t)B * (scatter ? n + skip : n) * D;
+  hipLaunchKernelGGL(token_rows_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src,
+                     dst, B, n, skip, D, scatter);
+  return hipGetLastError();
+}
+// out[c] = sum_b x[(b*stride_rows + row) * D + c]   (cls-token gradient)
+__global__ void sum_rows_strided_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long long stride_rows,
+                                        int row, int D) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += x[((size_t)b * stride_rows + row) * D + c];
+  out[c] = a;
+}
+hipError_t launch_sum_rows_strided(const float* x, float* out, int B, long long stride_rows, int row, int D, hipStream_t s) {
+  hipLaunchKernelGGL(sum_rows_strided_kernel, dim3((D + 127) / 128), dim3(128), 0, s, x, out, B, stride_rows, row, D);
+  return hipGetLastError();
+}
+
+// Stem convolution (Cin = 1, 3x3, pad 1) in training mode: raw weights, no bias / BN (z = conv(x)); and its
+// weight gradient dW[co][kh][kw] = sum_p dz[p][co] * x[p + tap]  (block per (co-group), deterministic).
+__global__ void stem_raw_kernel(const float* __restrict__ img, const float* __restrict__ w, float* __restrict__ z, int B,
+                                int H, int W, int Cout) {
+  const size_t total = (size_t)B * H * W * Cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int x = (int)((i / Cout) % W), y = (int)((i / ((size_t)Cout * W)) % H), b = (int)(i / ((size_t)Cout * W * H));
+    float a = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = y + kh - 1, iw = x + kw - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+          a = fmaf(img[((size_t)b * H + ih) * W + iw], w[co * 9 + kh * 3 + kw], a);
+      }
+    z[i] = a;
+  }
+}
+hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, int H, int W, int Cout, hipStream_t s) {
+  const size_t total = (size_t)B * H * W * Cout;
+  hipLaunchKernelGGL(stem_raw_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, img, w, z,
+                     B, H, W, Cout);
+  return hipGetLastError();
+}
+// part[chunk][tap][co]: chunked over pixels; reduced by launch_wgrad_reduce with M = Cout, N = 1 ... (taps = 9)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ dz,
+                                                         float* __restrict__ part, int B, int H, int W, int Cout,
+                                                         int chunk) {
+  // thread -> (co = tid % Cout, pixel lane = tid / Cout); Cout == 32 -> 8 pixel lanes
+  __shared__ float red[8][9][32];
+  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const long long P = (long long)B * H * W;
+  const long long r0 = (long long)blockIdx.x * chunk, r1 = r0 + chunk < P ? r0 + chunk : P;
+  float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long r = r0 + pl; r < r1; r += 8) {
+    const int x = (int)(r % W), y = (int)((r / W) % H);
+    const long long b = r / ((long long)W * H);
+    const float g = dz[(size_t)r * Cout + co];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = y + kh - 1, iw = x + kw - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+          acc[kh * 3 + kw] = fmaf(g, img[((size_t)b * H + ih) * W + iw], acc[kh * 3 + kw]);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[pl][t][co] = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * 32; i += 256) {
+    const int t = i / 32, c = i % 32;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][t][c];
+    part[((size_t)blockIdx.x * 9 + t) * Cout + c] = v;  // [chunk][tap][co] == wgrad partial layout with M = Cout, N = 1
+  }
+}
+hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int B, int H, int W, int Cout, int chunk,
+                             int nchunks, hipStream_t s) {
+  if (Cout != 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, Cout, chunk);
+  return hipGetLastError();
+}
+
+}  // namespace d2t

@@ -108,8 +108,9 @@ class Engine:
         _lib.check(rc, self.ctx, what)
 
     # ---- weights ---------------------------------------------------------
-    def sync_weights(self, module):
-        """Upload + pack the module's state if any tensor changed since last time."""
+    def sync_weights(self, module, finalize=True):
+        """Upload the module's state if any tensor changed since last time; finalize=True also folds / packs it
+        for inference (the training step reads the raw copies and skips that)."""
         items = []
         for name, t in list(module.named_parameters()) + list(module.named_buffers()):
             if not t.is_floating_point() or name.endswith("image_positional_encoder.pe"):
@@ -117,6 +118,9 @@ class Engine:
             items.append((name, t))
         sig = tuple((n, t.data_ptr(), t._version, tuple(t.shape)) for n, t in items)
         if sig == self._sig:
+            if finalize and getattr(self, "_fin_sig", None) != sig:
+                self._check(self.lib.d2t_finalize_weights(self.ctx, _lib.stream_of(items[0][1])), "finalize_weights")
+                self._fin_sig = sig
             return
         stream = None
         for name, t in items:
@@ -129,8 +133,43 @@ class Engine:
             shape = (C.c_int64 * td.dim())(*td.shape)
             self._check(self.lib.d2t_load_weight(self.ctx, name.encode(), _lib.ptr(td), shape, td.dim(), stream),
                         f"load_weight({name})")
-        self._check(self.lib.d2t_finalize_weights(self.ctx, stream), "finalize_weights")
+        self._fin_sig = None
+        if finalize:
+            self._check(self.lib.d2t_finalize_weights(self.ctx, stream), "finalize_weights")
+            self._fin_sig = sig
         self._sig = sig
+
+    # ---- training step -------------------------------------------------------
+    def train_forward(self, image, tgt):
+        """Model.forward under module.train(): logits [B,L,V] of the teacher-forced pass (BatchNorm on batch
+        statistics; the engine's running statistics are updated, see read_weight)."""
+        if not image.is_cuda:
+            raise RuntimeError("doc2tex_amd: input must be a ROCm (cuda) tensor; the engine has no CPU path")
+        image = image.float().contiguous()
+        tgt = tgt.to(torch.int64).contiguous()
+        B, _, H, W = image.shape
+        L = tgt.shape[1]
+        logits = torch.empty((B, L, self.cfg.vocab), dtype=torch.float32, device=image.device)
+        self._train_keep = (image, tgt)  # the backward pass reads them
+        self._check(self.lib.d2t_train_forward(self.ctx, _lib.ptr(image), B, H, W, _lib.ptr(tgt), L, _lib.ptr(logits),
+                                               _lib.stream_of(image)), "train_forward")
+        return logits
+
+    def train_backward(self, dlogits):
+        dlogits = dlogits.float().contiguous()
+        self._check(self.lib.d2t_train_backward(self.ctx, _lib.ptr(dlogits), _lib.stream_of(dlogits)), "train_backward")
+        self._train_keep = None
+
+    def train_grad(self, name, like):
+        g = torch.empty_like(like, dtype=torch.float32, memory_format=torch.contiguous_format)
+        self._check(self.lib.d2t_train_grad(self.ctx, name.encode(), _lib.ptr(g), g.numel(), _lib.stream_of(g)),
+                    f"train_grad({name})")
+        return g
+
+    def read_weight(self, name, dst):
+        """Copy the engine's current copy of a loaded tensor into `dst` (fp32, contiguous, same size)."""
+        self._check(self.lib.d2t_read_weight(self.ctx, name.encode(), _lib.ptr(dst), dst.numel(), _lib.stream_of(dst)),
+                    f"read_weight({name})")
 
     # ---- encoder -----------------------------------------------------------
     def encoder_shape(self, H, W):

@@ -1,0 +1,40 @@
+"""Training-mode forward/backward of `Model` as one autograd node.
+
+The reference trains through PyTorch autograd (`loss.backward()`, engine/training.py:137) on the logits that
+`model(image, text[:, :-1])` returns (`forward_step`, training.py:76-91).  Here the whole network is one
+`torch.autograd.Function`: forward = `d2t_train_forward` (BatchNorm on batch statistics, teacher-forced decoder),
+backward = `d2t_train_backward` on dL/dlogits, after which every parameter's gradient is copied out of the engine.
+The caller's criterion, `clip_grad_norm_` and optimizer (torch.optim, out of scope per SURVEY section 2) run unchanged.
+"""
+import torch
+
+
+class _TrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, image, text, names, *params):
+        eng = model.engine(finalize=False)
+        logits = eng.train_forward(image, text)
+        # BatchNorm side effects of module.train(): running statistics and the batch counter
+        with torch.no_grad():
+            for name, buf in model.named_buffers():
+                if name.endswith(("running_mean", "running_var")):
+                    eng.read_weight(name, buf)
+                elif name.endswith("num_batches_tracked"):
+                    buf += 1
+        eng._sig = None  # the buffers above changed: re-upload before the next eval forward
+        ctx.model, ctx.names, ctx.params = model, names, params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.model._engine
+        eng.train_backward(dlogits)
+        grads = tuple(eng.train_grad(n, p) if p.requires_grad else None for n, p in zip(ctx.names, ctx.params))
+        return (None, None, None, None) + grads
+
+
+def train_forward(model, image, text):
+    """logits [B, L, V] with autograd history reaching every trainable parameter of `model`."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    names = tuple(n for n, _ in named)
+    return _TrainStep.apply(model, image, text, names, *[p for _, p in named])

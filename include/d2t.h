@@ -183,6 +183,23 @@ int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
  * run side by side (the loop is a dependent chain of small kernels that cannot fill the chip alone). */
 int d2t_set_decode_chains(d2t_ctx* ctx, int32_t chains);
 
+/* ---- training step (engine/training.py:76-164) ----------
+ * d2t_train_forward runs Model.forward under module.train() for the HybridViT + TFM stack: BatchNorm on batch
+ * statistics (the engine's copies of running_mean / running_var are updated with momentum 0.1; read them back
+ * with d2t_read_weight), teacher-forced decoder pass over tgt [B][L] (= text[:, :-1]; PAD = 0 keys masked,
+ * causal), dropout 0.  logits [B][L][vocab] is caller memory.  Weights are the ones last given to
+ * d2t_load_weight (no finalize needed).  d2t_train_backward takes dL/dlogits [B][L][vocab] and leaves the
+ * gradient of every trainable parameter in engine memory; d2t_train_grad copies one out by its state_dict key.
+ * One forward may be followed by at most one backward.  All pointers are device pointers. */
+int d2t_train_forward(d2t_ctx* ctx, const float* image, int32_t B, int32_t H, int32_t W, const int64_t* tgt, int32_t L,
+                      float* logits, d2t_stream stream);
+int d2t_train_backward(d2t_ctx* ctx, const float* dlogits, d2t_stream stream);
+int d2t_train_grad(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
+/* copy the engine's current copy of a loaded tensor (e.g. BatchNorm running statistics after a training forward) */
+int d2t_read_weight(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
+/* free the training tape, gradient buffers and workspace */
+void d2t_train_release(d2t_ctx* ctx);
+
 /* ---- in-engine kernel timing (bench.py roofline leg) ------------------------
  * While enabled, d2t_encode brackets every implicit-GEMM (MFMA) launch with a
  * pair of HIP events on the launch stream.  d2t_profile_read synchronises,
