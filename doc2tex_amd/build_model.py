@@ -117,6 +117,8 @@ class Model(nn.Module):
         # 'fp32' = exact fp32 matrix-core convolutions (default); 'bf16x3' = split-bf16 convolutions
         # (3 bf16 MFMAs per product, fp32 accumulate; logits stay within 1e-3)
         self.conv_precision = "fp32"
+        # data-parallel training: a doc2tex_amd.dist.GradSync makes loss.backward() return all-reduced (mean) gradients
+        self.grad_sync = None
 
     def synchronize(self, host_sync=True):
         """Order the current stream (and optionally the host) after every outstanding pipelined decode."""

@@ -82,6 +82,8 @@ struct d2t_train_state {
   std::vector<TT> t;
   std::vector<Node> nodes;
   std::map<std::string, float*> grads;  // persistent, one buffer per trainable parameter
+  std::map<std::string, hipEvent_t> ready;  // recorded on the compute stream after the last kernel that writes a gradient
+  std::vector<std::string> touched;         // gradients written by the node being processed
   float* part = nullptr; size_t part_cap = 0;   // wgrad / column-reduction partial sums
   float* scratch = nullptr; size_t scratch_cap = 0;
   const int64_t* tgt = nullptr;
@@ -92,6 +94,7 @@ struct d2t_train_state {
   ~d2t_train_state() {
     tape.release();
     for (auto& kv : grads) hipFree(kv.second);
+    for (auto& kv : ready) hipEventDestroy(kv.second);
     if (part) hipFree(part);
     if (scratch) hipFree(scratch);
   }
@@ -135,6 +138,7 @@ struct Tr {  // builder / runner bound to one context and stream
     return D2T_OK;
   }
   int grad_buf(const std::string& k, float** p) {
+    st->touched.push_back(k);
     auto it = st->grads.find(k);
     if (it != st->grads.end()) { *p = it->second; return D2T_OK; }
     const RawW* r;
@@ -143,6 +147,9 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(dev_alloc(c, &q, r->numel * 4));
     TCHK(hipMemsetAsync(q, 0, r->numel * 4, s));
     st->grads[k] = (float*)q;
+    hipEvent_t ev;
+    TCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    st->ready[k] = ev;
     *p = (float*)q;
     return D2T_OK;
   }
@@ -637,6 +644,10 @@ struct Tr {  // builder / runner bound to one context and stream
           break;
         }
       }
+      // gradients this node wrote are final once the stream reaches this point (a parameter written by several
+      // nodes is re-recorded by each): d2t_train_grad on another stream waits for exactly this
+      for (const std::string& k : st->touched) TCHK(hipEventRecord(st->ready[k], s));
+      st->touched.clear();
     }
     return D2T_OK;
   }
@@ -678,6 +689,7 @@ int d2t_train_backward(d2t_ctx* c, const float* dlogits, d2t_stream stream) {
   Tr tr{c, st, (hipStream_t)stream};
   st->t[st->logits_id].grad = const_cast<float*>(dlogits);
   st->have_forward = false;  // the tape is consumed (the attention probabilities are overwritten)
+  st->touched.clear();
   return tr.backward();
 }
 
@@ -689,6 +701,8 @@ int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_
   if (it == st->grads.end()) return fail(c, D2T_ESTATE, "no gradient for '%s'", name);
   const RawW* r = find(c, name);
   if (!r || (int64_t)r->numel != numel) return fail(c, D2T_EINVAL, "gradient '%s': size mismatch", name);
+  // ordered after the backward kernels that produce this gradient, whichever stream `stream` is
+  HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, st->ready[name], 0));
   HIPCHK(c, hipMemcpyAsync(dst, it->second, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return D2T_OK;
 }

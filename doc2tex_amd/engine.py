@@ -166,6 +166,12 @@ class Engine:
                     f"train_grad({name})")
         return g
 
+    def train_grad_into(self, name, dst):
+        """Copy the gradient of `name` into the flat fp32 view `dst` on the current stream (ordered after the
+        kernels that produce it, whichever stream that is)."""
+        self._check(self.lib.d2t_train_grad(self.ctx, name.encode(), _lib.ptr(dst), dst.numel(), _lib.stream_of(dst)),
+                    f"train_grad({name})")
+
     def read_weight(self, name, dst):
         """Copy the engine's current copy of a loaded tensor into `dst` (fp32, contiguous, same size)."""
         self._check(self.lib.d2t_read_weight(self.ctx, name.encode(), _lib.ptr(dst), dst.numel(), _lib.stream_of(dst)),

@@ -28,8 +28,12 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.model._engine
-        eng.train_backward(dlogits)
-        grads = tuple(eng.train_grad(n, p) if p.requires_grad else None for n, p in zip(ctx.names, ctx.params))
+        eng.train_backward(dlogits)  # enqueues the whole backward on the current stream and returns
+        sync = getattr(ctx.model, "grad_sync", None)
+        if sync is None:
+            grads = tuple(eng.train_grad(n, p) for n, p in zip(ctx.names, ctx.params))
+        else:  # data-parallel: bucketed all-reduce-mean overlapped with the rest of the backward (dist.GradSync)
+            grads = tuple(sync.collect(eng.train_grad_into, ctx.names, ctx.params))
         return (None, None, None, None) + grads
 
 

@@ -190,6 +190,9 @@ int d2t_set_decode_chains(d2t_ctx* ctx, int32_t chains);
  * causal), dropout 0.  logits [B][L][vocab] is caller memory.  Weights are the ones last given to
  * d2t_load_weight (no finalize needed).  d2t_train_backward takes dL/dlogits [B][L][vocab] and leaves the
  * gradient of every trainable parameter in engine memory; d2t_train_grad copies one out by its state_dict key.
+ * d2t_train_grad may be given ANY stream: the copy is ordered (by an event) after the last backward kernel that
+ * writes that gradient, so a communication stream can pick up early gradients (decoder, ViT, deep backbone layers)
+ * and all-reduce them while the rest of the backward still runs on the compute stream.
  * One forward may be followed by at most one backward.  All pointers are device pointers. */
 int d2t_train_forward(d2t_ctx* ctx, const float* image, int32_t B, int32_t H, int32_t W, const int64_t* tgt, int32_t L,
                       float* logits, d2t_stream stream);

@@ -114,3 +114,22 @@ def test_train_step_gradients_match_oracle_autograd(cases, manifests):
         assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
         tight += _check_instance(m, ograds) <= 1e-3
     assert tight >= 2, tight
+
+
+def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
+    """model.grad_sync (bucketed copies on a communication stream, each ordered after its producing kernels by a
+    device event; world size 1 here, so no collective) returns bit-identical gradients."""
+    from doc2tex_amd.dist import GradSync
+    c = _case(cases, "train_step", "t2_train_step")
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    _step(m, img, text)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.load_state_dict(state0)
+    m.grad_sync = GradSync(bucket_bytes=4 << 20)
+    _step(m, img, text)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, ref[k]), k
