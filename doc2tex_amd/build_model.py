@@ -191,8 +191,8 @@ class Model(nn.Module):
             # module.train(): teacher-forced pass with BatchNorm on batch statistics (tfm.py:103-118), one autograd
             # node over the whole network so that loss.backward() (engine/training.py:137) fills every .grad
             from .train import train_forward
-            if self.stages["Seq"] != "ViT":
-                raise NotImplementedError("the training step is implemented for the HybridViT + TFM stack")
+            if self.stages["Seq"] not in ("ViT", "None"):
+                raise NotImplementedError("the training step is implemented for the HybridViT + TFM and ResNet + TFM stacks")
             if self.opt["Prediction"]["params"].get("dropout", 0.0) != 0.0:
                 raise NotImplementedError("training with dropout > 0 is not implemented in the HIP engine")
             logits = train_forward(self, input, text)

@@ -204,3 +204,6 @@ int need(d2t_ctx* c, const std::string& k, const RawW** out, std::vector<int64_t
 }
 
 }  // namespace
+
+// engine.hip: PositionalEncoding2D crop [h][w][C] (cached per (h, w) in the context)
+int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out);

@@ -211,6 +211,8 @@ int get_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) 
 
 }  // namespace
 
+int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) { return get_pe2d(c, h, w, C, s, out); }
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================

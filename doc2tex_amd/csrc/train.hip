@@ -51,7 +51,7 @@ struct TT {  // tensor on the tape
   float* grad = nullptr;
 };
 
-enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS };
+enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST };
 
 struct Node {
   Kind kind;
@@ -378,6 +378,19 @@ struct Tr {  // builder / runner bound to one context and stream
     return D2T_OK;
   }
 
+  // out[b] = in[b] + table  (PositionalEncoding2D of the ResNet+None encoder, recognizers/build_seq.py:69-76)
+  int add_const(int in, const float* table, int* out) {
+    const TT x = st->t[in];
+    RC(new_tensor(x.rows, x.cols, out, x.B, x.H, x.W));
+    const int per = (int)(x.rows / x.B) * x.cols;
+    for (int b = 0; b < x.B; ++b)
+      TCHK(launch_add_rows(x.p + (size_t)b * per, table, st->t[*out].p + (size_t)b * per, per, s));
+    Node n;
+    n.kind = N_ADDCONST; n.in = in; n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+
   // ViTEncoderV3 on top of the backbone (vit_encoder.py:249-268, patchembed.py:115-141)
   int vit(int feat, const std::string& p, int* out, float* into) {
     const d2t_config& g = c->cfg;
@@ -628,6 +641,7 @@ struct Tr {  // builder / runner bound to one context and stream
         case N_CONV: RC(bwd_conv(n)); break;
         case N_POOL: RC(bwd_pool(n)); break;
         case N_TOKENS: RC(bwd_tokens(n)); break;
+        case N_ADDCONST: RC(add_grad(n.in, st->t[n.out].grad)); break;
         case N_GELU: {
           const TT& x = st->t[n.in];
           float* dx;
@@ -662,7 +676,8 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (!c || !image || !tgt || !logits || B < 1 || H < 1 || W < 1 || L < 1) return fail(c, D2T_EINVAL, "bad argument");
   const d2t_config& g = c->cfg;
   if (g.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "the training step is implemented for the TFM head only");
-  if (g.encoder != D2T_ENC_HYBRID_VIT) return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT encoder only");
+  if (g.encoder != D2T_ENC_HYBRID_VIT && g.encoder != D2T_ENC_RESNET)
+    return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT and ResNet+None encoders");
   if (L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
   if (!c->train) c->train = new d2t_train_state();
   d2t_train_state* st = c->train;
@@ -673,9 +688,17 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   st->tgt = tgt; st->image = image; st->B = B; st->H = H; st->W = W; st->L = L;
   Tr tr{c, st, (hipStream_t)stream};
   int feat, mem, out;
-  const std::string sp = "seqmodeler.SequenceModeling.";
-  RC(tr.backbone(image, B, H, W, sp + "patch_embed.backbone.ConvNet.", &feat));
-  RC(tr.vit(feat, sp, &mem, nullptr));
+  if (g.encoder == D2T_ENC_HYBRID_VIT) {
+    const std::string sp = "seqmodeler.SequenceModeling.";
+    RC(tr.backbone(image, B, H, W, sp + "patch_embed.backbone.ConvNet.", &feat));
+    RC(tr.vit(feat, sp, &mem, nullptr));
+  } else {  // Feat=ResNet, Seq=None: + PositionalEncoding2D, [B,C,H,W] -> [B,HW,C] (already the NHWC row layout)
+    RC(tr.backbone(image, B, H, W, "featextractor.FeatureExtraction.ConvNet.", &feat));
+    const TT f = st->t[feat];
+    const float* pe;
+    RC(d2t_internal_pe2d(c, f.H, f.W, f.cols, (hipStream_t)stream, &pe));
+    RC(tr.add_const(feat, pe, &mem));
+  }
   RC(tr.decoder(mem, tgt, B, L, "predicter.Prediction.", logits, &out));
   st->logits_id = out;
   st->have_forward = true;
