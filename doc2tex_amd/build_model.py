@@ -167,8 +167,9 @@ class Model(nn.Module):
                 raise NotImplementedError(
                     "teacher-forced LSTM-attention decoding (is_train=True / model.train()) is not implemented in "
                     "the HIP engine; call model.eval() and pass is_train=False (engine/inferencing.py:70-76)")
-            if beam_size > 1:
-                raise NotImplementedError("LSTM-attention beam search (seq2seq.py:83-222) is not implemented yet")
+            if beam_size > 1:  # seq2seq.py:333-347 -> forward_beam (one sample, returns (seq, score, None))
+                prediction, logits = eng.decode_attn_beam(contextual_feature.contiguous(), beam_size)
+                return prediction, logits, None, {}
             prediction, logits = eng.decode_attn_greedy(contextual_feature.contiguous(), is_test)
             return prediction, logits, None, {}
         if self.training:

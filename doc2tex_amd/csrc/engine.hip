@@ -1009,6 +1009,154 @@ int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T
   return D2T_OK;
 }
 
+int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
+                         float* score_out, d2t_stream stream) {
+  // Attention.forward_beam (prediction_head/seq2seq.py:83-222) / AttentionV2.forward_beam (seq2seq_v2.py:12-174) for
+  // one sample: the attention cell + LSTMCell + generator of every live hypothesis run as ONE launch per step (the
+  // greedy kernel in step mode, one block per hypothesis, keys shared), log_softmax + flat top-k on the device, the
+  // reference's bookkeeping on the host -- including its quirks: step 0 ranks row 0 only; the LSTM state follows
+  // prev_word_inds[incomplete] but the coverage memory only `incomplete`; if the last executed step completed nothing
+  // the first live sequence is returned; otherwise the best score/len sequence with the MAXIMUM raw score.
+  if (!c || !memory || !seq_out || !len_out || !score_out || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  const d2t_config& g = c->cfg;
+  if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
+  if (!g.attn_coverage) return fail(c, D2T_ESTATE, "LSTM beam search is implemented for attn_type 'coverage' only");
+  if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
+  const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = beam_size;
+  const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
+  const int Tk = T - key_off;
+  if (Tk < 1 || Tk > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure(c, &c->dws, &c->dws_cap, ((size_t)T * Hh + 16) * 4))) return rc;
+  float* kp = c->dws;
+  // workspace (floats): logits [cap][V] | scores | topv | h_in c_in h_out c_out [cap][H] | mem_in mem_out [cap][Tk]
+  //                     | tok i64 [cap] | dummy tokens i64 [cap] | topi | idx_h | idx_m | end_step  (ints [cap])
+  const size_t nf = (size_t)cap * V + 2 * cap + 4 * (size_t)cap * Hh + 2 * (size_t)cap * Tk;
+  const size_t tok_off = (nf + 1) & ~(size_t)1;
+  const size_t ws_bytes = tok_off * 4 + 2 * (size_t)cap * 8 + 4 * (size_t)cap * 4 + 64;
+  if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, ws_bytes))) return rc;
+  float* d_logits = c->beam_ws;
+  float* d_scores = d_logits + (size_t)cap * V;
+  float* d_topv = d_scores + cap;
+  float* st[6];
+  st[0] = d_topv + cap;                          // h_in
+  st[1] = st[0] + (size_t)cap * Hh;              // c_in
+  st[2] = st[1] + (size_t)cap * Hh;              // h_out
+  st[3] = st[2] + (size_t)cap * Hh;              // c_out
+  st[4] = st[3] + (size_t)cap * Hh;              // mem_in
+  st[5] = st[4] + (size_t)cap * Tk;              // mem_out
+  int64_t* d_tok = reinterpret_cast<int64_t*>(d_logits + tok_off);
+  int64_t* d_dummy = d_tok + cap;
+  int* d_topi = reinterpret_cast<int*>(d_dummy + cap);
+  int* d_idxh = d_topi + cap;
+  int* d_idxm = d_idxh + cap;
+  int* d_end = d_idxm + cap;
+  char* hp = nullptr;
+  const size_t hbytes = (size_t)cap * (8 + 4 * 5) + 64;
+  if (hipHostMalloc(reinterpret_cast<void**>(&hp), hbytes, hipHostMallocDefault) != hipSuccess)
+    return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
+  int64_t* h_tok = reinterpret_cast<int64_t*>(hp);
+  float* h_scores = reinterpret_cast<float*>(hp + (size_t)cap * 8);
+  float* h_topv = h_scores + cap;
+  int* h_topi = reinterpret_cast<int*>(h_topv + cap);
+  int* h_idxh = h_topi + cap;
+  int* h_idxm = h_idxh + cap;
+  auto done = [&](int code) { hipHostFree(hp); return code; };
+#define BCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return done(fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  BCHK(linear_any(nullptr, s, memory, c->attn.key, nullptr, kp, T, ACT_NONE));
+  AttnDecP p{};
+  p.mem = memory; p.T = T; p.D = Hh; p.key_off = key_off;
+  p.init_mode = !g.attn_enc_init ? 0 : (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN ? 1 : 2);
+  p.kp = kp; p.wq_t = c->attn.wq_t; p.bq = c->attn.bq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
+  p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
+  p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
+  p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
+  p.emb = c->attn.emb; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
+  p.S = 1; p.V = V; p.H = Hh; p.E = Hh; p.coverage = 1; p.end_token = 1;
+  p.step_mode = 1;
+  p.st_h_in = st[0]; p.st_c_in = st[1]; p.st_mem_in = st[4];
+  p.st_h_out = st[2]; p.st_c_out = st[3]; p.st_mem_out = st[5];
+  p.tok_in = d_tok;
+
+  std::vector<std::vector<int64_t>> seqs((size_t)beam_size, std::vector<int64_t>{0});  // each starts with [GO] = 0
+  std::vector<float> live_scores((size_t)beam_size, 0.f);
+  std::vector<std::vector<int64_t>> complete;
+  std::vector<float> complete_scores;
+  int k = beam_size;
+  bool last_completed_any = false;
+  for (int step = 0; step < S; ++step) {
+    const int M = (int)seqs.size();
+    for (int i = 0; i < M; ++i) h_scores[i] = live_scores[i];
+    BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)M * 4, hipMemcpyHostToDevice, s));
+    p.B = M; p.first = step == 0;
+    BCHK(launch_attn_decode(p, s));
+    // step 0: the rows are identical and the reference ranks row 0 only (seq2seq.py:145-146)
+    BCHK(launch_beam_topk(d_logits, d_scores, step == 0 ? 1 : M, V, k, d_topv, d_topi, s));
+    BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    std::vector<std::vector<int64_t>> nseqs;
+    std::vector<float> nscores;
+    int ninc = 0;
+    last_completed_any = false;
+    for (int r = 0; r < k; ++r) {
+      const int prev = h_topi[r] / V, word = h_topi[r] % V;
+      std::vector<int64_t> sq = seqs[prev];
+      sq.push_back(word);
+      if (word == 1) {  // [s] (attn_converter.py:8)
+        complete.push_back(std::move(sq));
+        complete_scores.push_back(h_topv[r]);
+        last_completed_any = true;
+      } else {
+        h_idxh[ninc] = prev;  // LSTM state: hidden[prev_word_inds[incomplete]]
+        h_idxm[ninc] = r;     // coverage memory: (alpha_cum + alpha)[incomplete]
+        h_tok[ninc] = word;
+        nseqs.push_back(std::move(sq));
+        nscores.push_back(h_topv[r]);
+        ++ninc;
+      }
+    }
+    seqs.swap(nseqs);
+    live_scores.swap(nscores);
+    k = ninc;
+    if (k == 0) break;
+    if (step + 1 < S) {
+      BCHK(hipMemcpyAsync(d_idxh, h_idxh, (size_t)k * 4, hipMemcpyHostToDevice, s));
+      BCHK(hipMemcpyAsync(d_idxm, h_idxm, (size_t)k * 4, hipMemcpyHostToDevice, s));
+      BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)k * 8, hipMemcpyHostToDevice, s));
+      BCHK(launch_gather_rows(st[2], st[0], d_idxh, k, Hh, s));
+      BCHK(launch_gather_rows(st[3], st[1], d_idxh, k, Hh, s));
+      BCHK(launch_gather_rows(st[5], st[4], d_idxm, k, Tk, s));
+    }
+  }
+  BCHK(hipStreamSynchronize(s));
+#undef BCHK
+  std::vector<int64_t> out;
+  float score;
+  if (!last_completed_any) {  // seq2seq.py:209-216
+    out.assign(seqs[0].begin() + 1, seqs[0].end());
+    score = live_scores[0];
+  } else {
+    size_t best = 0;
+    for (size_t i = 1; i < complete.size(); ++i)
+      if ((double)complete_scores[i] / (double)complete[i].size() > (double)complete_scores[best] / (double)complete[best].size())
+        best = i;
+    out.assign(complete[best].begin() + 1, complete[best].end());
+    score = *std::max_element(complete_scores.begin(), complete_scores.end());
+  }
+  const int n = (int)std::min<size_t>(out.size(), (size_t)S);
+  for (int i = 0; i < n; ++i) seq_out[i] = out[i];
+  *len_out = n;
+  *score_out = score;
+  return done(D2T_OK);
+}
+
 int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
                             int64_t* tokens, float* logits, d2t_stream stream) {
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");

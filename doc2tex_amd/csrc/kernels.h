@@ -102,7 +102,15 @@ struct AttnDecP {
   const float* emb;                    // [V][E]
   float* probs; int64_t* tokens; int* end_step;  // [B][S][V], [B][S], [B] (-1 = never ended)
   int B, S, V, H, E, coverage, end_token;
+  // Beam-search step mode (S == 1): every block is one hypothesis of sample 0 (shared keys); the recurrent state is
+  // read from st_*_in (unless `first`: initial state as in the greedy loop) and left in st_*_out.
+  int step_mode, first;
+  const float *st_h_in, *st_c_in, *st_mem_in;  // [B][H], [B][H], [B][T - key_off]
+  float *st_h_out, *st_c_out, *st_mem_out;
+  const int64_t* tok_in;                        // [B] input token of this step
 };
+// dst[i][0..width) = src[idx[i]][0..width)
+hipError_t launch_gather_rows(const float* src, float* dst, const int* idx, int rows, int width, hipStream_t s);
 hipError_t launch_attn_decode(const AttnDecP& p, hipStream_t s);
 // dst[(row_off + c) * ld + r] = src[r * cols + c]
 hipError_t launch_transpose_into(const float* src, int rows, int cols, float* dst, int ld, int row_off, hipStream_t s);

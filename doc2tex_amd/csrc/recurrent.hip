@@ -132,8 +132,9 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   __shared__ __attribute__((aligned(16))) float wloc_s[11 * H];  // folded location filter, [tap][n]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int Tk = p.T - p.key_off;
-  const float* keys = p.mem + ((size_t)b * p.T + p.key_off) * p.D;
-  const float* kp = p.kp + ((size_t)b * p.T + p.key_off) * H;
+  const int bm = p.step_mode ? 0 : b;  // beam search: every hypothesis attends over sample 0
+  const float* keys = p.mem + ((size_t)bm * p.T + p.key_off) * p.D;
+  const float* kp = p.kp + ((size_t)bm * p.T + p.key_off) * H;
   float* ctx_s = x_s;
   float* emb_s = x_s + H;
   float* h_s = x_s + 2 * H;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   if (tid < H) {
     float init = 0.f;
     if (p.init_mode == 1) {
-      for (int t = 0; t < p.T; ++t) init += p.mem[((size_t)b * p.T + t) * p.D + tid];
+      for (int t = 0; t < p.T; ++t) init += p.mem[((size_t)bm * p.T + t) * p.D + tid];
       init /= (float)p.T;
     } else if (p.init_mode == 2) {
-      init = p.mem[(size_t)b * p.T * p.D + tid];
+      init = p.mem[(size_t)bm * p.T * p.D + tid];
     }
     hq_s[tid] = init;  // scratch
   }
@@ -169,6 +170,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   if (tid == 0) tok_s = 0;  // [GO]
   int ended = 0;
   __syncthreads();
+  if (p.step_mode && !p.first) {  // resume a hypothesis from its stored state
+    if (tid < H) { h_s[tid] = p.st_h_in[(size_t)b * H + tid]; c_s[tid] = p.st_c_in[(size_t)b * H + tid]; }
+    for (int t = tid; t < Tk; t += 1024) mem_s[t] = p.st_mem_in[(size_t)b * Tk + t];
+    if (tid == 0) tok_s = (int)p.tok_in[b];
+    __syncthreads();
+  }
 
   for (int step = 0; step < p.S; ++step) {
     // (1) query projection and target embedding
@@ -296,6 +303,21 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
     }
     __syncthreads();
   }
+  if (p.step_mode) {
+    if (tid < H) { p.st_h_out[(size_t)b * H + tid] = h_s[tid]; p.st_c_out[(size_t)b * H + tid] = c_s[tid]; }
+    for (int t = tid; t < Tk; t += 1024) p.st_mem_out[(size_t)b * Tk + t] = mem_s[t];
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx,
+                                   int width) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) dst[(size_t)i * width + c] = src[(size_t)idx[i] * width + c];
+}
+hipError_t launch_gather_rows(const float* src, float* dst, const int* idx, int rows, int width, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, s, src, dst, idx, width);
+  return hipGetLastError();
 }
 
 hipError_t launch_attn_decode(const AttnDecP& p, hipStream_t s) {

@@ -278,6 +278,18 @@ class Engine:
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self._check(self.lib.d2t_decode_wait(self.ctx, stream, int(bool(host_sync))), "decode_wait")
 
+    def decode_attn_beam(self, memory, beam_size):
+        """Attention.forward_beam / AttentionV2.forward_beam for one sample: (LongTensor [1, n] on the CPU, score)."""
+        memory = memory.float().contiguous()
+        assert memory.shape[0] == 1  # seq2seq.py:90
+        S = self.cfg.batch_max_length + 1
+        seq = (C.c_int64 * S)()
+        n = C.c_int32(0)
+        score = C.c_float(0.0)
+        self._check(self.lib.d2t_decode_attn_beam(self.ctx, _lib.ptr(memory), memory.shape[1], int(beam_size), seq,
+                                                  C.byref(n), C.byref(score), _lib.stream_of(memory)), "decode_attn_beam")
+        return torch.LongTensor(list(seq[: n.value])).unsqueeze(0), torch.tensor(float(score.value))
+
     def decode_beam(self, memory, beam_size):
         memory = memory.float().contiguous()
         if memory.shape[0] != 1:

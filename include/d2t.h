@@ -163,6 +163,13 @@ int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
+/* LSTM-attention beam search for ONE sample (reference: Attention.forward_beam, prediction_head/seq2seq.py:83-222;
+ * AttentionV2.forward_beam, seq2seq_v2.py:12-174 -- what config/test.yaml runs with beam_size 5 / 10).  Coverage
+ * attention only.  memory [1][T][256]; seq_out (host, >= batch_max_length + 1 entries) receives the token ids without
+ * the leading [GO]; *score_out the reference's returned score.  1 <= beam_size <= 16. */
+int d2t_decode_attn_beam(d2t_ctx* ctx, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out,
+                         int32_t* len_out, float* score_out, d2t_stream stream);
+
 /* ---- convolution arithmetic ------------------------------------------------
  * D2T_CONV_FP32   (default) exact fp32 on v_mfma_f32_32x32x2_f32.
  * D2T_CONV_BF16X3 backbone / patch-embed convolutions on the bf16 matrix cores with each fp32 operand

@@ -478,6 +478,81 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
     return probs.argmax(2), probs
 
 
+def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
+    """Attention.forward_beam (prediction_head/seq2seq.py:83-222) / AttentionV2.forward_beam (seq2seq_v2.py:12-174)
+    for one sample, coverage attention, embed_target=True.  Quirks kept: all `beam_size` rows start identical and
+    step 0 takes the top-k of row 0 only (:145-146); the hidden state is re-ordered by prev_word_inds[incomplete]
+    but the coverage memory only by `incomplete` (:197-207); a hypothesis ends on [s] = 1 and is stored with its
+    [GO]; when the LAST executed step completed nothing the first live sequence is returned even if earlier steps
+    completed some (:209-216); otherwise the best score/len sequence is returned together with the MAXIMUM raw
+    score (:218-224).  Returns (seq LongTensor [1, n], score float)."""
+    assert batch_H.shape[0] == 1
+    a = p + "attention_cell."
+    H1 = batch_H[0]
+    keys1 = H1[1:] if seqmodel == "TFM" else H1
+    init = H1.mean(dim=0) if seqmodel == "BiLSTM" else H1[0]
+    Hd = sd[a + "rnn.weight_hh"].shape[1]
+    k = beam_size
+    if enc_init:
+        h = F.linear(init, sd[p + "proj_init_h.weight"], sd[p + "proj_init_h.bias"])[None].repeat(k, 1)
+        c = F.linear(init, sd[p + "proj_init_c.weight"], sd[p + "proj_init_c.bias"])[None].repeat(k, 1)
+    else:
+        h, c = torch.zeros(k, Hd), torch.zeros(k, Hd)
+    keys = keys1[None].repeat(k, 1, 1)
+    T = keys.shape[1]
+    kp1 = F.linear(keys1, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
+    pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
+    alpha_cum = torch.zeros(k, T, 1)
+    mem = None
+    seqs = torch.zeros(k, 1, dtype=torch.long)  # [GO] = 0 (attn_converter.py:8)
+    targets = seqs[:, 0]
+    top_scores = torch.zeros(k, 1)
+    complete, complete_scores, complete_inds = [], [], []
+    for step in range(num_steps):
+        M = h.shape[0]
+        emb = F.embedding(targets, sd[p + "embedding.weight"])
+        hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
+        last = torch.zeros(M, T, 1) if mem is None else mem
+        loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
+        loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
+        e = F.linear(torch.tanh(kp1[None] + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])
+        alpha = F.softmax(e, dim=1)
+        context = torch.bmm(alpha.permute(0, 2, 1), keys[:M]).squeeze(1)
+        g = (F.linear(torch.cat([context, emb], 1), sd[a + "rnn.weight_ih"], sd[a + "rnn.bias_ih"])
+             + F.linear(h, sd[a + "rnn.weight_hh"], sd[a + "rnn.bias_hh"]))
+        gi, gf, gg, go = g.chunk(4, dim=1)
+        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+        h = torch.sigmoid(go) * torch.tanh(c)
+        out = F.linear(h, sd[a + "generator.weight"], sd[a + "generator.bias"])
+        V = out.shape[1]
+        scores = top_scores.expand_as(out) + F.log_softmax(out, dim=-1)
+        if step == 0:
+            top_v, top_w = scores[0].topk(k, 0, True, True)
+        else:
+            top_v, top_w = scores.reshape(-1).topk(k, 0, True, True)
+        prev = top_w // V
+        nxt = top_w % V
+        seqs = torch.cat([seqs[prev], nxt.unsqueeze(1)], dim=1)
+        incomplete = [i for i, w in enumerate(nxt.tolist()) if w != ATTN_END]
+        complete_inds = sorted(set(range(len(nxt))) - set(incomplete))
+        if complete_inds:
+            complete.extend(seqs[complete_inds].tolist())
+            complete_scores.extend(top_v[complete_inds].tolist())
+        k -= len(complete_inds)
+        if k == 0:
+            break
+        seqs = seqs[incomplete]
+        h, c = h[prev[incomplete]], c[prev[incomplete]]
+        top_scores = top_v[incomplete].unsqueeze(1)
+        targets = nxt[incomplete]
+        alpha_cum = (alpha_cum + alpha)[incomplete]
+        mem = alpha_cum
+    if not complete_inds:
+        return torch.tensor(seqs[0][1:].tolist(), dtype=torch.long)[None], float(top_scores[0])
+    best = max(range(len(complete)), key=lambda i: complete_scores[i] / len(complete[i]))
+    return torch.tensor(complete[best][1:], dtype=torch.long)[None], float(max(complete_scores))
+
+
 # ---------------------------------------------------------------------------
 # Model.forward  (modules/build_model.py:36-79)
 # ---------------------------------------------------------------------------
@@ -519,6 +594,9 @@ def forward(cfg, sd, image, text, is_train=True, is_test=False, faithful=False, 
         sm = pp.get("seqmodel", "ViT")
         if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
             sm = "first"  # seq2seq.py:229-238: keys = all tokens, init from token 0
+        if cfg.get("beam_size", 1) > 1:  # Attention.forward (seq2seq.py:333-347): beam only when not is_train
+            seq, score = attn_beam(mem, sd, p, cfg["batch_max_length"] + 1, sm, cfg["beam_size"], pp.get("enc_init", False))
+            return seq, score, {}
         preds, probs = attn_greedy(mem, sd, p, cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
                                    pp.get("enc_init", False), is_test)
         return preds, probs, {}

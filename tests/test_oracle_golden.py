@@ -68,6 +68,20 @@ def test_beam_matches_reference_fixture(cases, manifests, name):
     assert abs(score - c["score"]) <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish"])
+def test_attn_beam_matches_reference_fixture(cases, manifests, name):
+    """LSTM-attention beam search (seq2seq.py:83-222, seq2seq_v2.py:12-174) of the oracle against the reference."""
+    c = _case(cases, "attn_beam", name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    cfg["beam_size"] = c["beam_size"]
+    img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"])
+    with torch.no_grad():
+        seq, score, _ = R.forward(cfg, sd, img, torch.zeros(1, c["max_seq_len"] + 1, dtype=torch.long),
+                                  is_train=False, is_test=True)
+    assert seq[0].tolist() == c["seq"]
+    assert abs(score - c["score"]) <= 1e-3
+
+
 def test_teacher_forced_loss_matches_reference_fixture(cases, manifests):
     c = _case(cases, "train", "t2_train")
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])

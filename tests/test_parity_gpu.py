@@ -141,6 +141,37 @@ def test_beam_vs_oracle_other_seeds(cases, manifests):
         assert abs(score - oscore) <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish"])
+def test_attn_beam_vs_reference_fixture(cases, name):
+    """LSTM-attention beam search (Attention.forward_beam seq2seq.py:83-222, AttentionV2.forward_beam
+    seq2seq_v2.py:12-174; what config/test.yaml runs): token ids exact, score within 1e-3."""
+    c = _case(cases, "attn_beam", name)
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c["beam_size"])
+    img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.zeros(1, c["max_seq_len"] + 1, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        seq, score, _ = m(img, text, is_train=False, is_test=True)
+        seq2, score2, _ = m(img, text, is_train=False, is_test=True)
+    assert seq.shape[0] == 1 and seq[0].tolist() == c["seq"], (seq, c["seq"])
+    assert abs(float(score) - c["score"]) <= 1e-3, (score, c["score"])
+    assert torch.equal(seq, seq2) and float(score) == float(score2)
+
+
+def test_attn_beam_vs_oracle_other_seeds(cases, manifests):
+    c = _case(cases, "attn_beam", "ts0_beam5")
+    for iseed, eb, beam in [(601, 0.3, 5), (602, 0.25, 7), (603, 0.35, 3), (604, 0.0, 2)]:
+        cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], eb, beam_size=beam)
+        ocfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], eb)
+        ocfg["beam_size"] = beam
+        img = synth.synth_images(1, c["H"], c["W"], seed=iseed)
+        text = torch.zeros(1, c["max_seq_len"] + 1, dtype=torch.long)
+        with torch.no_grad():
+            seq, score, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=True)
+            oseq, oscore, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=True)
+        assert seq[0].tolist() == oseq[0].tolist(), (iseed, eb, beam)
+        assert abs(float(score) - oscore) <= 1e-3
+
+
 def test_beam_rejects_batches():
     cfg, m = engine_model("T2", 8, beam_size=3)
     img = synth.synth_images(2, 48, 64).cuda()

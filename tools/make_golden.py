@@ -60,6 +60,15 @@ BEAM_CASES = [
     ("c2_beam5", "C2", 96, 384, 12, 1234, 1011, 1.8, 5),
     ("t2_beam3_nofinish", "T2", 48, 64, 6, 1234, 1012, 0.0, 3),
 ]
+# LSTM-attention beam search (seq2seq.py:83-222 / seq2seq_v2.py:12-174): name, config, H, W, batch_max_length, wseed, iseed, end_bias, beam
+ATTN_BEAM_CASES = [
+    ("ts0_beam5", "TS0", 48, 64, 14, 1234, 1050, 0.3, 5),
+    ("c0_beam3", "C0", 32, 320, 12, 1234, 1051, 0.15, 3),
+    ("c0_beam3_end", "C0", 32, 320, 12, 1234, 1051, 0.2, 3),  # [s] wins at step 0
+    ("s0_beam10", "S0", 96, 384, 10, 1234, 1052, 0.3, 10),
+    ("s0_beam10_late", "S0", 96, 384, 10, 1234, 1052, 0.4, 10),  # completions early, none in the last step
+    ("ts0_beam4_nofinish", "TS0", 48, 64, 6, 1234, 1053, 0.0, 4),
+]
 TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
 # full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
 TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031)]
@@ -203,6 +212,21 @@ def run_beam(case):
     return rep
 
 
+def run_attn_beam(case):
+    name, cname, H, W, L, wseed, iseed, end_bias, beam = case
+    cfg, m, sd = build_ref(cname, L, beam_size=beam, wseed=wseed, end_bias=end_bias)
+    img = synth.synth_images(1, H, W, seed=iseed)
+    text = torch.zeros(1, L + 1, dtype=torch.long)  # engine/inferencing.py:58-63 (ignored by the beam path)
+    with torch.no_grad():
+        seq, score, _ = m(img, text, is_train=False, is_test=True)
+        rseq, rscore, _ = R.forward(cfg, slim_sd(sd), img, text, is_train=False, is_test=True)
+    assert torch.equal(seq, rseq), (seq, rseq)
+    assert abs(float(score) - rscore) <= 1e-4, (float(score), rscore)
+    return {"case": name, "config": cname, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
+            "end_bias": end_bias, "beam_size": beam, "seq": seq[0].tolist(), "score": float(score),
+            "ended": bool(len(seq[0]) and int(seq[0][-1]) == 1), "torch": torch.__version__}
+
+
 def run_train(case):
     name, cname, B, H, W, L, wseed, iseed = case
     cfg, m, sd = build_ref(cname, L, wseed=wseed)
@@ -289,6 +313,17 @@ def main():
     torch.manual_seed(0)
     summary = {"greedy": [], "beam": [], "train": [], "train_step": []}
     manifests = {}
+    if os.environ.get("GOLDEN_ONLY") == "attn_beam":  # refresh only the LSTM beam fixtures
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        summary["attn_beam"] = []
+        for case in ATTN_BEAM_CASES:
+            rep = run_attn_beam(case)
+            summary["attn_beam"].append(rep)
+            print("attn_beam", rep["case"], rep["seq"], rep["score"], "ended", rep["ended"], flush=True)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        return
     if os.environ.get("GOLDEN_ONLY") == "train_step":  # refresh only the training fixtures
         with open(os.path.join(GOLD, "cases.json")) as f:
             summary = json.load(f)
@@ -310,6 +345,11 @@ def main():
         rep = run_beam(case)
         summary["beam"].append(rep)
         print("beam", rep["case"], rep["seq"], rep["score"], "completed", rep["completed"], flush=True)
+    summary["attn_beam"] = []
+    for case in ATTN_BEAM_CASES:
+        rep = run_attn_beam(case)
+        summary["attn_beam"].append(rep)
+        print("attn_beam", rep["case"], rep["seq"], rep["score"], "ended", rep["ended"], flush=True)
     for case in TRAIN_CASES:
         rep = run_train(case)
         summary["train"].append(rep)
