@@ -40,6 +40,7 @@ struct LinW {
   const float* w = nullptr;
   const float* b = nullptr;
   int N = 0, K = 0;
+  const uint16_t *w_hi = nullptr, *w_lo = nullptr;  // optional bf16 split of w (large-M linears on the bf16x3 kernel)
 };
 struct LNW {
   const float* g = nullptr;
@@ -111,6 +112,7 @@ struct d2t_ctx {
   int word_pe_rows = 0;
   std::vector<DecLayer> dec;
   float* ckv_w = nullptr;  // [layers*2*d][d] cross-attention K,V projections of every layer
+  uint16_t *ckv_hi = nullptr, *ckv_lo = nullptr;  // its bf16 split
   float* ckv_b = nullptr;
   LinW out_proj;
 

@@ -45,6 +45,23 @@ int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K) {
   *out = LinW{w->p, b->p, N, K};
   return D2T_OK;
 }
+// bf16 hi/lo planes of a Linear's weight for the bf16x3 GEMM kernel (K % 32 == 0)
+int split_planes(d2t_ctx* c, const float* w, size_t n, const uint16_t** hi, const uint16_t** lo, hipStream_t s) {
+  void *ph, *pl;
+  int rc;
+  if ((rc = dev_alloc(c, &ph, n * 2)) || (rc = dev_alloc(c, &pl, n * 2))) return rc;
+  c->owned.push_back(ph);
+  c->owned.push_back(pl);
+  HIPCHK(c, launch_split_bf16(w, (uint16_t*)ph, (uint16_t*)pl, n, s));
+  *hi = (const uint16_t*)ph;
+  *lo = (const uint16_t*)pl;
+  return D2T_OK;
+}
+int split_lin(d2t_ctx* c, LinW* l, hipStream_t s) {
+  if (l->K % 32) return D2T_OK;
+  return split_planes(c, l->w, (size_t)l->N * l->K, &l->w_hi, &l->w_lo, s);
+}
+
 int get_ln(d2t_ctx* c, const std::string& k, LNW* out, int D) {
   const RawW *g, *b;
   int rc;
@@ -111,6 +128,7 @@ hipError_t linear_big(d2t_ctx* c, hipStream_t s, const float* x, const LinW& w, 
                       int act) {
   ConvP p{};
   p.in = x; p.w = w.w; p.bias = w.b; p.res = res; p.out = y;
+  if (c && c->conv_bf16x3 && w.w_hi) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }  // launch_conv picks the bf16x3 GEMM
   p.B = 1; p.H = 1; p.W = M; p.Cin = w.K; p.OH = 1; p.OW = M; p.Cout = w.N;
   p.KH = p.KW = p.SH = p.SW = 1; p.PH = p.PW = 0; p.M = M; p.K = w.K; p.act = act;
   return c ? conv_timed(c, p, s) : launch_conv(p, s);
@@ -436,6 +454,9 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
       const int hid = (int)f1->shape[0];
       if ((rc = get_lin(c, b + "mlp.fc1", &vb.fc1, hid, D)) || (rc = get_lin(c, b + "mlp.fc2", &vb.fc2, D, hid)))
         return rc;
+      if ((rc = split_lin(c, &vb.qkv, s)) || (rc = split_lin(c, &vb.proj, s)) || (rc = split_lin(c, &vb.fc1, s)) ||
+          (rc = split_lin(c, &vb.fc2, s)))
+        return rc;
       c->vit.push_back(vb);
     }
     if ((rc = get_ln(c, sm + "norm", &c->vit_norm, D))) return rc;
@@ -571,6 +592,12 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
     c->dec.push_back(dl);
   }
   if ((rc = get_lin(c, pp + "proj", &c->out_proj, V, d))) return rc;
+  {  // bf16 split of the stacked cross-attention K/V projection (one large-M GEMM per batch)
+    const uint16_t *hi = nullptr, *lo = nullptr;
+    if (d % 32 == 0 && (rc = split_planes(c, c->ckv_w, (size_t)g.dec_layers * 2 * d * d, &hi, &lo, s))) return rc;
+    c->ckv_hi = const_cast<uint16_t*>(hi);
+    c->ckv_lo = const_cast<uint16_t*>(lo);
+  }
   HIPCHK(c, hipStreamSynchronize(s));
   c->finalized = true;
   return D2T_OK;
@@ -795,6 +822,7 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
   const int d = g.dec_dim;
   ConvP p{};
   p.in = memory; p.w = c->ckv_w; p.bias = c->ckv_b; p.out = c->ckv;
+  if (c->conv_bf16x3 && c->ckv_hi) { p.w_hi = c->ckv_hi; p.w_lo = c->ckv_lo; }
   p.B = 1; p.H = 1; p.W = B * T; p.Cin = d; p.OH = 1; p.OW = B * T; p.Cout = g.dec_layers * 2 * d;
   p.KH = p.KW = p.SH = p.SW = 1; p.M = B * T; p.K = d; p.act = ACT_NONE;
   p.store_mode = STORE_KV; p.kv_T = T; p.kv_heads = g.dec_heads; p.kv_hd = d / g.dec_heads; p.kv_B = B;
