@@ -221,14 +221,21 @@ struct Tr {  // builder / runner bound to one context and stream
     n.KH = KH; n.KW = KW; n.SH = SH; n.SW = SW; n.PH = PH; n.PW = PW; n.relu = relu; n.N = Cout; n.K = KH * KW * x.cols;
     const float* w;
     RC(raw(wkey + ".weight", &w, (size_t)Cout * x.cols * KH * KW));
-    // raw OIHW -> the kernel's packed OHWI order (no BN folding in training mode)
-    RC(ensure_scratch((size_t)Cout * n.K + Cout));
+    // raw OIHW -> the kernel's packed OHWI order (no BN folding in training mode); in bf16x3 mode also its bf16
+    // hi / lo planes, which make launch_conv take the split-bf16 kernel (fp32 activations split on the fly)
+    const size_t wn = (size_t)Cout * n.K;
+    RC(ensure_scratch(2 * wn + Cout + 64));
     float* wp = st->scratch;
     const float* bias = nullptr;
     if (bnkey.empty()) RC(raw(wkey + ".bias", &bias, Cout));
-    TCHK(launch_pack_conv(w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, wp, wp + (size_t)Cout * n.K, Cout, x.cols, KH, KW, s));
+    TCHK(launch_pack_conv(w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, wp, wp + wn, Cout, x.cols, KH, KW, s));
     RC(alloc(&n.z, (size_t)P * Cout));
     ConvP p{};
+    if (c->conv_bf16x3) {
+      uint16_t* hi = reinterpret_cast<uint16_t*>(wp + wn + Cout + 16);
+      TCHK(launch_split_bf16(wp, hi, hi + wn, wn, s));
+      p.w_hi = hi; p.w_lo = hi + wn;
+    }
     p.in = x.p; p.w = wp; p.bias = bias; p.out = n.z;
     p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
@@ -605,6 +612,13 @@ struct Tr {  // builder / runner bound to one context and stream
     }
     RC(alloc(&dx, (size_t)x.rows * Cin));
     ConvP p{};
+    if (c->conv_bf16x3) {
+      float* planes;
+      RC(alloc(&planes, (size_t)Cin * Kd));  // two bf16 planes = Cin*Kd floats
+      uint16_t* hi = reinterpret_cast<uint16_t*>(planes);
+      TCHK(launch_split_bf16(wp, hi, hi + (size_t)Cin * Kd, (size_t)Cin * Kd, s));
+      p.w_hi = hi; p.w_lo = hi + (size_t)Cin * Kd;
+    }
     p.in = src; p.w = wp; p.out = dx;
     p.B = x.B; p.H = DH; p.W = DW; p.Cin = Cout; p.OH = x.H; p.OW = x.W; p.Cout = Cin;
     p.KH = n.KH; p.KW = n.KW; p.SH = p.SW = 1; p.PH = n.KH - 1 - n.PH; p.PW = n.KW - 1 - n.PW;

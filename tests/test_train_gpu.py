@@ -119,6 +119,22 @@ def test_train_step_gradients_match_oracle_autograd(cases, manifests):
     assert tight >= 2, tight
 
 
+def test_train_step_with_split_bf16_convolutions(cases, manifests):
+    """conv_precision = 'bf16x3' also routes the training step's forward and data-gradient convolutions through the
+    split-bf16 kernel (3 bf16 MFMAs per product): same gradient criteria as fp32."""
+    c = _case(cases, "train_step", "t2_train_step")
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
+    m.conv_precision = "bf16x3"
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=1130)
+    text = train_step_labels({**c, "iseed": 1130})
+    oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text)
+    loss, preds = _step(m, img, text)
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
+    assert _check_instance(m, ograds) <= 1e-3
+
+
 def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
     """model.grad_sync (bucketed copies on a communication stream, each ordered after its producing kernels by a
     device event; world size 1 here, so no collective) returns bit-identical gradients."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the training step (config C3 per-GPU shard: HybridViT + TFM-6, 128x512 crops, B=32, 150-token labels):
-forward (module.train()) + CE + backward in the HIP engine + torch.optim.AdamW step.  usage: train_bench.py [B] [steps]"""
+forward (module.train()) + CE + backward in the HIP engine + torch.optim.AdamW step.  usage: train_bench.py [B] [steps] [fp32|bf16x3]"""
 import os
 import sys
 import time
@@ -19,6 +19,7 @@ m = Model(cfg)
 tmpl = {k: v for k, v in m.state_dict().items()}
 m.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
 m = m.cuda().train()
+m.conv_precision = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
 img = synth.synth_images(B, H, W, seed=7).cuda()
 text = synth.synth_labels(B, max_len=L, seed=7).cuda()
@@ -43,5 +44,5 @@ for _ in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"train step B={B}: {dt * 1e3:.1f} ms = {B / dt:.1f} formulas/s, loss {float(l):.4f}, "
+print(f"train step B={B} {m.conv_precision}: {dt * 1e3:.1f} ms = {B / dt:.1f} formulas/s, loss {float(l):.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB (torch) ")
