@@ -649,9 +649,97 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
     if (lane < HD) p.dk[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c] = a * scale;
   }
 }
+// Same mathematics with coalesced accesses: dO and Q of the head are staged in LDS too, and the two column-wise
+// reductions (dV over queries with P, dK over queries with dS) run with lane = key (consecutive lanes read consecutive
+// probabilities of one query row) and wave = group of HD/4 channels.  Needs (2*Lk*(HD+1) + 2*Lq*HD + 4*Lk) floats of LDS.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrainP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;                             // [Lk][HD+1]
+  float* Vs = Ks + (size_t)p.Lk * (HD + 1);   // [Lk][HD+1]
+  float* dOs = Vs + (size_t)p.Lk * (HD + 1);  // [Lq][HD]
+  float* Qs = dOs + (size_t)p.Lq * HD;        // [Lq][HD]
+  float* Ds = Qs + (size_t)p.Lq * HD;         // [4 waves][Lk]
+  const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < p.Lk * HD; i += 256) {
+    const int j = i / HD, c = i % HD;
+    Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
+    Vs[j * (HD + 1) + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+  }
+  for (int i = tid; i < p.Lq * HD; i += 256) {
+    const int r = i / HD, c = i % HD;
+    dOs[i] = p.o[((size_t)b * p.Lq + r) * p.ldo + hh * HD + c];
+    Qs[i] = p.q[((size_t)b * p.Lq + r) * p.ldq + hh * HD + c];
+  }
+  __syncthreads();
+  float* probs = p.probs + ((size_t)b * p.heads + hh) * p.Lq * p.Lk;
+  constexpr int CG = HD / 4;  // channels per wave
+  // column reduction out[j][c] = alpha * sum_i M[i][j] * R[i][c]
+  auto colred = [&](const float* R, float* out, int ld, float alpha) {
+    for (int j0 = 0; j0 < p.Lk; j0 += 64) {
+      const int j = j0 + lane;
+      float acc[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+      if (j < p.Lk) {
+        for (int i = 0; i < p.Lq; ++i) {
+          const float m = probs[(size_t)i * p.Lk + j];
+          const float* r = R + i * HD + wave * CG;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) acc[c] = fmaf(m, r[c], acc[c]);
+        }
+        float* o = out + ((size_t)b * p.Lk + j) * ld + hh * HD + wave * CG;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) o[c] = acc[c] * alpha;
+      }
+    }
+  };
+  colred(dOs, p.dv, p.ldv, 1.f);  // phase 1: dV = P^T dO
+  __syncthreads();
+  const float scale = rsqrtf((float)HD);
+  constexpr int PH = 64 / HD;
+  const int c = lane % HD, ph = lane / HD;
+  for (int i = wave; i < p.Lq; i += 4) {  // phase 2: dS (in place) and dQ, one wave per query row
+    const float* d_o = dOs + i * HD;
+    float* prow = probs + (size_t)i * p.Lk;
+    float dsum = 0.f;
+    for (int j = lane; j < p.Lk; j += 64) {
+      float dp = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      Ds[wave * p.Lk + j] = dp;
+      dsum = fmaf(dp, prow[j], dsum);
+    }
+    dsum = wsum(dsum);
+    for (int j = lane; j < p.Lk; j += 64) {
+      const float ds = prow[j] * (Ds[wave * p.Lk + j] - dsum);
+      prow[j] = ds;
+      Ds[wave * p.Lk + j] = ds;
+    }
+    float a = 0.f;
+    for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[j * (HD + 1) + c], a);
+    if (PH == 2) a += __shfl_xor(a, 32, 64);
+    if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
+  }
+  __syncthreads();
+  colred(Qs, p.dk, p.ldk, scale);  // phase 3: dK = scale * dS^T Q
+}
+
 hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s) {
   const size_t lds = ((size_t)2 * p.Lk * (p.hd + 1) + 4 * (size_t)p.Lk) * 4;
+  const size_t lds_fast = lds + (size_t)2 * p.Lq * p.hd * 4;
   hipError_t e;
+  if (lds_fast <= 160 * 1024 && (p.hd == 32 || p.hd == 64)) {
+    if (p.hd == 32) {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_fast_kernel<32>), lds_fast)) != hipSuccess) return e;
+      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<32>, dim3(p.B * p.heads), dim3(256), lds_fast, s, p);
+    } else {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_fast_kernel<64>), lds_fast)) != hipSuccess) return e;
+      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<64>, dim3(p.B * p.heads), dim3(256), lds_fast, s, p);
+    }
+    return hipGetLastError();
+  }
   if (p.hd == 32) {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<32>), lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(attn_train_bwd_kernel<32>, dim3(p.B * p.heads), dim3(256), lds, s, p);
