@@ -23,7 +23,7 @@ class D2TConfig(C.Structure):
         "encoder", "in_channels", "backbone_out", "vit_depth", "vit_heads", "vit_dim", "patch_h", "patch_w",
         "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len",
         "decoder", "attn_hidden", "attn_kernel_size", "attn_kernel_dim", "attn_keys", "attn_enc_init",
-        "attn_coverage", "bilstm_hidden", "batch_max_length")]
+        "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb")]
 
 
 _P = C.c_void_p

@@ -194,6 +194,8 @@ class Model(nn.Module):
             from .train import train_forward
             if self.stages["Seq"] not in ("ViT", "None"):
                 raise NotImplementedError("the training step is implemented for the HybridViT + TFM and ResNet + TFM stacks")
+            if self.engine(finalize=False).cfg.gcb:
+                raise NotImplementedError("training with GlobalContext blocks (gcb: True) is not implemented in the HIP engine")
             if self.opt["Prediction"]["params"].get("dropout", 0.0) != 0.0:
                 raise NotImplementedError("training with dropout > 0 is not implemented in the HIP engine")
             logits = train_forward(self, input, text)

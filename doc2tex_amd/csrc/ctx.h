@@ -102,6 +102,8 @@ struct d2t_ctx {
   BiLstmW lstm[2];   // seq_modeling/bilstm.py
   AttnW attn;        // prediction_head/seq2seq.py
   std::vector<Block> layers[4];
+  GCParams gc[4] = {};  // GlobalContext block after each stage (cfg.gcb)
+  float* gc_ws = nullptr; size_t gc_ws_cap = 0;
   const float* pos_embed = nullptr;  // [1+gh*gw][dim]
   int pos_rows = 0;
   float* cls_row = nullptr;  // cls_token + pos_embed[0]

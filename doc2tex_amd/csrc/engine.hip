@@ -159,7 +159,9 @@ float* pick(d2t_ctx* c, std::initializer_list<const float*> live) {
 int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int W, Act* out, float* final_out,
                  const ConvP* final_extra, bool final_split) {
   hipError_t err = hipSuccess;
-  const bool sp = c->conv_bf16x3;
+  // GlobalContext blocks read and update whole fp32 maps, so with gcb the activations stay fp32 (the convolutions still
+  // take the split-bf16 kernel in bf16x3 mode, splitting their input on the fly)
+  const bool sp = c->conv_bf16x3 && !c->cfg.gcb;
   Act x{pick(c, {}), B, H, W, c->stem.Cout};
   x.split = sp;
   if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s));
@@ -180,7 +182,18 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
       if (b.has_down) r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}), nullptr, sp);
       x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &r, pick(c, {x.p, t.p, r.p}), nullptr, sp);
     }
+    if (c->cfg.gcb) {  // resnet.py:200-201: GlobalContext closes the stage
+      const int HW = x.H * x.W;
+      float* ws = c->gc_ws;  // logits [B*HW] | ctx [B][C] | y [B][C]
+      hipError_t e = launch_global_context(x.p, c->gc[li], ws, ws + (size_t)x.B * HW, ws + (size_t)x.B * HW + (size_t)x.B * x.C,
+                                           x.B, HW, x.C, s);
+      if (e != hipSuccess && err == hipSuccess) err = e;
+    }
   };
+  if (c->cfg.gcb) {
+    const int rc = ensure(c, &c->gc_ws, &c->gc_ws_cap, ((size_t)B * (H / 2) * (W / 2) + 2 * (size_t)B * 512 + 64) * 4);
+    if (rc) return rc;
+  }
   x = pool(x, 2, 2, 0, 0);
   stage(0);
   x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
@@ -315,6 +328,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->dstate) hipFree(c->dstate);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->zero_page) hipFree(c->zero_page);
+  if (c->gc_ws) hipFree(c->gc_ws);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->dstream) hipStreamDestroy(c->dstream);
   if (c->parked.skv) hipFree(c->parked.skv);
@@ -388,6 +402,19 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
         if ((rc = pack_conv(c, p + ".downsample.0", p + ".downsample.1", &b.down, s))) return rc;
       }
       c->layers[li].push_back(b);
+    }
+    if (c->cfg.gcb) {  // GlobalContext(planes) appended to the stage (visual_attention.py:105-165)
+      const std::string p = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(RESNET_LAYERS[li]) + ".";
+      const int C = c->layers[li].back().c2.Cout;
+      const RawW *wg, *bg, *w1, *b1, *lg, *lb, *w2, *b2;
+      if ((rc = need(c, p + "global_cxt.weight", &wg, {1, C, 1, 1})) || (rc = need(c, p + "global_cxt.bias", &bg, {1})) ||
+          (rc = need(c, p + "bottleneck_add.fc1.weight", &w1, {C, C, 1, 1})) ||
+          (rc = need(c, p + "bottleneck_add.fc1.bias", &b1, {C})) ||
+          (rc = need(c, p + "bottleneck_add.norm.weight", &lg, {C})) || (rc = need(c, p + "bottleneck_add.norm.bias", &lb, {C})) ||
+          (rc = need(c, p + "bottleneck_add.fc2.weight", &w2, {C, C, 1, 1})) ||
+          (rc = need(c, p + "bottleneck_add.fc2.bias", &b2, {C})))
+        return rc;
+      c->gc[li] = GCParams{wg->p, bg->p, w1->p, b1->p, lg->p, lb->p, w2->p, b2->p};
     }
   }
   if ((rc = pack_conv(c, bb + "conv1", bb + "bn1", &c->conv1, s))) return rc;

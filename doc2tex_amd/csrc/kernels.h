@@ -196,6 +196,11 @@ hipError_t launch_add_rows(const float* a, const float* b, float* out, int n, hi
 // out[b*img_stride*D + i] = row[i] for i < D  (cls-token row of every image)
 hipError_t launch_fill_cls(const float* row, float* out, int B, long long img_stride_floats, int D, hipStream_t s);
 
+// GlobalContext block (gcb): x [B][HW][C] += fc2(relu(LN(fc1(attention-pooled x))))
+struct GCParams { const float *wg, *bg, *w1, *b1, *ln_g, *ln_b, *w2, *b2; };
+hipError_t launch_global_context(float* x, const GCParams& w, float* logits, float* ctx, float* y, int B, int HW, int C,
+                                 hipStream_t s);
+
 // ---- training step (train_kernels.hip) --------------------------------------
 // Weight gradient ("TN" GEMM, optional filter taps): part[z][tap][m][n] = sum_{p in chunk z} a[p][m] * x[src(p,tap)][n]
 struct WgradP {

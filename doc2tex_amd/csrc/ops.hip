@@ -426,4 +426,116 @@ hipError_t launch_fill_cls(const float* row, float* out, int B, long long img_st
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// GlobalContext block (addon_module/visual_attention.py:105-165; gcb: True): per image a 1x1-conv attention map over
+// the H*W positions, softmax, attention-pooled channel vector, ConvMLP (fc1 -> LayerNorm -> ReLU -> fc2), added to
+// every position.  x is NHWC fp32 [B][HW][C], modified in place.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gc_logits_kernel(const float* __restrict__ x, const float* __restrict__ wg,
+                                                        const float* __restrict__ bg, float* __restrict__ logits,
+                                                        long long rows, int C) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float a = 0.f;
+  for (int c = lane; c < C; c += 64) a = fmaf(x[row * C + c], wg[c], a);
+  a = wave_sum(a);
+  if (lane == 0) logits[row] = a + bg[0];
+}
+// ctx[b][c] = sum_p softmax_p(logits[b])[p] * x[b][p][c];  one block per image
+__global__ __launch_bounds__(512) void gc_pool_kernel(const float* __restrict__ x, const float* __restrict__ logits,
+                                                      float* __restrict__ ctx, int HW, int C) {
+  __shared__ float red[16], wts[512];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* l = logits + (size_t)b * HW;
+  float m = -INFINITY;
+  for (int p = tid; p < HW; p += 512) m = fmaxf(m, l[p]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int p = tid; p < HW; p += 512) sum += expf(l[p] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[8 + wave] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tot += red[8 + w];
+  const float inv = 1.f / tot;
+  float acc = 0.f;  // thread = channel (C <= 512)
+  for (int p0 = 0; p0 < HW; p0 += 512) {
+    __syncthreads();
+    if (p0 + tid < HW) wts[tid] = expf(l[p0 + tid] - m) * inv;
+    __syncthreads();
+    const int n = HW - p0 < 512 ? HW - p0 : 512;
+    if (tid < C)
+      for (int p = 0; p < n; ++p) acc = fmaf(wts[p], x[((size_t)b * HW + p0 + p) * C + tid], acc);
+  }
+  if (tid < C) ctx[(size_t)b * C + tid] = acc;
+}
+// y[b] = fc2(relu(LayerNorm(fc1(ctx[b]))));  one block per image, thread = output channel (C <= 512)
+__global__ __launch_bounds__(512) void gc_mlp_kernel(const float* __restrict__ ctx, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ g,
+                                                     const float* __restrict__ be, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ y, int C) {
+  __shared__ float v[512], h[512], red[16];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < C) v[tid] = ctx[(size_t)b * C + tid];
+  __syncthreads();
+  float a = 0.f;
+  if (tid < C) {
+    a = b1[tid];
+    for (int k = 0; k < C; ++k) a = fmaf(v[k], w1[(size_t)tid * C + k], a);
+  }
+  float s = wave_sum(tid < C ? a : 0.f);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) mean += red[w];
+  mean /= C;
+  const float d = tid < C ? a - mean : 0.f;
+  float q = wave_sum(d * d);
+  if (lane == 0) red[8 + wave] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) var += red[8 + w];
+  const float rstd = 1.f / sqrtf(var / C + 1e-5f);
+  if (tid < C) h[tid] = fmaxf(d * rstd * g[tid] + be[tid], 0.f);
+  __syncthreads();
+  if (tid < C) {
+    float o = b2[tid];
+    for (int k = 0; k < C; ++k) o = fmaf(h[k], w2[(size_t)tid * C + k], o);
+    y[(size_t)b * C + tid] = o;
+  }
+}
+__global__ void gc_add_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n4, int HW, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int c = (int)(e % C);
+    const size_t b = e / ((size_t)HW * C);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(y + b * C + c);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+hipError_t launch_global_context(float* x, const GCParams& w, float* logits, float* ctx, float* y, int B, int HW, int C,
+                                 hipStream_t s) {
+  if (C > 512 || C % 4) return hipErrorInvalidValue;
+  const long long rows = (long long)B * HW;
+  hipLaunchKernelGGL(gc_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w.wg, w.bg, logits, rows, C);
+  hipLaunchKernelGGL(gc_pool_kernel, dim3(B), dim3(512), 0, s, x, logits, ctx, HW, C);
+  hipLaunchKernelGGL(gc_mlp_kernel, dim3(B), dim3(512), 0, s, ctx, w.w1, w.b1, w.ln_g, w.ln_b, w.w2, w.b2, y, C);
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(gc_add_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 1u << 20)), dim3(256), 0, s, x, y, n4,
+                     HW, C);
+  return hipGetLastError();
+}
+
 }  // namespace d2t

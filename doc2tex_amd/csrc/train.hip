@@ -693,6 +693,7 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (g.encoder != D2T_ENC_HYBRID_VIT && g.encoder != D2T_ENC_RESNET)
     return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT and ResNet+None encoders");
   if (L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
+  if (g.gcb) return fail(c, D2T_ESTATE, "the training step does not support GlobalContext blocks (gcb)");
   if (!c->train) c->train = new d2t_train_state();
   d2t_train_state* st = c->train;
   st->tape.reset();

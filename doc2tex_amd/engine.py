@@ -28,8 +28,7 @@ def config_from_opt(opt):
                                       "(PatchEmbed returns a 3-tuple, SURVEY.md 3 notes)")
         if not sp.get("fix_embed", False) or sp.get("patching_style") != "2d":
             raise NotImplementedError("only fix_embed=True, patching_style='2d' (ViTEncoderV3) is accelerated")
-        if bbp.get("gcb", False):
-            raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
+        cfg.gcb = int(bool(bbp.get("gcb", False)))
         cfg.encoder = _lib.ENC_HYBRID_VIT
         cfg.in_channels = int(bbp["input_channel"])
         cfg.backbone_out = int(bbp["output_channel"])
@@ -39,8 +38,9 @@ def config_from_opt(opt):
         cfg.patch_h, cfg.patch_w = int(ps[0]), int(ps[1])
     elif feat in ("ResNet", "VGG") and seq in ("None", "BiLSTM"):
         fp = opt["FeatureExtraction"]["params"]
-        if fp.get("gcb", False):
-            raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
+        if fp.get("gcb", False) and feat == "VGG":
+            raise NotImplementedError("gcb is a ResNet option")
+        cfg.gcb = int(bool(fp.get("gcb", False))) if feat == "ResNet" else 0
         cfg.in_channels = int(fp["input_channel"])
         cfg.backbone_out = int(fp["output_channel"])
         if seq == "BiLSTM":

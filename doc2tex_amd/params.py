@@ -32,11 +32,35 @@ class BasicBlockParams(_Holder):
         self.downsample = downsample
 
 
-class ResNetParams(_Holder):
-    """ResNet, feature_extractor/resnet.py:51-177 (gcb off)."""
+class _ConvMLPParams(_Holder):
+    """ConvMLP, addon_module/visual_attention.py:85-102.  Its `hidden_channels = in_channels or hidden_channels`
+    (:89) makes the hidden width equal to the input width whatever `rd_channels` says."""
 
-    def __init__(self, input_channel, output_channel):
+    def __init__(self, channels):
         super().__init__()
+        self.fc1 = nn.Conv2d(channels, channels, 1, bias=True)
+        self.norm = nn.LayerNorm(channels)  # LayerNorm2d
+        self.fc2 = nn.Conv2d(channels, channels, 1, bias=True)
+
+
+class GlobalContextParams(_Holder):
+    """GlobalContext(channel) with its defaults use_attn=True, fuse_add=True, fuse_scale=False
+    (visual_attention.py:105-165)."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.global_cxt = nn.Conv2d(channel, 1, 1, bias=True)
+        self.bottleneck_add = _ConvMLPParams(channel)
+        nn.init.kaiming_normal_(self.global_cxt.weight, mode="fan_in", nonlinearity="relu")
+        nn.init.zeros_(self.bottleneck_add.fc2.weight)
+
+
+class ResNetParams(_Holder):
+    """ResNet, feature_extractor/resnet.py:51-177."""
+
+    def __init__(self, input_channel, output_channel, with_gcb=False):
+        super().__init__()
+        self.with_gcb = with_gcb
         oc = [output_channel // 4, output_channel // 2, output_channel, output_channel]
         self.inplanes = output_channel // 8
         self.conv0_1 = nn.Conv2d(input_channel, output_channel // 16, 3, 1, 1, bias=False)
@@ -71,6 +95,8 @@ class ResNetParams(_Holder):
         layers = [BasicBlockParams(self.inplanes, planes, downsample)]
         self.inplanes = planes
         layers += [BasicBlockParams(planes, planes, None) for _ in range(1, blocks)]
+        if self.with_gcb:  # resnet.py:200-201
+            layers.append(GlobalContextParams(planes))
         return nn.Sequential(*layers)
 
 
@@ -79,11 +105,9 @@ class ResNetFeatureExtractorParams(_Holder):
 
     def __init__(self, input_channel=3, output_channel=512, gcb=False, pretrained=False, weight_dir=None, debug=False):
         super().__init__()
-        if gcb:
-            raise NotImplementedError("GlobalContext blocks (gcb=True) are not on the accelerated path")
         if pretrained:
             raise NotImplementedError("load weights through load_state_dict / load_checkpoint")
-        self.ConvNet = ResNetParams(input_channel, output_channel)
+        self.ConvNet = ResNetParams(input_channel, output_channel, with_gcb=bool(gcb))
         self.in_chans = input_channel
 
 

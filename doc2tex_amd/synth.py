@@ -119,6 +119,11 @@ _CONFIGS["S0"] = {
     "_crop": (128, 512),
     "_batch": 4,
 }
+# GlobalContext blocks on (gcb: True; off in every shipped config): tiny HybridViT and tiny ResNet + TFM
+_CONFIGS["T2G"] = copy.deepcopy(_CONFIGS["T2"])
+_CONFIGS["T2G"]["SequenceModeling"]["params"]["backbone"]["gcb"] = True
+_CONFIGS["T1G"] = copy.deepcopy(_CONFIGS["T1"])
+_CONFIGS["T1G"]["FeatureExtraction"]["params"]["gcb"] = True
 _CONFIGS["TS0"] = copy.deepcopy(_CONFIGS["S0"])  # tiny S0
 _CONFIGS["TS0"]["SequenceModeling"] = _vit_seq(depth=2)
 _CONFIGS["TS0"]["max_dimension"] = [48, 64]

@@ -93,6 +93,7 @@ typedef struct d2t_config {
   int32_t attn_coverage;    /* 1 = attn_type 'coverage' (accumulated alignment), 0 = 'loc_aware' */
   int32_t bilstm_hidden;    /* SequenceModeling.params.hidden_size of the BiLSTM, 256 */
   int32_t batch_max_length; /* Attn decoders run batch_max_length + 1 steps */
+  int32_t gcb;              /* 1: GlobalContext blocks close the four ResNet stages (gcb: True) */
 } d2t_config;
 
 /* ---- lifecycle ---------------------------------------------------------- */

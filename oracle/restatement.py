@@ -72,6 +72,21 @@ def _basic_block(x, sd, p, faithful, bn_train=None):
     return F.relu(out + x)
 
 
+def _global_context(x, sd, p):
+    """GlobalContext.forward with use_attn / fuse_add (addon_module/visual_attention.py:147-165): 1x1 conv -> softmax
+    over H*W -> attention-pooled channel vector -> ConvMLP (fc1, LayerNorm2d, ReLU, dropout (eval: off), fc2; the hidden
+    width equals the channel count, :88-89) -> added to every position."""
+    B, C, H, W = x.shape
+    attn = F.conv2d(x, sd[p + "global_cxt.weight"], sd[p + "global_cxt.bias"]).reshape(B, H * W)
+    attn = F.softmax(attn, dim=-1).unsqueeze(-1)
+    ctx = torch.bmm(x.reshape(B, C, H * W), attn).unsqueeze(-1)  # [B,C,1,1]
+    m = p + "bottleneck_add."
+    h = F.conv2d(ctx, sd[m + "fc1.weight"], sd[m + "fc1.bias"])
+    h = F.layer_norm(h.permute(0, 2, 3, 1), (h.shape[1],), sd[m + "norm.weight"], sd[m + "norm.bias"], 1e-5).permute(0, 3, 1, 2)
+    h = F.conv2d(F.relu(h), sd[m + "fc2.weight"], sd[m + "fc2.bias"])
+    return x + h
+
+
 def resnet(x, sd, p, faithful=True, bn_train=None):
     """ResNet.forward, resnet.py:205-245.  x [B,1,H,W] -> [B,512,H',W'] (NCHW)."""
     cb = lambda x, c, b, s=1, pd=1: F.relu(_conv_bn(x, sd, p + c, p + b, s, pd, faithful, bn_train))
@@ -80,17 +95,25 @@ def resnet(x, sd, p, faithful=True, bn_train=None):
     x = F.max_pool2d(x, 2, 2, 0)  # :94
     for i in range(RESNET_LAYERS[0]):
         x = _basic_block(x, sd, f"{p}layer1.{i}", faithful, bn_train)
+    if f"{p}layer1.{RESNET_LAYERS[0]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
+        x = _global_context(x, sd, f"{p}layer1.{RESNET_LAYERS[0]}.")
     x = cb(x, "conv1", "bn1")
     x = F.max_pool2d(x, 2, 2, 0)  # :106
     for i in range(RESNET_LAYERS[1]):
         x = _basic_block(x, sd, f"{p}layer2.{i}", faithful, bn_train)
+    if f"{p}layer2.{RESNET_LAYERS[1]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
+        x = _global_context(x, sd, f"{p}layer2.{RESNET_LAYERS[1]}.")
     x = cb(x, "conv2", "bn2")
     x = F.max_pool2d(x, 2, (2, 1), (0, 1))  # :120, implicit -inf padding
     for i in range(RESNET_LAYERS[2]):
         x = _basic_block(x, sd, f"{p}layer3.{i}", faithful, bn_train)
+    if f"{p}layer3.{RESNET_LAYERS[2]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
+        x = _global_context(x, sd, f"{p}layer3.{RESNET_LAYERS[2]}.")
     x = cb(x, "conv3", "bn3")
     for i in range(RESNET_LAYERS[3]):
         x = _basic_block(x, sd, f"{p}layer4.{i}", faithful, bn_train)
+    if f"{p}layer4.{RESNET_LAYERS[3]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
+        x = _global_context(x, sd, f"{p}layer4.{RESNET_LAYERS[3]}.")
     x = cb(x, "conv4_1", "bn4_1", (2, 1), (0, 1))  # :139-147
     x = cb(x, "conv4_2", "bn4_2", 1, 0)  # :149-157
     return x

@@ -49,25 +49,43 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _run_world(worker, world=2, attempts=3):
+    """Spawn `world` ranks of `worker(rank, world, port, queue)`; returns what rank 0 put on the queue.  The
+    rendezvous port is picked by binding port 0 and releasing it, so a collision with another process is possible:
+    retry on a fresh port if a rank dies before producing a result."""
+    last = None
+    for _ in range(attempts):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            out = q.get(timeout=300)
+        except Exception as e:  # noqa: BLE001 - queue.Empty or a broken pipe: clean up and retry
+            last = e
+            out = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if out is not None and all(p.exitcode == 0 for p in procs):
+            return out
+        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
+    raise last
+
+
 def _until_end(row):
     row = row.tolist()
     return row[: row.index(2) + 1] if 2 in row else row
 
 
 def test_sharded_decode_matches_single_process():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    toks, full = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    toks, full = _run_world(_worker)
     assert toks.shape[0] == full.shape[0] == 5
     # shard step counts differ (per-batch early exit), tokens up to each row's [s] are shard-invariant
     for a, b in zip(toks, full):
@@ -110,18 +128,6 @@ def _grad_worker(rank, world, port, q):
 def test_gradient_allreduce_is_bucketed_mean_over_ranks():
     """Data-parallel training exchange (config C3): GradSync returns the rank-mean of every gradient, in several
     buckets, with views shaped like the parameters."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    worst, nbuckets, nparams = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    worst, nbuckets, nparams = _run_world(_grad_worker)
     assert nparams == 164 and nbuckets >= 5  # ~56 M fp32 gradients in 8 MB buckets (some tensors exceed a bucket)
     assert worst <= 1e-7

@@ -12,7 +12,7 @@ from oracle import restatement as R
 
 # the two full-size greedy cases take ~15 s each on 8 cores; everything else is seconds
 GREEDY = ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_small_crop", "c2_greedy", "c1_greedy",
-          "c0_greedy", "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop"]
+          "c0_greedy", "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy"]
 
 
 def _case(cases, kind, name):

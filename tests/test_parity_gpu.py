@@ -33,7 +33,7 @@ def _run_engine(c, B=None):
 
 @pytest.mark.parametrize("name", ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_small_crop",
                                   "c2_greedy", "c1_greedy", "c0_greedy", "c0_greedy_early", "ts0_greedy",
-                                  "s0_greedy", "s0_small_crop"])
+                                  "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy"])
 def test_greedy_vs_reference_fixture(cases, name):
     c = _case(cases, "greedy", name)
     z = np.load(os.path.join(GOLD, name + ".npz"))

@@ -54,6 +54,9 @@ GREEDY_CASES = [
     ("ts0_greedy", "TS0", 2, 48, 64, 12, 1234, 1008, 0.0, False),
     ("s0_greedy", "S0", 2, 128, 512, 30, 1234, 1009, 0.0, False),
     ("s0_small_crop", "S0", 1, 96, 384, 10, 1234, 1013, 0.0, True),
+    # GlobalContext blocks on (gcb: True, addon_module/visual_attention.py:105-165)
+    ("t2g_greedy", "T2G", 2, 48, 64, 12, 1234, 1014, 0.0, False),
+    ("t1g_greedy", "T1G", 2, 32, 64, 12, 1234, 1015, 0.0, False),
 ]
 BEAM_CASES = [
     ("t2_beam5", "T2", 48, 64, 16, 1234, 1010, 1.8, 5),
@@ -313,6 +316,23 @@ def main():
     torch.manual_seed(0)
     summary = {"greedy": [], "beam": [], "train": [], "train_step": []}
     manifests = {}
+    if os.environ.get("GOLDEN_ONLY") == "gcb":  # add / refresh only the GlobalContext greedy fixtures
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        with open(os.path.join(GOLD, "manifests.json")) as f:
+            manifests = json.load(f)
+        for case in GREEDY_CASES:
+            if not case[0].endswith("g_greedy"):
+                continue
+            rep, man, cname = run_greedy(case)
+            manifests[cname] = man
+            summary["greedy"] = [r for r in summary["greedy"] if r["case"] != rep["case"]] + [rep]
+            print("greedy", rep["case"], "steps", rep["steps"], "dmem", rep["diff_mem_folded"], "dlogit", rep["diff_logits_cached"], flush=True)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+            json.dump(manifests, f)
+        return
     if os.environ.get("GOLDEN_ONLY") == "attn_beam":  # refresh only the LSTM beam fixtures
         with open(os.path.join(GOLD, "cases.json")) as f:
             summary = json.load(f)
