@@ -231,3 +231,36 @@ def test_bf16x3_convolutions_keep_parity(cases, name):
     steps = z["logit_steps"].tolist()
     dl = float(np.abs(logits[:, steps].cpu().numpy() - z["logits_sample"]).max())
     assert dl <= LOGIT_TOL, dl
+
+
+@pytest.mark.parametrize("cname,H,W,B,precision", [
+    ("T2", 48, 64, 1, "fp32"), ("T2", 45, 63, 3, "bf16x3"), ("T2", 35, 61, 2, "fp32"), ("T2", 47, 61, 5, "bf16x3"),
+    ("T1", 32, 64, 1, "bf16x3"), ("T1", 45, 99, 3, "fp32"), ("T1", 63, 130, 2, "bf16x3"),
+    ("TS0", 48, 64, 3, "bf16x3"), ("T2G", 41, 59, 2, "bf16x3"),
+])
+def test_odd_crop_shapes_and_batch_sizes(manifests, cname, H, W, B, precision):
+    """Ragged geometry: odd heights / widths (every pool and strided conv floors differently), batch sizes that are not
+    a multiple of anything, both arithmetic modes -- encoder memory and greedy tokens against the oracle."""
+    L = 10
+    cfg, m = engine_model(cname, L)
+    # max_dimension of the tiny configs is their nominal crop; larger crops need a larger positional table
+    ocfg, sd = oracle_state_dict(cname, manifests[cname], L)
+    if cfg["SequenceModeling"]["name"] == "ViT" and (H > cfg["max_dimension"][0] or W > cfg["max_dimension"][1]):
+        pytest.skip("crop exceeds max_dimension")
+    m.conv_precision = precision
+    img = synth.synth_images(B, H, W, seed=700 + H + W)
+    attn = cfg["Prediction"]["name"] != "TFM"
+    text = torch.zeros(B, L + 1, dtype=torch.long) if attn else torch.full((B, 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        omem, oshape, opad = R.forward_encoder(ocfg, sd, img, faithful=False)
+        opreds, ologits, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=False)
+        mem, shape, pad = m.forward_encoder(img.cuda())
+        preds, logits, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=False)
+    torch.cuda.synchronize()
+    assert tuple(mem.shape) == tuple(omem.shape)
+    assert (tuple(shape) if shape else None) == (tuple(oshape) if oshape else None)
+    assert (tuple(pad) if pad else None) == (tuple(opad) if opad else None)
+    scale = max(1.0, float(omem.abs().max()))
+    assert float((mem.cpu() - omem).abs().max()) / scale <= (5e-4 if precision == "bf16x3" else 1e-4)
+    assert torch.equal(preds.cpu(), opreds)
+    assert float((logits.cpu() - ologits).abs().max()) <= LOGIT_TOL
