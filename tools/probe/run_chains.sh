@@ -1,4 +1,4 @@
 set -e
-python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "pipelined or headline" 2>&1 | tail -3
-python bench.py --no-cpu-baseline 2>/dev/null | python tools/bench_line.py default
-python bench.py --steps 20 --warmup 6 --no-cpu-baseline 2>/dev/null | python tools/bench_line.py steps20
+for cfg in "2 32" "2 48" "2 64" "2 80" "2 96"; do set -- $cfg
+python bench.py --steps 20 --warmup 6 --no-cpu-baseline --chains $1 --reserve $2 2>/dev/null | python tools/bench_line.py "chains$1-reserve$2"
+done
