@@ -152,3 +152,33 @@ def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, ref[k]), k
+
+
+def test_grad_sync_over_rccl_single_rank(cases, manifests):
+    """The same path with real RCCL collectives (backend "nccl", a one-rank group on this GPU): bucket copies on the
+    communication stream, async all-reduce per bucket, hand-back to the compute stream -- gradients unchanged."""
+    import socket
+
+    import torch.distributed as dist
+    from doc2tex_amd.dist import GradSync
+    c = _case(cases, "train_step", "t2_train_step")
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    _step(m, img, text)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        m.load_state_dict(state0)
+        m.grad_sync = GradSync(bucket_bytes=16 << 20, always_reduce=True)
+        _step(m, img, text)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, ref[k]), k
+    finally:
+        dist.destroy_process_group()
