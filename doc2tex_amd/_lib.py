@@ -51,6 +51,9 @@ SIGNATURES = {
     "d2t_train_backward": (_I, [_P, _P, _P]),
     "d2t_train_grad": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "d2t_read_weight": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "d2t_train_set_dropout": (_I, [_P, C.c_float, C.c_uint64]),
+    "d2t_train_mask_count": (_I, [_P]),
+    "d2t_train_read_mask": (_I, [_P, _I, _P, C.c_int64, _P]),
     "d2t_train_release": (None, [_P]),
     "d2t_profile_enable": (_I, [_P, _I]),
     "d2t_profile_read": (_I, [_P, _I, C.POINTER(_I)] + [C.POINTER(_I)] * 3 + [C.POINTER(C.c_float)]),

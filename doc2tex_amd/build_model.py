@@ -196,8 +196,6 @@ class Model(nn.Module):
                 raise NotImplementedError("the training step is implemented for the HybridViT + TFM and ResNet + TFM stacks")
             if self.engine(finalize=False).cfg.gcb:
                 raise NotImplementedError("training with GlobalContext blocks (gcb: True) is not implemented in the HIP engine")
-            if self.opt["Prediction"]["params"].get("dropout", 0.0) != 0.0:
-                raise NotImplementedError("training with dropout > 0 is not implemented in the HIP engine")
             logits = train_forward(self, input, text)
             return logits.argmax(dim=2), logits, {}
         contextual_feature, output_shape, feat_pad = self.forward_encoder(input)

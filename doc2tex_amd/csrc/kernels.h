@@ -253,6 +253,8 @@ struct AttnTrainP {
   float *dq, *dk, *dv;     // backward outputs (q / k / v strides)
   const int64_t* keytok;   // optional [B][Lk]: keys whose token == pad_id are masked
   int B, heads, hd, Lq, Lk, ldq, ldk, ldv, ldo, causal, pad_id;
+  const uint8_t* dropmask; // optional [B][heads][Lq][Lk] keep mask of the attention-probability dropout
+  float dropscale;         // 1 / (1 - p)
 };
 hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s);
 hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s);
@@ -260,6 +262,11 @@ hipError_t launch_embed_train(const float* E, const float* pe, const int64_t* to
                               float scale, hipStream_t s);
 hipError_t launch_embed_bwd(const float* dx, const int64_t* tok, float* dE, int rows, int V, int D, float scale, int pad_id,
                             hipStream_t s);
+// mask[i] = 1 with probability 1 - p (Philox4x32-10 keyed by (seed, stream), counter = i / 8), else 0
+hipError_t launch_dropout_mask(uint8_t* mask, size_t n, float p, unsigned long long seed, unsigned long long stream_id,
+                               hipStream_t s);
+// out = a * mask * scale
+hipError_t launch_apply_mask(const float* a, const uint8_t* mask, float scale, float* out, size_t n, hipStream_t s);
 hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s);
 hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
                          int offw, hipStream_t s);

@@ -51,7 +51,7 @@ struct TT {  // tensor on the tape
   float* grad = nullptr;
 };
 
-enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST };
+enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD };
 
 struct Node {
   Kind kind;
@@ -73,6 +73,9 @@ struct Node {
   float* probs = nullptr;
   // N_TOKENS: out[b][0] = cls + pos[0], out[b][1+i] = in[b][i] + pos[1+i]   (in = patch tokens)
   int ntok = 0;
+  // N_DROPOUT / N_ATTN: keep mask (bytes) and 1 / (1 - p)
+  const uint8_t* mask = nullptr;
+  float mscale = 1.f;
 };
 
 }  // namespace
@@ -88,6 +91,10 @@ struct d2t_train_state {
   float* scratch = nullptr; size_t scratch_cap = 0;
   const int64_t* tgt = nullptr;
   const float* image = nullptr;
+  // dropout of nn.TransformerDecoderLayer (d2t_train_set_dropout): Philox masks keyed by (seed, forward call, site)
+  float drop_p = 0.f;
+  unsigned long long drop_seed = 0, drop_calls = 0, drop_site = 0;
+  std::vector<std::pair<const uint8_t*, size_t>> masks;  // in creation order (d2t_train_read_mask)
   int B = 0, H = 0, W = 0, L = 0;
   int logits_id = -1;
   bool have_forward = false;
@@ -360,18 +367,58 @@ struct Tr {  // builder / runner bound to one context and stream
     return D2T_OK;
   }
   int attention(int qt, int qoff, int kvt, int koff, int voff, int nb, int Lq, int Lk, int heads, int hd, int causal,
-                const int64_t* keytok, int* out) {
+                const int64_t* keytok, int* out, bool attn_dropout = false) {
     Node n;
     n.kind = N_ATTN; n.in = qt; n.in2 = kvt; n.qoff = qoff; n.koff = koff; n.voff = voff; n.nb = nb; n.Lq = Lq; n.Lk = Lk;
     n.heads = heads; n.hd = hd; n.causal = causal; n.keytok = keytok;
     RC(alloc(&n.probs, (size_t)nb * heads * Lq * Lk));
+    if (attn_dropout) {  // nn.MultiheadAttention(dropout=p): on the softmax probabilities
+      RC(new_mask((size_t)nb * heads * Lq * Lk, &n.mask));
+      n.mscale = 1.f / (1.f - st->drop_p);
+    }
     RC(new_tensor((long long)nb * Lq, heads * hd, out));
     AttnTrainP p{};
+    p.dropmask = n.mask; p.dropscale = n.mscale;
     p.q = st->t[qt].p + qoff; p.k = st->t[kvt].p + koff; p.v = st->t[kvt].p + voff; p.o = st->t[*out].p; p.probs = n.probs;
     p.keytok = keytok; p.B = nb; p.heads = heads; p.hd = hd; p.Lq = Lq; p.Lk = Lk;
     p.ldq = st->t[qt].cols; p.ldk = p.ldv = st->t[kvt].cols; p.ldo = heads * hd; p.causal = causal; p.pad_id = 0;
     TCHK(launch_attn_train_fwd(p, s));
     n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  // a fresh keep mask of n elements (nullptr when dropout is off)
+  int new_mask(size_t n, const uint8_t** m) {
+    *m = nullptr;
+    if (st->drop_p <= 0.f) return D2T_OK;
+    float* raw;
+    RC(alloc(&raw, n / 4 + 2));
+    uint8_t* mk = reinterpret_cast<uint8_t*>(raw);
+    TCHK(launch_dropout_mask(mk, n, st->drop_p, st->drop_seed, (st->drop_calls << 16) | st->drop_site, s));
+    ++st->drop_site;
+    st->masks.push_back({mk, n});
+    *m = mk;
+    return D2T_OK;
+  }
+  // nn.Dropout(p): out = in * mask / (1 - p); identity (no node) when p == 0
+  int dropout(int in, int* out) {
+    if (st->drop_p <= 0.f) { *out = in; return D2T_OK; }
+    const TT x = st->t[in];
+    Node n;
+    n.kind = N_DROPOUT; n.in = in; n.mscale = 1.f / (1.f - st->drop_p);
+    RC(new_mask((size_t)x.rows * x.cols, &n.mask));
+    RC(new_tensor(x.rows, x.cols, out));
+    TCHK(launch_apply_mask(x.p, n.mask, n.mscale, st->t[*out].p, (size_t)x.rows * x.cols, s));
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int add(int a, int b, int* out) {
+    const TT x = st->t[a];
+    RC(new_tensor(x.rows, x.cols, out));
+    TCHK(launch_ew(x.p, st->t[b].p, st->t[*out].p, (size_t)x.rows * x.cols, EW_ADD, s));
+    Node n;
+    n.kind = N_ADD; n.in = a; n.in2 = b; n.out = *out;
     st->nodes.push_back(n);
     return D2T_OK;
   }
@@ -455,20 +502,43 @@ struct Tr {  // builder / runner bound to one context and stream
     Node en;
     en.kind = N_EMBED; en.out = x; en.wkey = p + "word_embed.weight";
     st->nodes.push_back(en);
+    const bool dp = st->drop_p > 0.f;
     for (int l = 0; l < g.dec_layers; ++l) {
       const std::string lp = p + "model.layers." + std::to_string(l) + ".";
       int qkv, a, y1, x1, q2, kv, a2, y2, x2, f, y3, x3;
       RC(linear(x, lp + "self_attn.in_proj", 3 * D, D, 0, ACT_NONE, -1, &qkv));
-      RC(attention(qkv, 0, qkv, D, 2 * D, B, L, L, heads, hd, 1, tgt, &a));
-      RC(linear(a, lp + "self_attn.out_proj", D, D, 0, ACT_NONE, x, &y1));
+      RC(attention(qkv, 0, qkv, D, 2 * D, B, L, L, heads, hd, 1, tgt, &a, dp));
+      if (!dp) {
+        RC(linear(a, lp + "self_attn.out_proj", D, D, 0, ACT_NONE, x, &y1));
+      } else {  // x + dropout1(self_attn(x)): the residual add can no longer ride in the GEMM epilogue
+        int z, d;
+        RC(linear(a, lp + "self_attn.out_proj", D, D, 0, ACT_NONE, -1, &z));
+        RC(dropout(z, &d));
+        RC(add(x, d, &y1));
+      }
       RC(layernorm(y1, lp + "norm1", 1e-5f, &x1));
       RC(linear(x1, lp + "multihead_attn.in_proj", D, D, 0, ACT_NONE, -1, &q2));
       RC(linear(mem, lp + "multihead_attn.in_proj", 2 * D, D, D, ACT_NONE, -1, &kv));
-      RC(attention(q2, 0, kv, 0, D, B, L, T, heads, hd, 0, nullptr, &a2));
-      RC(linear(a2, lp + "multihead_attn.out_proj", D, D, 0, ACT_NONE, x1, &y2));
+      RC(attention(q2, 0, kv, 0, D, B, L, T, heads, hd, 0, nullptr, &a2, dp));
+      if (!dp) {
+        RC(linear(a2, lp + "multihead_attn.out_proj", D, D, 0, ACT_NONE, x1, &y2));
+      } else {
+        int z, d;
+        RC(linear(a2, lp + "multihead_attn.out_proj", D, D, 0, ACT_NONE, -1, &z));
+        RC(dropout(z, &d));
+        RC(add(x1, d, &y2));
+      }
       RC(layernorm(y2, lp + "norm2", 1e-5f, &x2));
       RC(linear(x2, lp + "linear1", g.dec_ff, D, 0, ACT_RELU, -1, &f));
-      RC(linear(f, lp + "linear2", D, g.dec_ff, 0, ACT_NONE, x2, &y3));
+      if (!dp) {
+        RC(linear(f, lp + "linear2", D, g.dec_ff, 0, ACT_NONE, x2, &y3));
+      } else {  // x + dropout3(linear2(dropout(relu(linear1(x)))))
+        int fd, z, d;
+        RC(dropout(f, &fd));
+        RC(linear(fd, lp + "linear2", D, g.dec_ff, 0, ACT_NONE, -1, &z));
+        RC(dropout(z, &d));
+        RC(add(x2, d, &y3));
+      }
       RC(layernorm(y3, lp + "norm3", 1e-5f, &x3));
       x = x3;
     }
@@ -548,6 +618,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.dq = st->t[n.in].grad + n.qoff; p.dk = st->t[n.in2].grad + n.koff; p.dv = st->t[n.in2].grad + n.voff;
     p.B = n.nb; p.heads = n.heads; p.hd = n.hd; p.Lq = n.Lq; p.Lk = n.Lk;
     p.ldq = st->t[n.in].cols; p.ldk = p.ldv = st->t[n.in2].cols; p.ldo = n.heads * n.hd;
+    p.dropmask = n.mask; p.dropscale = n.mscale;
     TCHK(launch_attn_train_bwd(p, s));
     return D2T_OK;
   }
@@ -656,6 +727,27 @@ struct Tr {  // builder / runner bound to one context and stream
         case N_POOL: RC(bwd_pool(n)); break;
         case N_TOKENS: RC(bwd_tokens(n)); break;
         case N_ADDCONST: RC(add_grad(n.in, st->t[n.out].grad)); break;
+        case N_DROPOUT: {
+          const TT& x = st->t[n.in];
+          float* dx;
+          RC(alloc(&dx, (size_t)x.rows * x.cols));
+          TCHK(launch_apply_mask(st->t[n.out].grad, n.mask, n.mscale, dx, (size_t)x.rows * x.cols, s));
+          RC(add_grad(n.in, dx));
+          break;
+        }
+        case N_ADD: {  // both operands receive the gradient; the second gets its own copy unless it only accumulates
+          float* g = st->t[n.out].grad;
+          RC(add_grad(n.in, g));
+          if (!st->t[n.in2].grad) {
+            const TT& y = st->t[n.out];
+            float* cp;
+            RC(alloc(&cp, (size_t)y.rows * y.cols));
+            TCHK(launch_copy(g, cp, (size_t)y.rows * y.cols, s));
+            g = cp;
+          }
+          RC(add_grad(n.in2, g));
+          break;
+        }
         case N_GELU: {
           const TT& x = st->t[n.in];
           float* dx;
@@ -700,6 +792,9 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   st->t.clear();
   st->nodes.clear();
   st->have_forward = false;
+  st->masks.clear();
+  st->drop_site = 0;
+  ++st->drop_calls;
   st->tgt = tgt; st->image = image; st->B = B; st->H = H; st->W = W; st->L = L;
   Tr tr{c, st, (hipStream_t)stream};
   int feat, mem, out;
@@ -753,6 +848,26 @@ int d2t_read_weight(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t
   HIPCHK(c, hipMemcpyAsync(dst, r->p, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return D2T_OK;
 }
+
+int d2t_train_set_dropout(d2t_ctx* c, float p, uint64_t seed) {
+  if (!c || !(p >= 0.f) || p >= 1.f) return fail(c, D2T_EINVAL, "dropout probability must be in [0, 1)");
+  if (!c->train) c->train = new d2t_train_state();
+  if (c->train->drop_seed != seed) c->train->drop_calls = 0;
+  c->train->drop_p = p;
+  c->train->drop_seed = seed;
+  return D2T_OK;
+}
+
+int d2t_train_read_mask(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t numel, d2t_stream stream) {
+  if (!c || !dst) return fail(c, D2T_EINVAL, "bad argument");
+  d2t_train_state* st = c->train;
+  if (!st || index < 0 || (size_t)index >= st->masks.size()) return fail(c, D2T_EINVAL, "no dropout mask %d", index);
+  if ((int64_t)st->masks[index].second != numel) return fail(c, D2T_EINVAL, "mask %d has %zu elements", index, st->masks[index].second);
+  HIPCHK(c, hipMemcpyAsync(dst, st->masks[index].first, (size_t)numel, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return D2T_OK;
+}
+
+int d2t_train_mask_count(d2t_ctx* c) { return c && c->train ? (int)c->train->masks.size() : 0; }
 
 void d2t_train_release(d2t_ctx* c) {
   if (c && c->train) {

@@ -551,10 +551,11 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const AttnTrainP p)
     sum = wsum(sum);
     const float inv = 1.f / sum;
     float* prow = p.probs + (((size_t)b * p.heads + hh) * p.Lq + i) * p.Lk;
+    const uint8_t* mrow = p.dropmask ? p.dropmask + (((size_t)b * p.heads + hh) * p.Lq + i) * p.Lk : nullptr;
     for (int j = lane; j < p.Lk; j += 64) {
       const float w = P[j] * inv;
-      P[j] = w;
-      prow[j] = w;
+      prow[j] = w;                                            // saved: the softmax itself
+      P[j] = mrow ? w * (mrow[j] ? p.dropscale : 0.f) : w;    // used: after dropout (nn.MultiheadAttention dropout)
     }
     // o[c] = sum_j P[j] * V[j][c]: lane -> (c = lane % HD, key phase = lane / HD)
     constexpr int PH = 64 / HD;
@@ -603,10 +604,15 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
   float* probs = p.probs + ((size_t)b * p.heads + hh) * p.Lq * p.Lk;
   constexpr int PH = 64 / HD;
   const int c = lane % HD, ph = lane / HD;
-  // phase 1: dV[j][c] = sum_i P[i][j] * dO[i][c]   (wave per key)
+  const uint8_t* dmask = p.dropmask ? p.dropmask + ((size_t)b * p.heads + hh) * p.Lq * p.Lk : nullptr;
+  // phase 1: dV[j][c] = sum_i (P o D)[i][j] * dO[i][c]   (wave per key; D = dropout keep mask * scale)
   for (int j = wave; j < p.Lk; j += 4) {
     float a = 0.f;
-    for (int i = ph; i < p.Lq; i += PH) a = fmaf(probs[(size_t)i * p.Lk + j], p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c], a);
+    for (int i = ph; i < p.Lq; i += PH) {
+      float w = probs[(size_t)i * p.Lk + j];
+      if (dmask) w *= dmask[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
+      a = fmaf(w, p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c], a);
+    }
     if (PH == 2) a += __shfl_xor(a, 32, 64);
     if (lane < HD) p.dv[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c] = a;
   }
@@ -619,11 +625,13 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
 #pragma unroll
     for (int cc = 0; cc < HD; ++cc) d_o[cc] = dop[cc];
     float* prow = probs + (size_t)i * p.Lk;
+    const uint8_t* mrow = dmask ? dmask + (size_t)i * p.Lk : nullptr;
     float dsum = 0.f;
     for (int j = lane; j < p.Lk; j += 64) {
       float dp = 0.f;
 #pragma unroll
       for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      if (mrow) dp *= mrow[j] ? p.dropscale : 0.f;
       dsum = fmaf(dp, prow[j], dsum);
     }
     dsum = wsum(dsum);
@@ -631,6 +639,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
       float dp = 0.f;
 #pragma unroll
       for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      if (mrow) dp *= mrow[j] ? p.dropscale : 0.f;
       const float ds = prow[j] * (dp - dsum);
       prow[j] = ds;  // read again by phase 3 (after the block barrier)
       Ds[wave * p.Lk + j] = ds;
@@ -676,7 +685,8 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
   float* probs = p.probs + ((size_t)b * p.heads + hh) * p.Lq * p.Lk;
   constexpr int CG = HD / 4;  // channels per wave
   // column reduction out[j][c] = alpha * sum_i M[i][j] * R[i][c]
-  auto colred = [&](const float* R, float* out, int ld, float alpha) {
+  const uint8_t* dmask = p.dropmask ? p.dropmask + ((size_t)b * p.heads + hh) * p.Lq * p.Lk : nullptr;
+  auto colred = [&](const float* R, float* out, int ld, float alpha, const uint8_t* dm) {
     for (int j0 = 0; j0 < p.Lk; j0 += 64) {
       const int j = j0 + lane;
       float acc[CG];
@@ -684,7 +694,8 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
       for (int c = 0; c < CG; ++c) acc[c] = 0.f;
       if (j < p.Lk) {
         for (int i = 0; i < p.Lq; ++i) {
-          const float m = probs[(size_t)i * p.Lk + j];
+          float m = probs[(size_t)i * p.Lk + j];
+          if (dm) m *= dm[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
           const float* r = R + i * HD + wave * CG;
 #pragma unroll
           for (int c = 0; c < CG; ++c) acc[c] = fmaf(m, r[c], acc[c]);
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
       }
     }
   };
-  colred(dOs, p.dv, p.ldv, 1.f);  // phase 1: dV = P^T dO
+  colred(dOs, p.dv, p.ldv, 1.f, dmask);  // phase 1: dV = (P o D)^T dO
   __syncthreads();
   const float scale = rsqrtf((float)HD);
   constexpr int PH = 64 / HD;
@@ -708,6 +719,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
       float dp = 0.f;
 #pragma unroll
       for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      if (dmask) dp *= dmask[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
       Ds[wave * p.Lk + j] = dp;
       dsum = fmaf(dp, prow[j], dsum);
     }
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
     if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
   }
   __syncthreads();
-  colred(Qs, p.dk, p.ldk, scale);  // phase 3: dK = scale * dS^T Q
+  colred(Qs, p.dk, p.ldk, scale, nullptr);  // phase 3: dK = scale * dS^T Q
 }
 
 hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s) {
@@ -781,6 +793,56 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __
 hipError_t launch_embed_bwd(const float* dx, const int64_t* tok, float* dE, int rows, int V, int D, float scale, int pad_id,
                             hipStream_t s) {
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, s, dx, tok, dE, rows, D, scale, pad_id);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Dropout: keep masks from Philox4x32-10 (counter-based, so forward and backward see the same mask without storing
+// random state; masks are materialised as bytes because several kernels consume them)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(unsigned long long counter, unsigned long long stream_id, unsigned k0, unsigned k1,
+                                           unsigned (&out)[4]) {
+  unsigned c0 = (unsigned)counter, c1 = (unsigned)(counter >> 32), c2 = (unsigned)stream_id, c3 = (unsigned)(stream_id >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, unsigned thresh16, unsigned long long seed,
+                                    unsigned long long stream_id) {
+  const size_t groups = (n + 7) / 8;  // eight 16-bit draws per Philox call
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
+    unsigned r[4];
+    philox4x32(g, stream_id, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = g * 8 + k;
+      if (i < n) mask[i] = ((r[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) >= thresh16 ? 1 : 0;
+    }
+  }
+}
+hipError_t launch_dropout_mask(uint8_t* mask, size_t n, float p, unsigned long long seed, unsigned long long stream_id,
+                               hipStream_t s) {
+  if (!n) return hipSuccess;
+  const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);  // drop when the 16-bit draw is below p * 2^16
+  const size_t groups = (n + 7) / 8;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)std::min<size_t>((groups + 255) / 256, 1u << 16)), dim3(256), 0, s, mask,
+                     n, thresh, seed, stream_id);
+  return hipGetLastError();
+}
+__global__ void apply_mask_kernel(const float* __restrict__ a, const uint8_t* __restrict__ m, float scale,
+                                  float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = m[i] ? a[i] * scale : 0.f;
+}
+hipError_t launch_apply_mask(const float* a, const uint8_t* mask, float scale, float* out, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, s, a, mask,
+                     scale, out, n);
   return hipGetLastError();
 }
 

@@ -155,6 +155,18 @@ class Engine:
                                                _lib.stream_of(image)), "train_forward")
         return logits
 
+    def set_dropout(self, p, seed):
+        """Dropout probability of the decoder layers in the training step and the seed of its Philox masks."""
+        self._check(self.lib.d2t_train_set_dropout(self.ctx, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF), "train_set_dropout")
+
+    def mask_count(self):
+        return int(self.lib.d2t_train_mask_count(self.ctx))
+
+    def read_mask(self, index, numel):
+        m = torch.empty(int(numel), dtype=torch.uint8, device="cuda")
+        self._check(self.lib.d2t_train_read_mask(self.ctx, int(index), _lib.ptr(m), int(numel), _lib.stream_of(m)), "train_read_mask")
+        return m
+
     def train_backward(self, dlogits):
         dlogits = dlogits.float().contiguous()
         self._check(self.lib.d2t_train_backward(self.ctx, _lib.ptr(dlogits), _lib.stream_of(dlogits)), "train_backward")

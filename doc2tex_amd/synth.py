@@ -124,6 +124,8 @@ _CONFIGS["T2G"] = copy.deepcopy(_CONFIGS["T2"])
 _CONFIGS["T2G"]["SequenceModeling"]["params"]["backbone"]["gcb"] = True
 _CONFIGS["T1G"] = copy.deepcopy(_CONFIGS["T1"])
 _CONFIGS["T1G"]["FeatureExtraction"]["params"]["gcb"] = True
+_CONFIGS["T2D"] = copy.deepcopy(_CONFIGS["T2"])  # training with dropout in the decoder layers
+_CONFIGS["T2D"]["Prediction"]["params"]["dropout"] = 0.1
 _CONFIGS["TS0"] = copy.deepcopy(_CONFIGS["S0"])  # tiny S0
 _CONFIGS["TS0"]["SequenceModeling"] = _vit_seq(depth=2)
 _CONFIGS["TS0"]["max_dimension"] = [48, 64]

@@ -13,6 +13,9 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, text, names, *params):
         eng = model.engine(finalize=False)
+        # nn.TransformerDecoderLayer(dropout=p): masks from the engine's Philox stream, seeded like torch's generator
+        p = float(model.opt["Prediction"]["params"].get("dropout", 0.0) or 0.0)
+        eng.set_dropout(p, torch.initial_seed())
         logits = eng.train_forward(image, text)
         # BatchNorm side effects of module.train(): running statistics and the batch counter
         with torch.no_grad():

@@ -208,6 +208,14 @@ int d2t_train_backward(d2t_ctx* ctx, const float* dlogits, d2t_stream stream);
 int d2t_train_grad(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
 /* copy the engine's current copy of a loaded tensor (e.g. BatchNorm running statistics after a training forward) */
 int d2t_read_weight(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
+/* Dropout of nn.TransformerDecoderLayer(dropout=p) in the training step: on the attention probabilities of both
+ * attentions, after each of the three sub-layers (dropout1/2/3) and inside the feed-forward block.  Keep masks are
+ * Philox4x32-10 draws keyed by (seed, number of training forwards since the seed was set, site index): statistically
+ * the same as torch's dropout, not the same random stream.  p = 0 (default) disables it.  The masks of the last
+ * forward can be read back (creation order = the order torch draws them) for verification. */
+int d2t_train_set_dropout(d2t_ctx* ctx, float p, uint64_t seed);
+int d2t_train_mask_count(d2t_ctx* ctx);
+int d2t_train_read_mask(d2t_ctx* ctx, int32_t index, uint8_t* dst, int64_t numel, d2t_stream stream);
 /* free the training tape, gradient buffers and workspace */
 void d2t_train_release(d2t_ctx* ctx);
 

@@ -239,12 +239,15 @@ def _split_heads(x, heads):  # [B,L,d] -> [B,H,L,hd]
     return x.view(B, L, heads, d // heads).transpose(1, 2)
 
 
-def _attend(q, k, v, mask=None):
-    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], additive mask broadcastable to [B,H,Lq,Lk]."""
+def _attend(q, k, v, mask=None, drop=None):
+    """q [B,H,Lq,hd], k/v [B,H,Lk,hd], additive mask broadcastable to [B,H,Lq,Lk].  drop: see _decoder_layer."""
     s = (q @ k.transpose(-2, -1)) * (q.shape[-1] ** -0.5)
     if mask is not None:
         s = s + mask
-    o = s.softmax(dim=-1) @ v
+    pr = s.softmax(dim=-1)
+    if drop is not None:  # nn.MultiheadAttention(dropout=p): on the attention probabilities
+        pr = pr * drop(pr.shape, "attn")
+    o = pr @ v
     B, H, L, hd = o.shape
     return o.transpose(1, 2).reshape(B, L, H * hd)
 
@@ -262,22 +265,28 @@ def cross_kv(mem, sd, p, heads):
     return _split_heads(k, heads), _split_heads(v, heads)
 
 
-def _decoder_layer(x, sd, p, heads, self_k, self_v, ck, cv, mask):
+def _decoder_layer(x, sd, p, heads, self_k, self_v, ck, cv, mask, drop=None):
     """One nn.TransformerDecoderLayer (norm_first=False) on queries x [B,Lq,d].
 
     self_k/self_v [B,H,Lk,hd] are the self-attention keys/values (already
-    including x's own positions); ck/cv the cross-attention K,V of the memory."""
+    including x's own positions); ck/cv the cross-attention K,V of the memory.
+
+    drop (training with dropout > 0): callable(shape, kind) -> keep mask already scaled by 1/(1-p), asked for in
+    the order torch draws them: self-attention probabilities ("attn"), dropout1 ("hidden"), cross-attention
+    probabilities, dropout2, the feed-forward block's inner dropout, dropout3 (nn.TransformerDecoderLayer
+    _sa_block / _mha_block / _ff_block)."""
     d = x.shape[-1]
+    dr = (lambda t: t * drop(t.shape, "hidden")) if drop is not None else (lambda t: t)
     w, b = sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]
     q = _split_heads(F.linear(x, w[:d], b[:d]), heads)
-    a = _attend(q, self_k, self_v, mask)
-    x = _ln(x + F.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"]), sd, p + "norm1")
+    a = _attend(q, self_k, self_v, mask, drop)
+    x = _ln(x + dr(F.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])), sd, p + "norm1")
     w, b = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
     q = _split_heads(F.linear(x, w[:d], b[:d]), heads)
-    a = _attend(q, ck, cv)
-    x = _ln(x + F.linear(a, sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"]), sd, p + "norm2")
-    h = F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"]))
-    return _ln(x + F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"]), sd, p + "norm3")
+    a = _attend(q, ck, cv, None, drop)
+    x = _ln(x + dr(F.linear(a, sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"])), sd, p + "norm2")
+    h = dr(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])))
+    return _ln(x + dr(F.linear(h, sd[p + "linear2.weight"], sd[p + "linear2.bias"])), sd, p + "norm3")
 
 
 def _self_kv(x, sd, p, heads):
@@ -299,7 +308,7 @@ def _embed(tgt, sd, p, pos0=0):
     return e + sd[p + "pos_enc.pe"][pos0:pos0 + tgt.shape[1]][None]
 
 
-def tfm_full_pass(tgt, mem, sd, p, layers, heads, key_padding=False):
+def tfm_full_pass(tgt, mem, sd, p, layers, heads, key_padding=False, drop=None):
     """Decoder over a whole token prefix tgt [B,L] (what the reference runs at
     every greedy step, and the teacher-forced training pass tfm.py:103-118)."""
     B, L = tgt.shape
@@ -311,7 +320,7 @@ def tfm_full_pass(tgt, mem, sd, p, layers, heads, key_padding=False):
         lp = f"{p}model.layers.{i}."
         sk, sv = _self_kv(x, sd, lp, heads)
         ck, cv = cross_kv(mem, sd, lp, heads)
-        x = _decoder_layer(x, sd, lp, heads, sk, sv, ck, cv, mask)
+        x = _decoder_layer(x, sd, lp, heads, sk, sv, ck, cv, mask, drop)
     return F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
 
 
@@ -651,23 +660,23 @@ def is_trainable(key):
     return tail not in ("running_mean", "running_var", "num_batches_tracked", "pe", "pos_embed")
 
 
-def train_forward(cfg, sd, image, text_in, bn_train):
+def train_forward(cfg, sd, image, text_in, bn_train, drop=None):
     """Model.forward under module.train() for the TFM head: BatchNorm on batch statistics (their running
     updates are left in `bn_train`), teacher-forced decoder pass with causal + PAD key-padding masks
     (tfm.py:103-118).  Dropout is 0 in every parity config.  Returns logits [B,L,V]."""
     pp = cfg["Prediction"]["params"]
     mem, _, _ = forward_encoder(cfg, sd, image, faithful=True, bn_train=bn_train)
     return tfm_full_pass(text_in, mem, sd, "predicter.Prediction.", pp["num_decoder_layers"], pp["nhead"],
-                         key_padding=True)
+                         key_padding=True, drop=drop)
 
 
-def train_step_grads(cfg, sd, image, text):
+def train_step_grads(cfg, sd, image, text, drop=None):
     """forward_step + loss.backward() (engine/training.py:83-88,126,137): text [B,L+1] with [GO] first;
     the model sees text[:, :-1], the target is text[:, 1:].  Returns (loss, logits, {key: grad}, bn_train)."""
     params = {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and is_trainable(k)) else v)
               for k, v in sd.items()}
     bn_train = {}
-    logits = train_forward(cfg, params, image, text[:, :-1], bn_train)
+    logits = train_forward(cfg, params, image, text[:, :-1], bn_train, drop)
     loss = ce_loss(logits, text[:, 1:])
     names = [k for k, v in params.items() if v.is_floating_point() and v.requires_grad]
     grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)

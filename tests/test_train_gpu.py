@@ -182,3 +182,55 @@ def test_grad_sync_over_rccl_single_rank(cases, manifests):
                 assert torch.equal(p.grad, ref[k]), k
     finally:
         dist.destroy_process_group()
+
+
+def test_train_step_with_dropout(cases, manifests):
+    """nn.TransformerDecoderLayer(dropout=0.1): the engine draws Philox keep masks; fed with the SAME masks (read back
+    through d2t_train_read_mask, in torch's draw order) the oracle's autograd gives the same loss, logits and gradients.
+    Also: keep rate, reproducibility for a fixed torch seed, fresh masks on the next step."""
+    c = _case(cases, "train_dropout", "t2d_train_dropout")
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = synth.synth_labels(c["B"], max_len=c["max_seq_len"], seed=c["iseed"])
+    p = c["p"]
+    torch.manual_seed(4242)
+    loss, preds = _step(m, img, text)
+    eng = m._engine
+    layers = cfg["Prediction"]["params"]["num_decoder_layers"]
+    assert eng.mask_count() == 6 * layers
+    idx = [0]
+    kept = []
+
+    def drop(shape, kind):
+        n = int(np.prod(shape))
+        mk = eng.read_mask(idx[0], n).cpu().float().reshape(tuple(shape))
+        idx[0] += 1
+        kept.append(float(mk.mean()))
+        return mk / (1.0 - p)
+
+    oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text, drop=drop)
+    assert idx[0] == 6 * layers
+    assert all(abs(k - (1.0 - p)) < 0.02 for k in kept), kept
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
+    _check_instance(m, ograds)
+    d1_numel = c["B"] * (c["max_seq_len"] + 1) * cfg["Prediction"]["params"]["d_model"]
+    first_mask = eng.read_mask(1, d1_numel).clone()  # dropout1 of layer 0: [B*L][d_model]
+    g1 = {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
+    # next step, same torch seed: new masks (the forward counter advanced)
+    m.load_state_dict(state0)
+    _step(m, img, text)
+    assert not torch.equal(eng.read_mask(1, first_mask.numel()), first_mask)
+    # re-seeding restarts the stream: identical masks and gradients
+    m.load_state_dict(state0)
+    torch.manual_seed(4243)
+    _step(m, img, text)
+    torch.manual_seed(4242)
+    m.load_state_dict(state0)
+    _step(m, img, text)
+    assert torch.equal(eng.read_mask(1, first_mask.numel()), first_mask)
+    for k, q in m.named_parameters():
+        if q.grad is not None:
+            assert torch.equal(q.grad, g1[k]), k

@@ -76,6 +76,8 @@ TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
 # full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
 TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031)]
 GRAD_SAMPLES = 48
+# dropout placement (p = 0.1 in the decoder layers): name, config, B, H, W, L, wseed, iseed, mask seed
+TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77)]
 
 
 def build_ref(cfg_name, max_seq_len, beam_size=None, wseed=1234, end_bias=0.0):
@@ -311,11 +313,88 @@ def run_train_step(case):
             "grad_norms": norms, "seconds": round(time.time() - t0, 1), "torch": torch.__version__}
 
 
+class SeqFirstMasks:
+    """Keep masks drawn in call order from a seeded generator, in the (L, B, D) layout nn.TransformerDecoderLayer
+    (batch_first=False) presents to its nn.Dropout modules."""
+
+    def __init__(self, p, seed):
+        self.p, self.g = p, torch.Generator().manual_seed(seed)
+
+    def draw(self, shape):
+        return (torch.rand(tuple(shape), generator=self.g) >= self.p).float() / (1.0 - self.p)
+
+
+def run_train_dropout(case):
+    """Pins WHERE the oracle applies dropout: the reference runs with torch.nn.functional.dropout replaced by a
+    seeded mask source (its attention-probability dropout, which lives inside scaled_dot_product_attention and cannot
+    be intercepted, is switched off for this run); the oracle gets the same masks at its "hidden" sites."""
+    name, cname, B, H, W, L, wseed, iseed, mseed = case
+    cfg, m, sd = build_ref(cname, L, wseed=wseed)
+    p = cfg["Prediction"]["params"]["dropout"]
+    m.train()
+    for layer in m.predicter.Prediction.model.layers:
+        layer.self_attn.dropout = 0.0
+        layer.multihead_attn.dropout = 0.0
+    img = synth.synth_images(B, H, W, seed=iseed)
+    text = synth.synth_labels(B, max_len=L, seed=iseed)
+    src = SeqFirstMasks(p, mseed)
+    real = torch.nn.functional.dropout
+
+    def fake(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        return input * src.draw(input.shape)
+
+    torch.nn.functional.dropout = fake
+    try:
+        _, preds, _ = m(img, text[:, :-1])
+    finally:
+        torch.nn.functional.dropout = real
+    loss = torch.nn.functional.cross_entropy(preds.view(-1, preds.shape[-1]), text[:, 1:].contiguous().view(-1),
+                                             ignore_index=0, reduction="none").mean()
+    loss.backward()
+    ref_grads = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    osrc = SeqFirstMasks(p, mseed)
+
+    def drop(shape, kind):
+        if kind == "attn":
+            return torch.ones(tuple(shape))
+        Bq, Lq, D = shape
+        return osrc.draw((Lq, Bq, D)).transpose(0, 1)
+
+    oloss, ologits, ograds, _ = R.train_step_grads(cfg, slim_sd(sd), img, text, drop=drop)
+    assert abs(float(oloss) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (float(oloss), float(loss))
+    assert maxdiff(ologits, preds.detach()) <= TOL
+    worst = max(float((ograds[k].double() - g.double()).abs().max() / max(1e-6, float(g.double().abs().max())))
+                for k, g in ref_grads.items())
+    assert worst <= 5e-4, worst
+    return {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
+            "mask_seed": mseed, "p": p, "loss": float(loss), "logits_sum": float(preds.detach().double().sum()),
+            "oracle_worst_rel_grad_diff": worst, "torch": torch.__version__}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     summary = {"greedy": [], "beam": [], "train": [], "train_step": []}
     manifests = {}
+    if os.environ.get("GOLDEN_ONLY") == "train_dropout":
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        with open(os.path.join(GOLD, "manifests.json")) as f:
+            manifests = json.load(f)
+        summary["train_dropout"] = []
+        for case in TRAIN_DROPOUT_CASES:
+            rep = run_train_dropout(case)
+            summary["train_dropout"].append(rep)
+            print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
+        cfg_, m_, sd_ = build_ref("T2D", 24)
+        manifests["T2D"] = manifest(sd_)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+            json.dump(manifests, f)
+        return
     if os.environ.get("GOLDEN_ONLY") == "gcb":  # add / refresh only the GlobalContext greedy fixtures
         with open(os.path.join(GOLD, "cases.json")) as f:
             summary = json.load(f)
@@ -378,6 +457,12 @@ def main():
         rep = run_train_step(case)
         summary["train_step"].append(rep)
         print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
+    summary["train_dropout"] = []
+    for case in TRAIN_DROPOUT_CASES:
+        rep = run_train_dropout(case)
+        summary["train_dropout"].append(rep)
+        print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
+    manifests["T2D"] = manifest(build_ref("T2D", 24)[2])
     with open(os.path.join(GOLD, "cases.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(GOLD, "manifests.json"), "w") as f:
