@@ -8,6 +8,8 @@ in libd2t (hand-written gfx950 HIP kernels) through ctypes.  There is no CPU or
 eager-PyTorch fallback: on a machine without the built library or without a
 HIP device the forward raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -114,9 +116,9 @@ class Model(nn.Module):
         self.reserved_blocks = 64
         # pipelined mode: decode loops in flight side by side (1 or 2)
         self.decode_chains = 1
-        # 'fp32' = exact fp32 matrix-core convolutions (default); 'bf16x3' = split-bf16 convolutions
-        # (3 bf16 MFMAs per product, fp32 accumulate; logits stay within 1e-3)
-        self.conv_precision = "fp32"
+        # 'bf16x3' (default) = split-bf16 convolutions / large GEMMs (3 bf16 MFMAs per product, fp32 accumulate: tokens
+        # bit-exact, logits within 1e-3 on every fixture); 'fp32' = exact fp32 matrix-core arithmetic
+        self.conv_precision = os.environ.get("D2T_CONV_PRECISION", "bf16x3")
         # data-parallel training: a doc2tex_amd.dist.GradSync makes loss.backward() return all-reduced (mean) gradients
         self.grad_sync = None
 

@@ -119,13 +119,13 @@ def test_train_step_gradients_match_oracle_autograd(cases, manifests):
     assert tight >= 2, tight
 
 
-def test_train_step_with_split_bf16_convolutions(cases, manifests):
-    """conv_precision = 'bf16x3' also routes the training step's forward and data-gradient convolutions through the
-    split-bf16 kernel (3 bf16 MFMAs per product): same gradient criteria as fp32."""
+def test_train_step_in_pure_fp32(cases, manifests):
+    """conv_precision = 'fp32' keeps the training step's forward and data-gradient convolutions on the exact fp32 MFMA
+    (the default routes them through the split-bf16 kernel, which every other test here exercises): same criteria."""
     c = _case(cases, "train_step", "t2_train_step")
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
     _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
-    m.conv_precision = "bf16x3"
+    m.conv_precision = "fp32"
     img = synth.synth_images(c["B"], c["H"], c["W"], seed=1130)
     text = train_step_labels({**c, "iseed": 1130})
     oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text)
