@@ -110,6 +110,32 @@ def test_headline_shape_properties(cases):
     assert torch.equal(preds, logits.argmax(-1))  # tokens are the argmax of the returned logits
 
 
+def test_headline_shape_in_the_benchmarked_serving_mode(cases):
+    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, 64 reserved block slots: four batches in
+    flight give exactly the synchronous results, and the fixture rows stay exact."""
+    c = _case(cases, "greedy", "c2_greedy")
+    z = np.load(os.path.join(GOLD, "c2_greedy.npz"))
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    base = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    imgs = []
+    for i in range(4):
+        x = synth.synth_images(64, c["H"], c["W"], seed=300 + i)
+        x[: c["B"]] = base  # the fixture rows ride in every batch
+        imgs.append(x.cuda())
+    text = torch.full((64, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        ref = [m(x, text, is_train=False) for x in imgs]
+        ref = [(p.clone(), l.clone()) for p, l, _ in ref]
+        m.pipelined, m.decode_chains, m.reserved_blocks = True, 2, 64
+        got = [m(x, text, is_train=False)[:2] for x in imgs]  # ring of four result buffers
+        m.synchronize()
+        torch.cuda.synchronize()
+    for (p, l), (rp, rl) in zip(got, ref):
+        assert torch.equal(p, rp) and torch.equal(l, rl)
+        assert np.array_equal(p[: c["B"]].cpu().numpy(), z["tokens"])
+    m.pipelined = False
+
+
 @pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish"])
 def test_beam_vs_reference_fixture(cases, name):
     """forward_beam + Beam (tfm.py:145-186, tools/beam.py) for one sample: the best
