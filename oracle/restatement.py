@@ -452,7 +452,7 @@ def bilstm(x, sd, p):
     return F.linear(torch.cat(outs, dim=2), sd[p + "linear.weight"], sd[p + "linear.bias"])
 
 
-def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False):
+def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False, teacher=None):
     """Attention.forward_greedy (prediction_head/seq2seq.py:224-331) / AttentionV2.forward_greedy
     (seq2seq_v2.py:176-293) in eval mode (is_train=False) with embed_target=True, on the
     LocationAwareAttention cell (addon_module/attention1D.py:121-161,203-242).
@@ -480,7 +480,7 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
     kp = F.linear(keys, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
     pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
     for i in range(num_steps):
-        emb = F.embedding(targets, sd[p + "embedding.weight"])
+        emb = F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)  # seq2seq.py:33-35
         hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
         last = torch.zeros(B, T, 1) if mem is None else mem
         loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
@@ -499,6 +499,12 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
             mem = alpha_cum
         else:  # loc_aware
             mem = alpha
+        if teacher is not None:  # is_train with teacher_forcing = 1.0 (seq2seq.py:311-316): next input = text[:, i + 1]
+            probs[:, i] = out
+            if i == num_steps - 1:
+                break
+            targets = teacher[:, i + 1]
+            continue
         probs[:, i] = out
         if i == num_steps - 1:
             break
@@ -542,7 +548,7 @@ def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
     complete, complete_scores, complete_inds = [], [], []
     for step in range(num_steps):
         M = h.shape[0]
-        emb = F.embedding(targets, sd[p + "embedding.weight"])
+        emb = F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)  # seq2seq.py:33-35
         hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
         last = torch.zeros(M, T, 1) if mem is None else mem
         loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
@@ -661,11 +667,18 @@ def is_trainable(key):
 
 
 def train_forward(cfg, sd, image, text_in, bn_train, drop=None):
-    """Model.forward under module.train() for the TFM head: BatchNorm on batch statistics (their running
-    updates are left in `bn_train`), teacher-forced decoder pass with causal + PAD key-padding masks
-    (tfm.py:103-118).  Dropout is 0 in every parity config.  Returns logits [B,L,V]."""
+    """Model.forward under module.train(): BatchNorm on batch statistics (their running updates are left in
+    `bn_train`); TFM head: teacher-forced decoder pass with causal + PAD key-padding masks (tfm.py:103-118);
+    Attn / Attnv2 heads: the LSTM-attention loop fed with the label tokens (teacher_forcing = 1.0,
+    seq2seq.py:311-316; droprate 0).  Returns logits [B,L,V]."""
     pp = cfg["Prediction"]["params"]
     mem, _, _ = forward_encoder(cfg, sd, image, faithful=True, bn_train=bn_train)
+    if cfg["Prediction"]["name"] in ("Attn", "Attnv2"):
+        sm = pp.get("seqmodel", "ViT")
+        if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
+            sm = "first"
+        return attn_greedy(mem, sd, "predicter.Prediction.", cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
+                           pp.get("enc_init", False), teacher=text_in)[1]
     return tfm_full_pass(text_in, mem, sd, "predicter.Prediction.", pp["num_decoder_layers"], pp["nhead"],
                          key_padding=True, drop=drop)
 
@@ -677,6 +690,8 @@ def train_step_grads(cfg, sd, image, text, drop=None):
               for k, v in sd.items()}
     bn_train = {}
     logits = train_forward(cfg, params, image, text[:, :-1], bn_train, drop)
+    # CE ignore_index: PAD = 0 for the TFM converter; for the Attn converter index 0 is [GO], also ignored
+    # (attn_converter.py:17) -- the same call either way
     loss = ce_loss(logits, text[:, 1:])
     names = [k for k, v in params.items() if v.is_floating_point() and v.requires_grad]
     grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)

@@ -114,15 +114,21 @@ def _grad_sample_index(key, numel, n=48):
 
 
 def train_step_labels(c):
-    """The label tensor tools/make_golden.py fed to the reference for a train_step case."""
+    """The label tensor tools/make_golden.py fed to the reference for a train_step case (TFM converter layout, or
+    the Attn converter's: [GO] = 0 first and as padding, [s] = 1)."""
     L = c["max_seq_len"]
     text = synth.synth_labels(c["B"], max_len=L, seed=c["iseed"])
     text[0, L // 2:] = 0
     text[0, L // 2 - 1] = R.END
+    if c["config"] in ("TS0", "S0", "C0"):
+        t = text.clone()
+        t[text == 1] = 0
+        t[text == 2] = 1
+        text = t
     return text
 
 
-@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step"])
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
     reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""

@@ -74,7 +74,9 @@ ATTN_BEAM_CASES = [
 ]
 TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
 # full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
-TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031)]
+TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031),
+                    # HybridViT + Attnv2 (the shipped config/train.yaml stack), teacher_forcing 1.0, droprate 0
+                    ("ts0_train_step", "TS0", 3, 48, 64, 24, 1234, 1032)]
 GRAD_SAMPLES = 48
 # dropout placement (p = 0.1 in the decoder layers): name, config, B, H, W, L, wseed, iseed, mask seed
 TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77)]
@@ -269,6 +271,20 @@ def grad_sample_index(key, numel):
     return torch.randint(0, numel, (min(GRAD_SAMPLES, numel),), generator=g)
 
 
+def train_labels(cfg, B, L, iseed):
+    """Teacher-forcing labels of a train_step case.  TFM converter: [GO]=1 first, [s]=2, PAD=0 (tfm_converter.py);
+    Attn converter: [GO]=0 first AND as padding, [s]=1 (attn_converter.py:8-17,31-50)."""
+    text = synth.synth_labels(B, max_len=L, seed=iseed)
+    text[0, L // 2:] = 0
+    text[0, L // 2 - 1] = R.END  # one short label so PAD masking / ignore_index are exercised
+    if cfg["Prediction"]["name"] in ("Attn", "Attnv2"):
+        t = text.clone()
+        t[text == 1] = 0   # [GO]
+        t[text == 2] = 1   # [s]
+        text = t           # ordinary tokens (>= 4) and the padding zeros stay
+    return text
+
+
 def run_train_step(case):
     """forward_step + loss.backward() of the REFERENCE in module.train() mode (engine/training.py:76-91,126,137);
     checks the oracle's train_step_grads against it and stores loss, logits / gradient samples, gradient norms and
@@ -277,9 +293,7 @@ def run_train_step(case):
     cfg, m, sd = build_ref(cname, L, wseed=wseed)
     m.train()
     img = synth.synth_images(B, H, W, seed=iseed)
-    text = synth.synth_labels(B, max_len=L, seed=iseed)
-    text[0, L // 2:] = 0
-    text[0, L // 2 - 1] = R.END  # one short label so PAD masking / ignore_index are exercised
+    text = train_labels(cfg, B, L, iseed)
     t0 = time.time()
     _, preds, _ = m(img, text[:, :-1])  # is_train defaults to True (training.py:88)
     cost = torch.nn.functional.cross_entropy(preds.view(-1, preds.shape[-1]), text[:, 1:].contiguous().view(-1),
