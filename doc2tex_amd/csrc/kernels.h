@@ -108,7 +108,38 @@ struct AttnDecP {
   const float *st_h_in, *st_c_in, *st_mem_in;  // [B][H], [B][H], [B][T - key_off]
   float *st_h_out, *st_c_out, *st_mem_out;
   const int64_t* tok_in;                        // [B] input token of this step
+  // Training forward (teacher forcing, seq2seq.py:311-316): the input token of step t is teacher[b*S + t]; the
+  // recurrent state of every step is saved for the backward pass (all optional).
+  const int64_t* teacher;
+  float *sv_hprev, *sv_cprev, *sv_hafter, *sv_cafter;  // [B][S][H]: LSTM state before / after step t
+  float* sv_gates;         // [B][S][4H]: i, f, g, o after their nonlinearities
+  float* sv_alpha;         // [B][S][T - key_off]
+  float* sv_hq;            // [B][S][H]   query projection
+  float* sv_x;             // [B][S][D + E]: LSTMCell input [context | embedding]
 };
+// Backward of the teacher-forced loop above (one block per batch row, steps in reverse).  Gradients that are sums
+// over (row, step) of outer products are left as per-(row, step) factors for GEMMs: dgates, dhq, demb, dh0 / dc0.
+struct AttnTrainBwdP {
+  const float* dlogits;    // [B][S][V]
+  const float* mem; int T, D, key_off;        // keys = mem[b][key_off:]
+  const float* kp;         // [B][T][H] key projection (forward value)
+  const float *wg_t, *wih_raw, *whh_raw, *wq_raw, *wloc, *bloc, *wscore;  // wg_t [H][V]; raw [4H][D+E], [4H][H], [H][H]
+  int taps;
+  const float *sv_cprev, *sv_cafter, *sv_gates, *sv_alpha, *sv_hq;
+  float* dmem;             // [B][T][D]  += context path (zero-initialised by the caller)
+  float* dkp;              // [B][T][H]  += score path   (zero-initialised by the caller)
+  float *dgates, *dhq, *demb;   // [B][S][4H], [B][S][H], [B][S][E]
+  float *dh0, *dc0;        // [B][H]
+  float *dwloc, *dbloc, *dwscore, *dbscore;   // per-row partials [B][H][taps], [B][H], [B][H], [B]
+  int B, S, V, H, E, coverage;
+};
+hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p, hipStream_t s);
+// fold / unfold of loc_proj o loc_conv: gradients of the four location-layer tensors from the per-row partials
+hipError_t launch_loc_unfold_bwd(const float* dwloc, const float* dbloc, int B, const float* conv_w, const float* conv_b,
+                                 const float* proj_w, int H, int kd, int taps, float* d_conv_w, float* d_conv_b,
+                                 float* d_proj_w, float* d_proj_b, hipStream_t s);
+// out[c] = sum_b part[b][c]
+hipError_t launch_sum_over_rows(const float* part, float* out, int B, int C, hipStream_t s);
 // dst[i][0..width) = src[idx[i]][0..width)
 hipError_t launch_gather_rows(const float* src, float* dst, const int* idx, int rows, int width, hipStream_t s);
 hipError_t launch_attn_decode(const AttnDecP& p, hipStream_t s);

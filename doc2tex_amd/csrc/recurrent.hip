@@ -178,6 +178,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   }
 
   for (int step = 0; step < p.S; ++step) {
+    if (p.teacher && tid == 0) tok_s = (int)p.teacher[(size_t)b * p.S + step];
+    if (p.sv_hprev && tid < H) {
+      p.sv_hprev[((size_t)b * p.S + step) * H + tid] = h_s[tid];
+      p.sv_cprev[((size_t)b * p.S + step) * H + tid] = c_s[tid];
+    }
+    if (p.teacher) __syncthreads();
     // (1) query projection and target embedding
     if (tid < H) {
       float a = p.bq[tid];
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
       for (int k = 0; k < H; ++k) a = fmaf(h_s[k], p.wq_t[(size_t)k * H + tid], a);
       hq_s[tid] = a;
       emb_s[tid] = p.emb[(size_t)tok_s * p.E + tid];
+      if (p.sv_hq) p.sv_hq[((size_t)b * p.S + step) * H + tid] = a;
     }
     __syncthreads();
     // (2) scores: e[t] = w . tanh(key_proj[t] + query_proj + loc(mem)[t]) + b ; one wave per key
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
       for (int t = tid; t < Tk; t += 1024) {
         const float a = alpha_s[t] * inv;
         alpha_s[t] = a;
+        if (p.sv_alpha) p.sv_alpha[((size_t)b * p.S + step) * Tk + t] = a;
         mem_s[t] = p.coverage ? mem_s[t] + a : a;  // coverage: accumulated alignment (seq2seq.py:302-304)
       }
     }
@@ -252,7 +260,13 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
       gate_s[gq * H + c] = a;
     }
     __syncthreads();
-    if (tid < H) ctx_s[tid] = (gate_s[tid] + gate_s[H + tid]) + (gate_s[2 * H + tid] + gate_s[3 * H + tid]);
+    if (tid < H) {
+      ctx_s[tid] = (gate_s[tid] + gate_s[H + tid]) + (gate_s[2 * H + tid] + gate_s[3 * H + tid]);
+      if (p.sv_x) {
+        p.sv_x[((size_t)b * p.S + step) * (p.D + p.E) + tid] = ctx_s[tid];
+        p.sv_x[((size_t)b * p.S + step) * (p.D + p.E) + p.D + tid] = emb_s[tid];
+      }
+    }
     __syncthreads();
     // (5) LSTMCell gates: thread = gate row, [ctx ; emb ; h] . W^T (coalesced transposed weights)
     {
@@ -269,6 +283,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
       const float c = fg * c_s[tid] + ig * gg;
       c_s[tid] = c;
       h_s[tid] = og * tanhf(c);
+      if (p.sv_gates) {
+        float* gs = p.sv_gates + ((size_t)b * p.S + step) * 4 * H;
+        gs[tid] = ig; gs[H + tid] = fg; gs[2 * H + tid] = gg; gs[3 * H + tid] = og;
+        p.sv_hafter[((size_t)b * p.S + step) * H + tid] = h_s[tid];
+        p.sv_cafter[((size_t)b * p.S + step) * H + tid] = c;
+      }
     }
     __syncthreads();
     // (6) generator logits + argmax (first maximum)
@@ -307,6 +327,305 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
     if (tid < H) { p.st_h_out[(size_t)b * H + tid] = h_s[tid]; p.st_c_out[(size_t)b * H + tid] = c_s[tid]; }
     for (int t = tid; t < Tk; t += 1024) p.st_mem_out[(size_t)b * Tk + t] = mem_s[t];
   }
+}
+
+// ---------------------------------------------------------------------------
+// Backward of the teacher-forced LSTM-attention loop (Attention / AttentionV2.forward_greedy with is_train,
+// teacher_forcing = 1, coverage or location-aware memory): one block per batch row walks the steps in reverse.
+// H = D = E = 256.  See AttnTrainBwdP for what is produced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTrainBwdP p) {
+  constexpr int H = 256;
+  __shared__ float dh_s[H], dc_s[H], dgate_s[4 * H], dctx_s[H], dhprev_s[H], hq_s[H], dhq_s[H];
+  __shared__ float alpha_s[AD_MAXT], mem_s[AD_MAXT + 16], dal_s[AD_MAXT], de_s[AD_MAXT], dcov_s[AD_MAXT], dmem_s[AD_MAXT + 16];
+  __shared__ float part_s[16][H];
+  __shared__ float dl_s[1024], red_s[32];
+  __shared__ __attribute__((aligned(16))) float wloc_s[11 * H];  // [tap][n]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int Tk = p.T - p.key_off, half = p.taps / 2;
+  const float* keys = p.mem + ((size_t)b * p.T + p.key_off) * p.D;
+  const float* kp = p.kp + ((size_t)b * p.T + p.key_off) * H;
+  float* dkeys = p.dmem + ((size_t)b * p.T + p.key_off) * p.D;
+  float* dkp = p.dkp + ((size_t)b * p.T + p.key_off) * H;
+  for (int i = tid; i < p.taps * H; i += 1024) wloc_s[i] = p.wloc[(i % H) * p.taps + i / H];
+  if (tid < H) { dh_s[tid] = 0.f; dc_s[tid] = 0.f; }
+  for (int i = tid; i < AD_MAXT; i += 1024) { dcov_s[i] = 0.f; mem_s[i] = 0.f; dmem_s[i] = 0.f; }
+  if (tid < 16) { mem_s[AD_MAXT + tid] = 0.f; dmem_s[AD_MAXT + tid] = 0.f; }
+  __syncthreads();
+  // memory after the last step = sum of all alignments (coverage) / the last alignment (location-aware)
+  for (int t = 0; t < p.S; ++t)
+    for (int j = tid; j < Tk; j += 1024) {
+      const float a = p.sv_alpha[((size_t)b * p.S + t) * Tk + j];
+      mem_s[j] = p.coverage ? mem_s[j] + a : a;
+    }
+  // persistent per-lane accumulators over all steps (lane -> channels n0..n0+3 of the score layer)
+  const int n0 = lane * 4;
+  float acc_ws[4] = {0, 0, 0, 0}, acc_bl[4] = {0, 0, 0, 0}, acc_wl[11][4];
+#pragma unroll
+  for (int a = 0; a < 11; ++a)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc_wl[a][k] = 0.f;
+  float acc_bs = 0.f;
+  __syncthreads();
+
+  for (int t = p.S - 1; t >= 0; --t) {
+    const size_t bt = (size_t)b * p.S + t;
+    // A. this step's alignment; memory BEFORE the step
+    for (int j = tid; j < Tk; j += 1024) {
+      const float a = p.sv_alpha[bt * Tk + j];
+      alpha_s[j] = a;
+      if (p.coverage) mem_s[j] -= a;
+      else mem_s[j] = t > 0 ? p.sv_alpha[(bt - 1) * Tk + j] : 0.f;
+    }
+    if (tid < p.V) dl_s[tid] = p.dlogits[bt * p.V + tid];
+    if (tid < H) hq_s[tid] = p.sv_hq[bt * H + tid];
+    __syncthreads();
+    // B. dh += generator^T dlogits   (4 threads per hidden unit)
+    {
+      const int n = tid >> 2, q = tid & 3;
+      float a = 0.f;
+      for (int v = q; v < p.V; v += 4) a = fmaf(dl_s[v], p.wg_t[(size_t)n * p.V + v], a);
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      if (q == 0) dh_s[n] += a;
+    }
+    __syncthreads();
+    // C. LSTMCell backward
+    if (tid < H) {
+      const float* gs = p.sv_gates + bt * 4 * H;
+      const float ig = gs[tid], fg = gs[H + tid], gg = gs[2 * H + tid], og = gs[3 * H + tid];
+      const float cp = p.sv_cprev[bt * H + tid], tc = tanhf(p.sv_cafter[bt * H + tid]);
+      const float dh = dh_s[tid];
+      const float dc = dc_s[tid] + dh * og * (1.f - tc * tc);
+      const float dai = dc * gg * ig * (1.f - ig), daf = dc * cp * fg * (1.f - fg);
+      const float dag = dc * ig * (1.f - gg * gg), dao = dh * tc * og * (1.f - og);
+      dgate_s[tid] = dai; dgate_s[H + tid] = daf; dgate_s[2 * H + tid] = dag; dgate_s[3 * H + tid] = dao;
+      float* dg = p.dgates + bt * 4 * H;
+      dg[tid] = dai; dg[H + tid] = daf; dg[2 * H + tid] = dag; dg[3 * H + tid] = dao;
+      dc_s[tid] = dc * fg;
+    }
+    __syncthreads();
+    // D. gradient of the LSTMCell input [ctx | emb] and of h_prev (coalesced over the raw weights' columns)
+    if (tid < 2 * H) {
+      float a = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 4 * H; ++r) a = fmaf(dgate_s[r], p.wih_raw[(size_t)r * 2 * H + tid], a);
+      if (tid < H) dctx_s[tid] = a;
+      else p.demb[bt * p.E + (tid - H)] = a;
+    } else if (tid < 3 * H) {
+      const int k = tid - 2 * H;
+      float a = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 4 * H; ++r) a = fmaf(dgate_s[r], p.whh_raw[(size_t)r * H + k], a);
+      dhprev_s[k] = a;
+    }
+    __syncthreads();
+    // E. context backward: dalpha_j = dctx . key_j ; dkeys_j += alpha_j * dctx   (wave per key)
+    {
+      const float4 dc4 = *reinterpret_cast<const float4*>(dctx_s + n0);
+      for (int j = wave; j < Tk; j += 16) {
+        const float4 k4 = *reinterpret_cast<const float4*>(keys + (size_t)j * p.D + n0);
+        float e = dc4.x * k4.x + dc4.y * k4.y + dc4.z * k4.z + dc4.w * k4.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        if (lane == 0) dal_s[j] = e;
+        const float a = alpha_s[j];
+        float4* dk = reinterpret_cast<float4*>(dkeys + (size_t)j * p.D + n0);
+        float4 v = *dk;
+        v.x = fmaf(a, dc4.x, v.x); v.y = fmaf(a, dc4.y, v.y); v.z = fmaf(a, dc4.z, v.z); v.w = fmaf(a, dc4.w, v.w);
+        *dk = v;
+      }
+    }
+    __syncthreads();
+    // F. softmax backward (with the coverage gradient of later steps)
+    {
+      float s = 0.f;
+      for (int j = tid; j < Tk; j += 1024) s = fmaf(alpha_s[j], dal_s[j] + dcov_s[j], s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (lane == 0) red_s[wave] = s;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tot += red_s[w];
+      for (int j = tid; j < Tk; j += 1024) {
+        const float de = alpha_s[j] * (dal_s[j] + dcov_s[j] - tot);
+        de_s[j] = de;
+        acc_bs += de;
+      }
+    }
+    __syncthreads();
+    // G. score backward: u = key_proj_j + query + loc_j ; du = de_j * w * (1 - tanh(u)^2)   (wave per key)
+    {
+      const float4 hq4 = *reinterpret_cast<const float4*>(hq_s + n0);
+      const float4 ws4 = *reinterpret_cast<const float4*>(p.wscore + n0);
+      const float4 bl4 = *reinterpret_cast<const float4*>(p.bloc + n0);
+      float dq[4] = {0, 0, 0, 0};
+      for (int j = wave; j < Tk; j += 16) {
+        const float4 k4 = *reinterpret_cast<const float4*>(kp + (size_t)j * H + n0);
+        float lc[4] = {bl4.x, bl4.y, bl4.z, bl4.w};
+        for (int a = 0; a < p.taps; ++a) {
+          const int tt = j + a - half;
+          const float m = (tt >= 0 && tt < Tk) ? mem_s[tt] : 0.f;
+          const float4 wl = *reinterpret_cast<const float4*>(wloc_s + a * H + n0);
+          lc[0] = fmaf(wl.x, m, lc[0]); lc[1] = fmaf(wl.y, m, lc[1]); lc[2] = fmaf(wl.z, m, lc[2]); lc[3] = fmaf(wl.w, m, lc[3]);
+        }
+        const float th[4] = {tanhf(k4.x + hq4.x + lc[0]), tanhf(k4.y + hq4.y + lc[1]), tanhf(k4.z + hq4.z + lc[2]),
+                             tanhf(k4.w + hq4.w + lc[3])};
+        const float w4[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
+        const float de = de_s[j];
+        float du[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          du[k] = de * w4[k] * (1.f - th[k] * th[k]);
+          dq[k] += du[k];
+          acc_ws[k] = fmaf(de, th[k], acc_ws[k]);
+        }
+        float4* dkp4 = reinterpret_cast<float4*>(dkp + (size_t)j * H + n0);
+        float4 v = *dkp4;
+        v.x += du[0]; v.y += du[1]; v.z += du[2]; v.w += du[3];
+        *dkp4 = v;
+        for (int a = 0; a < p.taps; ++a) {
+          const int tt = j + a - half;
+          const bool in = tt >= 0 && tt < Tk;
+          const float m = in ? mem_s[tt] : 0.f;
+          const float4 wl = *reinterpret_cast<const float4*>(wloc_s + a * H + n0);
+          float g = du[0] * wl.x + du[1] * wl.y + du[2] * wl.z + du[3] * wl.w;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc_wl[a][k] = fmaf(du[k], m, acc_wl[a][k]);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+          if (lane == 0 && in) atomicAdd(&dmem_s[tt], g);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { part_s[wave][n0 + k] = dq[k]; acc_bl[k] += dq[k]; }
+    }
+    __syncthreads();
+    if (tid < H) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) a += part_s[w][tid];
+      dhq_s[tid] = a;
+      p.dhq[bt * H + tid] = a;
+    }
+    __syncthreads();
+    // H. query projection backward into h_prev; I. coverage recursion; J. hand the state gradients to step t-1
+    if (tid < H) {
+      float a = dhprev_s[tid];
+#pragma unroll 8
+      for (int n = 0; n < H; ++n) a = fmaf(dhq_s[n], p.wq_raw[(size_t)n * H + tid], a);
+      dh_s[tid] = a;
+    }
+    for (int j = tid; j < Tk; j += 1024) {
+      if (p.coverage) dcov_s[j] += dmem_s[j];
+      else dcov_s[j] = dmem_s[j];  // location-aware: the memory of step t is the alignment of step t-1 only
+      dmem_s[j] = 0.f;
+    }
+    __syncthreads();
+  }
+  if (tid < H) { p.dh0[(size_t)b * H + tid] = dh_s[tid]; p.dc0[(size_t)b * H + tid] = dc_s[tid]; }
+  // per-row partial sums of the score / location layers: reduce the 16 waves' lane accumulators through LDS
+  auto reduce_store = [&](float (&v)[4], float* dst) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part_s[wave][n0 + k] = v[k];
+    __syncthreads();
+    if (tid < H) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) a += part_s[w][tid];
+      dst[tid] = a;
+    }
+  };
+  reduce_store(acc_ws, p.dwscore + (size_t)b * H);
+  reduce_store(acc_bl, p.dbloc + (size_t)b * H);
+  for (int a = 0; a < p.taps; ++a) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part_s[wave][n0 + k] = acc_wl[a][k];
+    __syncthreads();
+    if (tid < H) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) v += part_s[w][tid];
+      p.dwloc[((size_t)b * H + tid) * p.taps + a] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc_bs += __shfl_xor(acc_bs, o, 64);
+  if (lane == 0) red_s[wave] = acc_bs;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += red_s[w];
+    p.dbscore[b] = tot;
+  }
+}
+hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p, hipStream_t s) {
+  if (p.H != 256 || p.D != 256 || p.E != 256 || p.V > 1024 || p.T - p.key_off > AD_MAXT || p.T - p.key_off < 1 || p.taps > 11)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_train_lstm_bwd_kernel, dim3(p.B), dim3(1024), 0, s, p);
+  return hipGetLastError();
+}
+
+// gradients of loc_conv.weight [kd][taps], loc_conv.bias [kd], loc_proj.weight [H][kd], loc_proj.bias [H] from the
+// folded filter's: wloc[n][a] = sum_m Wp[n][m] Wc[m][a],  bloc[n] = bp[n] + sum_m Wp[n][m] bc[m]
+__global__ void loc_unfold_bwd_kernel(const float* __restrict__ dwloc, const float* __restrict__ dbloc, int B,
+                                      const float* __restrict__ cw, const float* __restrict__ cb,
+                                      const float* __restrict__ pw, int H, int kd, int taps, float* d_cw, float* d_cb,
+                                      float* d_pw, float* d_pb) {
+  extern __shared__ float sm[];  // summed dwloc [H][taps] | dbloc [H]
+  float* W = sm;
+  float* Bv = sm + H * taps;
+  for (int i = threadIdx.x; i < H * taps; i += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dwloc[(size_t)b * H * taps + i];
+    W[i] = a;
+  }
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dbloc[(size_t)b * H + i];
+    Bv[i] = a;
+    d_pb[i] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * kd; i += blockDim.x) {  // d_pw[n][m]
+    const int n = i / kd, m = i % kd;
+    float a = Bv[n] * cb[m];
+    for (int t = 0; t < taps; ++t) a = fmaf(W[n * taps + t], cw[m * taps + t], a);
+    d_pw[i] = a;
+  }
+  for (int i = threadIdx.x; i < kd * taps; i += blockDim.x) {  // d_cw[m][t]
+    const int m = i / taps, t = i % taps;
+    float a = 0.f;
+    for (int n = 0; n < H; ++n) a = fmaf(W[n * taps + t], pw[n * kd + m], a);
+    d_cw[i] = a;
+  }
+  for (int m = threadIdx.x; m < kd; m += blockDim.x) {
+    float a = 0.f;
+    for (int n = 0; n < H; ++n) a = fmaf(Bv[n], pw[n * kd + m], a);
+    d_cb[m] = a;
+  }
+}
+hipError_t launch_loc_unfold_bwd(const float* dwloc, const float* dbloc, int B, const float* conv_w, const float* conv_b,
+                                 const float* proj_w, int H, int kd, int taps, float* d_conv_w, float* d_conv_b,
+                                 float* d_proj_w, float* d_proj_b, hipStream_t s) {
+  hipLaunchKernelGGL(loc_unfold_bwd_kernel, dim3(1), dim3(1024), (size_t)(H * taps + H) * 4, s, dwloc, dbloc, B, conv_w, conv_b,
+                     proj_w, H, kd, taps, d_conv_w, d_conv_b, d_proj_w, d_proj_b);
+  return hipGetLastError();
+}
+__global__ void sum_over_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += part[(size_t)b * C + c];
+  out[c] = a;
+}
+hipError_t launch_sum_over_rows(const float* part, float* out, int B, int C, hipStream_t s) {
+  hipLaunchKernelGGL(sum_over_rows_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, out, B, C);
+  return hipGetLastError();
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx,

@@ -51,7 +51,7 @@ struct TT {  // tensor on the tape
   float* grad = nullptr;
 };
 
-enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD };
+enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD, N_LSTM };
 
 struct Node {
   Kind kind;
@@ -76,6 +76,8 @@ struct Node {
   // N_DROPOUT / N_ATTN: keep mask (bytes) and 1 / (1 - p)
   const uint8_t* mask = nullptr;
   float mscale = 1.f;
+  // N_LSTM (teacher-forced LSTM-attention decoder): in = memory, in2 = key projection, out = logits; saved state
+  float* aux[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -546,6 +548,143 @@ struct Tr {  // builder / runner bound to one context and stream
     return D2T_OK;
   }
 
+  // Attention / AttentionV2.forward_greedy under is_train with teacher_forcing = 1 (seq2seq.py:224-331): the whole loop
+  // is one launch of the greedy kernel fed with the label tokens; its per-step state is kept for bwd_lstm.
+  int lstm_decoder(int mem, const int64_t* tgt, int B, int S, float* logits, int* out) {
+    const d2t_config& g = c->cfg;
+    const int Hh = g.attn_hidden, V = g.vocab, T = (int)(st->t[mem].rows / B);
+    const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0, Tk = T - key_off;
+    if (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN)
+      return fail(c, D2T_ESTATE, "training the Attn head on a BiLSTM encoder is not implemented");
+    if (!c->finalized) return fail(c, D2T_ESTATE, "the Attn training step needs finalized weights");
+    int kp;
+    RC(linear(mem, "predicter.Prediction.attention_cell.attn.key_proj", Hh, Hh, 0, ACT_NONE, -1, &kp));
+    Node n;
+    n.kind = N_LSTM; n.in = mem; n.in2 = kp; n.nb = B; n.Lq = S; n.Lk = T; n.koff = key_off;
+    const size_t BS = (size_t)B * S;
+    RC(alloc(&n.aux[0], BS * Hh));      // h_prev
+    RC(alloc(&n.aux[1], BS * Hh));      // c_prev
+    RC(alloc(&n.aux[2], BS * Hh));      // h_after
+    RC(alloc(&n.aux[3], BS * Hh));      // c_after
+    RC(alloc(&n.aux[4], BS * 4 * Hh));  // gates
+    RC(alloc(&n.aux[5], BS * Tk));      // alpha
+    RC(alloc(&n.aux[6], BS * Hh));      // hq
+    RC(alloc(&n.aux[7], BS * 2 * Hh));  // [ctx | emb]
+    float* dummy;
+    RC(alloc(&dummy, BS * 2 + B + 16));  // tokens (int64) and end_step scratch
+    RC(new_tensor((long long)BS, V, out, 0, 0, 0, logits));
+    AttnDecP p{};
+    p.mem = st->t[mem].p; p.T = T; p.D = Hh; p.key_off = key_off;
+    p.init_mode = !g.attn_enc_init ? 0 : 2;
+    p.kp = st->t[kp].p; p.wq_t = c->attn.wq_t; p.bq = c->attn.bq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
+    p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
+    p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
+    p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
+    p.emb = c->attn.emb; p.probs = logits; p.tokens = reinterpret_cast<int64_t*>(dummy);
+    p.end_step = reinterpret_cast<int*>(dummy + BS * 2);
+    p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage; p.end_token = 1;
+    p.teacher = tgt;
+    p.sv_hprev = n.aux[0]; p.sv_cprev = n.aux[1]; p.sv_hafter = n.aux[2]; p.sv_cafter = n.aux[3];
+    p.sv_gates = n.aux[4]; p.sv_alpha = n.aux[5]; p.sv_hq = n.aux[6]; p.sv_x = n.aux[7];
+    TCHK(launch_attn_decode(p, s));
+    n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  int zeros(float** p, size_t floats) {
+    RC(alloc(p, floats));
+    TCHK(hipMemsetAsync(*p, 0, floats * 4, s));
+    return D2T_OK;
+  }
+  int bwd_lstm(const Node& n) {
+    const d2t_config& g = c->cfg;
+    const int B = n.nb, S = n.Lq, T = n.Lk, Hh = g.attn_hidden, V = g.vocab, key_off = n.koff, Tk = T - key_off;
+    const int taps = c->attn.taps, kd = g.attn_kernel_dim;
+    const long long BS = (long long)B * S;
+    const std::string pp = "predicter.Prediction.", ac = pp + "attention_cell.";
+    const TT& mem = st->t[n.in];
+    const TT& kp = st->t[n.in2];
+    const float* dl = st->t[n.out].grad;
+    const float *wih, *whh, *wq, *cw, *cb, *pw;
+    RC(raw(ac + "rnn.weight_ih", &wih));
+    RC(raw(ac + "rnn.weight_hh", &whh));
+    RC(raw(ac + "attn.query_proj.weight", &wq));
+    RC(raw(ac + "attn.loc_conv.weight", &cw));
+    RC(raw(ac + "attn.loc_conv.bias", &cb));
+    RC(raw(ac + "attn.loc_proj.weight", &pw));
+    AttnTrainBwdP p{};
+    p.dlogits = dl; p.mem = mem.p; p.T = T; p.D = Hh; p.key_off = key_off; p.kp = kp.p;
+    p.wg_t = c->attn.wg_t; p.wih_raw = wih; p.whh_raw = whh; p.wq_raw = wq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
+    p.wscore = c->attn.wscore; p.taps = taps;
+    p.sv_cprev = n.aux[1]; p.sv_cafter = n.aux[3]; p.sv_gates = n.aux[4]; p.sv_alpha = n.aux[5]; p.sv_hq = n.aux[6];
+    float *dmem, *dkp, *dgates, *dhq, *demb, *dh0, *dc0, *dwloc, *dbloc, *dwscore, *dbscore;
+    RC(zeros(&dmem, (size_t)mem.rows * mem.cols));
+    RC(zeros(&dkp, (size_t)kp.rows * kp.cols));
+    RC(alloc(&dgates, (size_t)BS * 4 * Hh));
+    RC(alloc(&dhq, (size_t)BS * Hh));
+    RC(alloc(&demb, (size_t)BS * Hh));
+    RC(alloc(&dh0, (size_t)B * Hh));
+    RC(alloc(&dc0, (size_t)B * Hh));
+    RC(alloc(&dwloc, (size_t)B * Hh * taps));
+    RC(alloc(&dbloc, (size_t)B * Hh));
+    RC(alloc(&dwscore, (size_t)B * Hh));
+    RC(alloc(&dbscore, (size_t)B + 16));
+    p.dmem = dmem; p.dkp = dkp; p.dgates = dgates; p.dhq = dhq; p.demb = demb; p.dh0 = dh0; p.dc0 = dc0;
+    p.dwloc = dwloc; p.dbloc = dbloc; p.dwscore = dwscore; p.dbscore = dbscore;
+    p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage;
+    TCHK(launch_attn_train_lstm_bwd(p, s));
+    // weight gradients = sums over (row, step) of outer products -> TN GEMMs on the saved factors
+    float *gW, *gB, *gB2;
+    RC(grad_buf(ac + "generator.weight", &gW));
+    RC(grad_buf(ac + "generator.bias", &gB));
+    RC(wgrad(dl, V, n.aux[2], Hh, BS, V, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    RC(colsum(dl, BS, V, gB));
+    RC(grad_buf(ac + "rnn.weight_ih", &gW));
+    RC(wgrad(dgates, 4 * Hh, n.aux[7], 2 * Hh, BS, 4 * Hh, 2 * Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    RC(grad_buf(ac + "rnn.weight_hh", &gW));
+    RC(wgrad(dgates, 4 * Hh, n.aux[0], Hh, BS, 4 * Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    RC(grad_buf(ac + "rnn.bias_ih", &gB));
+    RC(grad_buf(ac + "rnn.bias_hh", &gB2));
+    RC(colsum(dgates, BS, 4 * Hh, gB));
+    TCHK(launch_copy(gB, gB2, (size_t)4 * Hh, s));
+    RC(grad_buf(ac + "attn.query_proj.weight", &gW));
+    RC(grad_buf(ac + "attn.query_proj.bias", &gB));
+    RC(wgrad(dhq, Hh, n.aux[0], Hh, BS, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    RC(colsum(dhq, BS, Hh, gB));
+    RC(grad_buf(ac + "attn.score.weight", &gW));
+    RC(grad_buf(ac + "attn.score.bias", &gB));
+    TCHK(launch_sum_over_rows(dwscore, gW, B, Hh, s));
+    TCHK(launch_sum_over_rows(dbscore, gB, B, 1, s));
+    float *gcw, *gcb, *gpw, *gpb;
+    RC(grad_buf(ac + "attn.loc_conv.weight", &gcw));
+    RC(grad_buf(ac + "attn.loc_conv.bias", &gcb));
+    RC(grad_buf(ac + "attn.loc_proj.weight", &gpw));
+    RC(grad_buf(ac + "attn.loc_proj.bias", &gpb));
+    TCHK(launch_loc_unfold_bwd(dwloc, dbloc, B, cw, cb, pw, Hh, kd, taps, gcw, gcb, gpw, gpb, s));
+    RC(grad_buf(pp + "embedding.weight", &gW));
+    TCHK(launch_embed_bwd(demb, st->tgt, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
+    if (g.attn_enc_init) {  // h0 / c0 = proj_init_{h,c}(memory[:, 0])
+      RC(grad_buf(pp + "proj_init_h.weight", &gW));
+      RC(grad_buf(pp + "proj_init_h.bias", &gB));
+      RC(wgrad(dh0, Hh, mem.p, T * Hh, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+      RC(colsum(dh0, B, Hh, gB));
+      RC(grad_buf(pp + "proj_init_c.weight", &gW));
+      RC(grad_buf(pp + "proj_init_c.bias", &gB));
+      RC(wgrad(dc0, Hh, mem.p, T * Hh, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+      RC(colsum(dc0, B, Hh, gB));
+      float *t1, *dinit;
+      RC(alloc(&t1, (size_t)B * Hh));
+      RC(alloc(&dinit, (size_t)B * Hh));
+      RC(gemm_nt(dh0, c->attn.wih_t, nullptr, nullptr, t1, B, Hh, Hh, ACT_NONE));
+      RC(gemm_nt(dc0, c->attn.wic_t, nullptr, t1, dinit, B, Hh, Hh, ACT_NONE));
+      for (int b = 0; b < B; ++b)
+        TCHK(launch_add_rows(dmem + (size_t)b * T * Hh, dinit + (size_t)b * Hh, dmem + (size_t)b * T * Hh, Hh, s));
+    }
+    RC(add_grad(n.in, dmem));
+    RC(add_grad(n.in2, dkp));
+    return D2T_OK;
+  }
+
   // ---------------- backward ----------------
   int bwd_linear(const Node& n) {
     const TT& y = st->t[n.out];
@@ -727,6 +866,7 @@ struct Tr {  // builder / runner bound to one context and stream
         case N_POOL: RC(bwd_pool(n)); break;
         case N_TOKENS: RC(bwd_tokens(n)); break;
         case N_ADDCONST: RC(add_grad(n.in, st->t[n.out].grad)); break;
+        case N_LSTM: RC(bwd_lstm(n)); break;
         case N_DROPOUT: {
           const TT& x = st->t[n.in];
           float* dx;
@@ -781,10 +921,12 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
                       float* logits, d2t_stream stream) {
   if (!c || !image || !tgt || !logits || B < 1 || H < 1 || W < 1 || L < 1) return fail(c, D2T_EINVAL, "bad argument");
   const d2t_config& g = c->cfg;
-  if (g.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "the training step is implemented for the TFM head only");
+  const bool lstm = g.decoder == D2T_DEC_ATTN;
   if (g.encoder != D2T_ENC_HYBRID_VIT && g.encoder != D2T_ENC_RESNET)
     return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT and ResNet+None encoders");
-  if (L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
+  if (lstm && g.encoder != D2T_ENC_HYBRID_VIT) return fail(c, D2T_ESTATE, "the Attn training step needs the HybridViT encoder");
+  if (lstm && L != g.batch_max_length + 1) return fail(c, D2T_EINVAL, "the Attn head trains on batch_max_length + 1 = %d steps", g.batch_max_length + 1);
+  if (!lstm && L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
   if (g.gcb) return fail(c, D2T_ESTATE, "the training step does not support GlobalContext blocks (gcb)");
   if (!c->train) c->train = new d2t_train_state();
   d2t_train_state* st = c->train;
@@ -809,7 +951,8 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
     RC(d2t_internal_pe2d(c, f.H, f.W, f.cols, (hipStream_t)stream, &pe));
     RC(tr.add_const(feat, pe, &mem));
   }
-  RC(tr.decoder(mem, tgt, B, L, "predicter.Prediction.", logits, &out));
+  if (lstm) RC(tr.lstm_decoder(mem, tgt, B, L, logits, &out));
+  else RC(tr.decoder(mem, tgt, B, L, "predicter.Prediction.", logits, &out));
   st->logits_id = out;
   st->have_forward = true;
   return D2T_OK;

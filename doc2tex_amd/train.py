@@ -12,7 +12,9 @@ import torch
 class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, text, names, *params):
-        eng = model.engine(finalize=False)
+        # the LSTM-attention head reads the engine's derived (transposed / folded) decoder weights, so it needs the
+        # finalize pass; the TFM head reads the raw copies only
+        eng = model.engine(finalize=model.stages["Pred"] != "TFM")
         # nn.TransformerDecoderLayer(dropout=p): masks from the engine's Philox stream, seeded like torch's generator
         p = float(model.opt["Prediction"]["params"].get("dropout", 0.0) or 0.0)
         eng.set_dropout(p, torch.initial_seed())

@@ -48,16 +48,25 @@ def _l2_errors(m, ograds):
     out = {}
     for k, g in ograds.items():
         g = g.double()
-        out[k] = float((params[k].grad.double().cpu() - g).norm() / max(float(g.norm()), 1e-30))
+        err = float((params[k].grad.double().cpu() - g).norm())
+        if float(g.norm()) < 1e-6:  # mathematically zero gradients (the score bias under the softmax): rounding noise only
+            assert err < 1e-5, (k, err)
+            out[k] = 0.0
+        else:
+            out[k] = err / float(g.norm())
     return out
 
 
 def _check_instance(m, ograds):
     params = dict(m.named_parameters())
-    last = max(int(k.split("layers.")[1].split(".")[0]) for k in ograds if "model.layers." in k)
-    strict = [k for k in ograds if k.startswith("predicter.Prediction.proj.")
-              or (f"model.layers.{last}." in k and ("linear2" in k or "norm3" in k))]
-    assert len(strict) == 6
+    if any("model.layers." in k for k in ograds):  # TFM head
+        last = max(int(k.split("layers.")[1].split(".")[0]) for k in ograds if "model.layers." in k)
+        strict = [k for k in ograds if k.startswith("predicter.Prediction.proj.")
+                  or (f"model.layers.{last}." in k and ("linear2" in k or "norm3" in k))]
+        assert len(strict) == 6
+    else:  # LSTM-attention head: the generator is downstream of every decision
+        strict = [k for k in ograds if ".generator." in k]
+        assert len(strict) == 2
     for k in strict:
         assert _rel(params[k].grad, ograds[k]) <= 1e-4, (k, _rel(params[k].grad, ograds[k]))
     l2 = _l2_errors(m, ograds)
@@ -67,10 +76,11 @@ def _check_instance(m, ograds):
     return max(upper)
 
 
-@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step"])
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """Loss, logits, BatchNorm running statistics and gradient norms of the reference's own step (fixture):
-    HybridViT + TFM (t2) and ResNet + PositionalEncoding2D + TFM with d_model 512 (t1)."""
+    HybridViT + TFM (t2), ResNet + PositionalEncoding2D + TFM with d_model 512 (t1), and HybridViT + Attnv2 -- the
+    LSTM-attention head of the shipped config/train.yaml, teacher-forced (ts0)."""
     c = _case(cases, "train_step", name)
     z = np.load(os.path.join(GOLD, name + ".npz"))
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
@@ -86,7 +96,9 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
         assert _rel(bufs[k], v) <= 1e-4, k
         assert np.abs(bufs[k].cpu().numpy() - z["bn:" + k]).max() <= 1e-4 * max(1.0, float(np.abs(z["bn:" + k]).max())), k
     assert int(bufs[next(k for k in bufs if k.endswith("num_batches_tracked"))]) == 1
-    _check_instance(m, ograds)
+    upper = _check_instance(m, ograds)
+    if name == "ts0_train_step":  # no ReLU in the LSTM head: decoder + ViT are flip-free on this instance (measured 3e-5)
+        assert upper <= 1e-3, upper
     params = dict(m.named_parameters())
     for k, (norm, _) in c["grad_norms"].items():
         assert abs(float(params[k].grad.double().norm()) - norm) <= 3e-2 * max(norm, 1e-6), k
@@ -94,7 +106,9 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
         assert params["seqmodeler.SequenceModeling.pos_embed"].grad is None  # frozen (vit_encoder.py:235-237)
     m.eval()  # the model still serves inference, now with the updated running statistics
     with torch.no_grad():
-        out = m(img.cuda(), torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda"), is_train=False)
+        go = (torch.zeros(c["B"], c["max_seq_len"] + 1, dtype=torch.long) if name.startswith("ts0")
+              else torch.full((c["B"], 1), R.GO, dtype=torch.long))
+        out = m(img.cuda(), go.cuda(), is_train=False)
         omem, _, _ = R.forward_encoder(cfg, {**sd, **obn}, img, faithful=True)
         mem, _, _ = m.forward_encoder(img.cuda())
     assert out[0].shape[0] == c["B"]
