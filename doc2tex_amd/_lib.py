@@ -52,6 +52,7 @@ SIGNATURES = {
     "d2t_train_grad": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "d2t_read_weight": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "d2t_train_set_dropout": (_I, [_P, C.c_float, C.c_uint64]),
+    "d2t_train_set_teacher_flags": (_I, [_P, C.c_char_p, _I]),
     "d2t_train_mask_count": (_I, [_P]),
     "d2t_train_read_mask": (_I, [_P, _I, _P, C.c_int64, _P]),
     "d2t_train_release": (None, [_P]),

@@ -195,17 +195,12 @@ class Model(nn.Module):
             # with is_train), one autograd node over the whole network so that loss.backward() (engine/training.py:137)
             # fills every .grad
             from .train import train_forward
-            pp = self.opt["Prediction"]["params"]
             if self.stages["Pred"] == "TFM":
                 if self.stages["Seq"] not in ("ViT", "None"):
                     raise NotImplementedError("the training step is implemented for the HybridViT + TFM and ResNet + TFM stacks")
             else:  # Attn / Attnv2
                 if self.stages["Seq"] != "ViT":
                     raise NotImplementedError("training the LSTM-attention head is implemented on the HybridViT encoder only")
-                if pp.get("droprate", 0.0) != 0.0:
-                    raise NotImplementedError("training the LSTM-attention head with droprate > 0 is not implemented")
-                if pp.get("teacher_forcing", 1.0) < 1.0:
-                    raise NotImplementedError("scheduled sampling (teacher_forcing < 1, seq2seq.py:311-314) is not implemented")
             if self.engine(finalize=False).cfg.gcb:
                 raise NotImplementedError("training with GlobalContext blocks (gcb: True) is not implemented in the HIP engine")
             logits = train_forward(self, input, text)

@@ -111,6 +111,10 @@ struct AttnDecP {
   // Training forward (teacher forcing, seq2seq.py:311-316): the input token of step t is teacher[b*S + t]; the
   // recurrent state of every step is saved for the backward pass (all optional).
   const int64_t* teacher;
+  const uint8_t* use_teacher;   // optional [S]: 0 = feed the model's own argmax at that step (scheduled sampling)
+  const uint8_t* out_dropmask;  // optional [B][S][V] keep mask of the dropout on the generator output (seq2seq.py:298)
+  float out_dropscale;
+  int64_t* sv_tok;              // [B][S] the input token each step actually used
   float *sv_hprev, *sv_cprev, *sv_hafter, *sv_cafter;  // [B][S][H]: LSTM state before / after step t
   float* sv_gates;         // [B][S][4H]: i, f, g, o after their nonlinearities
   float* sv_alpha;         // [B][S][T - key_off]

@@ -178,7 +178,10 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   }
 
   for (int step = 0; step < p.S; ++step) {
-    if (p.teacher && tid == 0) tok_s = (int)p.teacher[(size_t)b * p.S + step];
+    if (p.teacher && tid == 0) {
+      if (step == 0 || !p.use_teacher || p.use_teacher[step]) tok_s = (int)p.teacher[(size_t)b * p.S + step];
+      if (p.sv_tok) p.sv_tok[(size_t)b * p.S + step] = tok_s;  // otherwise: the argmax of the previous step
+    }
     if (p.sv_hprev && tid < H) {
       p.sv_hprev[((size_t)b * p.S + step) * H + tid] = h_s[tid];
       p.sv_cprev[((size_t)b * p.S + step) * H + tid] = c_s[tid];
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
       v = p.bg[tid];
 #pragma unroll 8
       for (int k = 0; k < H; ++k) v = fmaf(h_s[k], p.wg_t[(size_t)k * p.V + tid], v);
+      if (p.out_dropmask) v = p.out_dropmask[((size_t)b * p.S + step) * p.V + tid] ? v * p.out_dropscale : 0.f;
       p.probs[((size_t)b * p.S + step) * p.V + tid] = v;
     }
     logit_s[tid] = v;

@@ -96,6 +96,7 @@ struct d2t_train_state {
   // dropout of nn.TransformerDecoderLayer (d2t_train_set_dropout): Philox masks keyed by (seed, forward call, site)
   float drop_p = 0.f;
   unsigned long long drop_seed = 0, drop_calls = 0, drop_site = 0;
+  std::vector<uint8_t> teacher_flags;  // d2t_train_set_teacher_flags (scheduled sampling of the LSTM head); empty = all teacher
   std::vector<std::pair<const uint8_t*, size_t>> masks;  // in creation order (d2t_train_read_mask)
   int B = 0, H = 0, W = 0, L = 0;
   int logits_id = -1;
@@ -570,9 +571,24 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(alloc(&n.aux[5], BS * Tk));      // alpha
     RC(alloc(&n.aux[6], BS * Hh));      // hq
     RC(alloc(&n.aux[7], BS * 2 * Hh));  // [ctx | emb]
-    float* dummy;
+    float *dummy, *tokbuf;
     RC(alloc(&dummy, BS * 2 + B + 16));  // tokens (int64) and end_step scratch
+    RC(alloc(&tokbuf, BS * 2 + 2));      // input token per (row, step), int64
+    n.keytok = reinterpret_cast<const int64_t*>(tokbuf);
     RC(new_tensor((long long)BS, V, out, 0, 0, 0, logits));
+    if (st->drop_p > 0.f) {  // nn.Dropout(droprate) on the generator output of every step (seq2seq.py:298)
+      RC(new_mask(BS * V, &n.mask));
+      n.mscale = 1.f / (1.f - st->drop_p);
+    }
+    const uint8_t* d_flags = nullptr;
+    if (!st->teacher_flags.empty()) {
+      if ((int)st->teacher_flags.size() != S) return fail(c, D2T_EINVAL, "teacher flags: %zu entries for %d steps", st->teacher_flags.size(), S);
+      float* fb;
+      RC(alloc(&fb, S / 4 + 2));
+      TCHK(hipMemcpyAsync(fb, st->teacher_flags.data(), S, hipMemcpyHostToDevice, s));
+      TCHK(hipStreamSynchronize(s));  // the host vector may change before an asynchronous copy would run
+      d_flags = reinterpret_cast<const uint8_t*>(fb);
+    }
     AttnDecP p{};
     p.mem = st->t[mem].p; p.T = T; p.D = Hh; p.key_off = key_off;
     p.init_mode = !g.attn_enc_init ? 0 : 2;
@@ -583,7 +599,8 @@ struct Tr {  // builder / runner bound to one context and stream
     p.emb = c->attn.emb; p.probs = logits; p.tokens = reinterpret_cast<int64_t*>(dummy);
     p.end_step = reinterpret_cast<int*>(dummy + BS * 2);
     p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage; p.end_token = 1;
-    p.teacher = tgt;
+    p.teacher = tgt; p.use_teacher = d_flags; p.out_dropmask = n.mask; p.out_dropscale = n.mscale;
+    p.sv_tok = reinterpret_cast<int64_t*>(tokbuf);
     p.sv_hprev = n.aux[0]; p.sv_cprev = n.aux[1]; p.sv_hafter = n.aux[2]; p.sv_cafter = n.aux[3];
     p.sv_gates = n.aux[4]; p.sv_alpha = n.aux[5]; p.sv_hq = n.aux[6]; p.sv_x = n.aux[7];
     TCHK(launch_attn_decode(p, s));
@@ -605,6 +622,12 @@ struct Tr {  // builder / runner bound to one context and stream
     const TT& mem = st->t[n.in];
     const TT& kp = st->t[n.in2];
     const float* dl = st->t[n.out].grad;
+    if (n.mask) {  // output dropout: everything upstream sees the masked, rescaled gradient
+      float* dlm;
+      RC(alloc(&dlm, (size_t)BS * V));
+      TCHK(launch_apply_mask(dl, n.mask, n.mscale, dlm, (size_t)BS * V, s));
+      dl = dlm;
+    }
     const float *wih, *whh, *wq, *cw, *cb, *pw;
     RC(raw(ac + "rnn.weight_ih", &wih));
     RC(raw(ac + "rnn.weight_hh", &whh));
@@ -662,7 +685,7 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(grad_buf(ac + "attn.loc_proj.bias", &gpb));
     TCHK(launch_loc_unfold_bwd(dwloc, dbloc, B, cw, cb, pw, Hh, kd, taps, gcw, gcb, gpw, gpb, s));
     RC(grad_buf(pp + "embedding.weight", &gW));
-    TCHK(launch_embed_bwd(demb, st->tgt, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
+    TCHK(launch_embed_bwd(demb, n.keytok, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
     if (g.attn_enc_init) {  // h0 / c0 = proj_init_{h,c}(memory[:, 0])
       RC(grad_buf(pp + "proj_init_h.weight", &gW));
       RC(grad_buf(pp + "proj_init_h.bias", &gB));
@@ -998,6 +1021,13 @@ int d2t_train_set_dropout(d2t_ctx* c, float p, uint64_t seed) {
   if (c->train->drop_seed != seed) c->train->drop_calls = 0;
   c->train->drop_p = p;
   c->train->drop_seed = seed;
+  return D2T_OK;
+}
+
+int d2t_train_set_teacher_flags(d2t_ctx* c, const uint8_t* flags, int32_t n) {
+  if (!c || n < 0 || (n > 0 && !flags)) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->train) c->train = new d2t_train_state();
+  c->train->teacher_flags.assign(flags, flags + n);
   return D2T_OK;
 }
 

@@ -159,6 +159,12 @@ class Engine:
         """Dropout probability of the decoder layers in the training step and the seed of its Philox masks."""
         self._check(self.lib.d2t_train_set_dropout(self.ctx, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF), "train_set_dropout")
 
+    def set_teacher_flags(self, flags):
+        """Scheduled sampling of the LSTM-attention head: flags[t] = 1 feeds the label at step t, 0 the model's own
+        arg-max (seq2seq.py:311-316).  None / empty = always the label."""
+        data = bytes(bytearray(int(bool(f)) for f in flags)) if flags else b""
+        self._check(self.lib.d2t_train_set_teacher_flags(self.ctx, data, len(data)), "train_set_teacher_flags")
+
     def mask_count(self):
         return int(self.lib.d2t_train_mask_count(self.ctx))
 

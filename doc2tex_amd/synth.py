@@ -130,6 +130,10 @@ _CONFIGS["TS0"] = copy.deepcopy(_CONFIGS["S0"])  # tiny S0
 _CONFIGS["TS0"]["SequenceModeling"] = _vit_seq(depth=2)
 _CONFIGS["TS0"]["max_dimension"] = [48, 64]
 _CONFIGS["TS0"]["_crop"] = (48, 64)
+# the shipped training recipe of the LSTM head (config/train.yaml:38-49): droprate 0.25, plus scheduled sampling
+_CONFIGS["TS0D"] = copy.deepcopy(_CONFIGS["TS0"])
+_CONFIGS["TS0D"]["Prediction"]["params"]["droprate"] = 0.25
+_CONFIGS["TS0D"]["Prediction"]["params"]["teacher_forcing"] = 0.7
 _CONFIGS["C3"] = copy.deepcopy(_CONFIGS["C2"])
 _CONFIGS["C3"]["_batch"] = 32  # per GPU; 256 global over 8 GPUs
 

@@ -15,9 +15,19 @@ class _TrainStep(torch.autograd.Function):
         # the LSTM-attention head reads the engine's derived (transposed / folded) decoder weights, so it needs the
         # finalize pass; the TFM head reads the raw copies only
         eng = model.engine(finalize=model.stages["Pred"] != "TFM")
-        # nn.TransformerDecoderLayer(dropout=p): masks from the engine's Philox stream, seeded like torch's generator
-        p = float(model.opt["Prediction"]["params"].get("dropout", 0.0) or 0.0)
+        # dropout (nn.TransformerDecoderLayer(dropout=p) / the LSTM head's droprate on its generator output): masks from
+        # the engine's Philox stream, seeded like torch's generator
+        pp = model.opt["Prediction"]["params"]
+        tfm = model.stages["Pred"] == "TFM"
+        p = float(pp.get("dropout" if tfm else "droprate", 0.0) or 0.0)
         eng.set_dropout(p, torch.initial_seed())
+        if not tfm:
+            # scheduled sampling (seq2seq.py:311-316): one random.random() per step but the last, drawn exactly as the
+            # reference draws them, so seeding `random` reproduces its choices
+            import random
+            tf = float(pp.get("teacher_forcing", 1.0))
+            flags = [1] + [0 if tf < random.random() else 1 for _ in range(text.shape[1] - 1)]
+            eng.set_teacher_flags(None if all(flags) else flags)
         logits = eng.train_forward(image, text)
         # BatchNorm side effects of module.train(): running statistics and the batch counter
         with torch.no_grad():

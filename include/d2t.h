@@ -214,6 +214,11 @@ int d2t_read_weight(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d
  * the same as torch's dropout, not the same random stream.  p = 0 (default) disables it.  The masks of the last
  * forward can be read back (creation order = the order torch draws them) for verification. */
 int d2t_train_set_dropout(d2t_ctx* ctx, float p, uint64_t seed);
+/* LSTM-attention head only.  (a) d2t_train_set_dropout's p is the head's `droprate`: dropout on the generator output
+ * of every step (seq2seq.py:298), one [B][S][V] mask.  (b) Scheduled sampling (seq2seq.py:311-316): flags[t] (host
+ * bytes, n = batch_max_length + 1 of them; flags[0] is ignored) says whether step t is fed the label token (1) or the
+ * arg-max of step t-1's output (0).  n = 0 restores "always the label".  The flags apply to the following forwards. */
+int d2t_train_set_teacher_flags(d2t_ctx* ctx, const uint8_t* flags, int32_t n);
 int d2t_train_mask_count(d2t_ctx* ctx);
 int d2t_train_read_mask(d2t_ctx* ctx, int32_t index, uint8_t* dst, int64_t numel, d2t_stream stream);
 /* free the training tape, gradient buffers and workspace */

@@ -452,7 +452,8 @@ def bilstm(x, sd, p):
     return F.linear(torch.cat(outs, dim=2), sd[p + "linear.weight"], sd[p + "linear.bias"])
 
 
-def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False, teacher=None):
+def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False, teacher=None,
+                flags=None, drop=None):
     """Attention.forward_greedy (prediction_head/seq2seq.py:224-331) / AttentionV2.forward_greedy
     (seq2seq_v2.py:176-293) in eval mode (is_train=False) with embed_target=True, on the
     LocationAwareAttention cell (addon_module/attention1D.py:121-161,203-242).
@@ -499,11 +500,16 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
             mem = alpha_cum
         else:  # loc_aware
             mem = alpha
-        if teacher is not None:  # is_train with teacher_forcing = 1.0 (seq2seq.py:311-316): next input = text[:, i + 1]
+        if teacher is not None:
+            # is_train (seq2seq.py:298-316): dropout on the generator output, then the next input is the label
+            # text[:, i + 1] unless scheduled sampling (teacher_forcing < random.random(), flags[i + 1] == 0 here)
+            # picks the arg-max of the (dropped) output
+            if drop is not None:
+                out = out * drop(out.shape, "hidden")
             probs[:, i] = out
             if i == num_steps - 1:
                 break
-            targets = teacher[:, i + 1]
+            targets = teacher[:, i + 1] if (flags is None or flags[i + 1]) else out.argmax(1)
             continue
         probs[:, i] = out
         if i == num_steps - 1:
@@ -666,7 +672,7 @@ def is_trainable(key):
     return tail not in ("running_mean", "running_var", "num_batches_tracked", "pe", "pos_embed")
 
 
-def train_forward(cfg, sd, image, text_in, bn_train, drop=None):
+def train_forward(cfg, sd, image, text_in, bn_train, drop=None, flags=None):
     """Model.forward under module.train(): BatchNorm on batch statistics (their running updates are left in
     `bn_train`); TFM head: teacher-forced decoder pass with causal + PAD key-padding masks (tfm.py:103-118);
     Attn / Attnv2 heads: the LSTM-attention loop fed with the label tokens (teacher_forcing = 1.0,
@@ -678,18 +684,18 @@ def train_forward(cfg, sd, image, text_in, bn_train, drop=None):
         if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
             sm = "first"
         return attn_greedy(mem, sd, "predicter.Prediction.", cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
-                           pp.get("enc_init", False), teacher=text_in)[1]
+                           pp.get("enc_init", False), teacher=text_in, flags=flags, drop=drop)[1]
     return tfm_full_pass(text_in, mem, sd, "predicter.Prediction.", pp["num_decoder_layers"], pp["nhead"],
                          key_padding=True, drop=drop)
 
 
-def train_step_grads(cfg, sd, image, text, drop=None):
+def train_step_grads(cfg, sd, image, text, drop=None, flags=None):
     """forward_step + loss.backward() (engine/training.py:83-88,126,137): text [B,L+1] with [GO] first;
     the model sees text[:, :-1], the target is text[:, 1:].  Returns (loss, logits, {key: grad}, bn_train)."""
     params = {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and is_trainable(k)) else v)
               for k, v in sd.items()}
     bn_train = {}
-    logits = train_forward(cfg, params, image, text[:, :-1], bn_train, drop)
+    logits = train_forward(cfg, params, image, text[:, :-1], bn_train, drop, flags)
     # CE ignore_index: PAD = 0 for the TFM converter; for the Attn converter index 0 is [GO], also ignored
     # (attn_converter.py:17) -- the same call either way
     loss = ce_loss(logits, text[:, 1:])

@@ -153,21 +153,26 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
         assert np.abs(v.numpy() - z["bn:" + k]).max() <= 1e-5 * max(1.0, float(np.abs(z["bn:" + k]).max())), k
 
 
-def test_train_dropout_placement_matches_reference_fixture(cases, manifests):
-    """Decoder-layer dropout (p = 0.1): with the seeded masks tools/make_golden.py fed to the reference through a
-    replaced torch.nn.functional.dropout, the oracle reproduces the reference's loss and logits."""
-    c = _case(cases, "train_dropout", "t2d_train_dropout")
+@pytest.mark.parametrize("name", ["t2d_train_dropout", "ts0d_train_dropout"])
+def test_train_dropout_placement_matches_reference_fixture(cases, manifests, name):
+    """Dropout placement.  TFM decoder layers (p = 0.1) and the LSTM head's generator-output dropout (0.25) with
+    scheduled sampling (teacher_forcing 0.7): with the seeded masks tools/make_golden.py fed to the reference through a
+    replaced torch.nn.functional.dropout (and the same `random` stream), the oracle reproduces its loss and logits."""
+    c = _case(cases, "train_dropout", name)
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
     img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
-    text = synth.synth_labels(c["B"], max_len=c["max_seq_len"], seed=c["iseed"])
+    text = (train_step_labels({**c, "config": "TS0"}) if name.startswith("ts0")
+            else synth.synth_labels(c["B"], max_len=c["max_seq_len"], seed=c["iseed"]))
     g = torch.Generator().manual_seed(c["mask_seed"])
 
     def drop(shape, kind):
         if kind == "attn":  # switched off in the pinning run (lives inside scaled_dot_product_attention)
             return torch.ones(tuple(shape))
+        if len(shape) == 2:
+            return (torch.rand(tuple(shape), generator=g) >= c["p"]).float() / (1.0 - c["p"])
         B, L, D = shape
         return ((torch.rand((L, B, D), generator=g) >= c["p"]).float() / (1.0 - c["p"])).transpose(0, 1)
 
-    loss, logits, grads, _ = R.train_step_grads(cfg, sd, img, text, drop=drop)
+    loss, logits, grads, _ = R.train_step_grads(cfg, sd, img, text, drop=drop, flags=c.get("flags"))
     assert abs(float(loss) - c["loss"]) <= 1e-5 * max(1.0, abs(c["loss"]))
     assert abs(float(logits.double().sum()) - c["logits_sum"]) <= 1e-3 * max(1.0, abs(c["logits_sum"]))

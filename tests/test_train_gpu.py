@@ -248,3 +248,36 @@ def test_train_step_with_dropout(cases, manifests):
     for k, q in m.named_parameters():
         if q.grad is not None:
             assert torch.equal(q.grad, g1[k]), k
+
+
+def test_lstm_head_training_with_output_dropout_and_scheduled_sampling(cases, manifests):
+    """The shipped training recipe of the LSTM head (config/train.yaml: droprate 0.25) plus scheduled sampling
+    (teacher_forcing 0.7): the engine draws the `random` numbers exactly as the reference does (so the fixture's
+    sampled steps are reproduced) and its own Philox output mask; the oracle on the same flags and mask agrees."""
+    import random
+    c = _case(cases, "train_dropout", "ts0d_train_dropout")
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"])
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels({**c, "config": "TS0"})
+    flags = c["flags"]
+    assert 0 in flags[1:] and 1 in flags[1:]
+    random.seed(c["mask_seed"])  # the reference's random.random() stream of the fixture run
+    torch.manual_seed(99)
+    loss, preds = _step(m, img, text)
+    eng = m._engine
+    assert eng.mask_count() == 1
+    S, V, p = c["max_seq_len"] + 1, preds.shape[-1], c["p"]
+    mask = eng.read_mask(0, c["B"] * S * V).cpu().float().reshape(c["B"], S, V)
+    assert abs(float(mask.mean()) - (1.0 - p)) < 0.02
+    step = [0]
+
+    def drop(shape, kind):
+        mk = mask[:, step[0], :] / (1.0 - p)
+        step[0] += 1
+        return mk
+
+    oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text, drop=drop, flags=flags)
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
+    assert _check_instance(m, ograds) <= 3e-2

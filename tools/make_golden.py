@@ -79,7 +79,9 @@ TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_tra
                     ("ts0_train_step", "TS0", 3, 48, 64, 24, 1234, 1032)]
 GRAD_SAMPLES = 48
 # dropout placement (p = 0.1 in the decoder layers): name, config, B, H, W, L, wseed, iseed, mask seed
-TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77)]
+TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77),
+                       # LSTM head: droprate 0.25 on the generator output + scheduled sampling (teacher_forcing 0.7)
+                       ("ts0d_train_dropout", "TS0D", 3, 48, 64, 24, 1234, 1061, 78)]
 
 
 def build_ref(cfg_name, max_seq_len, beam_size=None, wseed=1234, end_bias=0.0):
@@ -344,13 +346,17 @@ def run_train_dropout(case):
     be intercepted, is switched off for this run); the oracle gets the same masks at its "hidden" sites."""
     name, cname, B, H, W, L, wseed, iseed, mseed = case
     cfg, m, sd = build_ref(cname, L, wseed=wseed)
-    p = cfg["Prediction"]["params"]["dropout"]
+    lstm = cfg["Prediction"]["name"] != "TFM"
+    p = cfg["Prediction"]["params"]["droprate" if lstm else "dropout"]
     m.train()
-    for layer in m.predicter.Prediction.model.layers:
-        layer.self_attn.dropout = 0.0
-        layer.multihead_attn.dropout = 0.0
+    if not lstm:
+        for layer in m.predicter.Prediction.model.layers:
+            layer.self_attn.dropout = 0.0
+            layer.multihead_attn.dropout = 0.0
     img = synth.synth_images(B, H, W, seed=iseed)
-    text = synth.synth_labels(B, max_len=L, seed=iseed)
+    text = train_labels(cfg, B, L, iseed) if lstm else synth.synth_labels(B, max_len=L, seed=iseed)
+    import random
+    random.seed(mseed)  # scheduled sampling of the LSTM head draws random.random() once per step (seq2seq.py:312)
     src = SeqFirstMasks(p, mseed)
     real = torch.nn.functional.dropout
 
@@ -373,17 +379,24 @@ def run_train_dropout(case):
     def drop(shape, kind):
         if kind == "attn":
             return torch.ones(tuple(shape))
+        if len(shape) == 2:  # LSTM head: one [B, V] mask per step, drawn in that layout
+            return osrc.draw(shape)
         Bq, Lq, D = shape
         return osrc.draw((Lq, Bq, D)).transpose(0, 1)
 
-    oloss, ologits, ograds, _ = R.train_step_grads(cfg, slim_sd(sd), img, text, drop=drop)
+    flags = None
+    if lstm:
+        random.seed(mseed)
+        tf = cfg["Prediction"]["params"].get("teacher_forcing", 1.0)
+        flags = [1] + [0 if tf < random.random() else 1 for _ in range(L)]
+    oloss, ologits, ograds, _ = R.train_step_grads(cfg, slim_sd(sd), img, text, drop=drop, flags=flags)
     assert abs(float(oloss) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (float(oloss), float(loss))
     assert maxdiff(ologits, preds.detach()) <= TOL
     worst = max(float((ograds[k].double() - g.double()).abs().max() / max(1e-6, float(g.double().abs().max())))
                 for k, g in ref_grads.items())
     assert worst <= 5e-4, worst
     return {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
-            "mask_seed": mseed, "p": p, "loss": float(loss), "logits_sum": float(preds.detach().double().sum()),
+            "mask_seed": mseed, "p": p, "flags": flags, "loss": float(loss), "logits_sum": float(preds.detach().double().sum()),
             "oracle_worst_rel_grad_diff": worst, "torch": torch.__version__}
 
 
@@ -402,8 +415,8 @@ def main():
             rep = run_train_dropout(case)
             summary["train_dropout"].append(rep)
             print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
-        cfg_, m_, sd_ = build_ref("T2D", 24)
-        manifests["T2D"] = manifest(sd_)
+        for cn in ("T2D", "TS0D"):
+            manifests[cn] = manifest(build_ref(cn, 24)[2])
         with open(os.path.join(GOLD, "cases.json"), "w") as f:
             json.dump(summary, f, indent=1)
         with open(os.path.join(GOLD, "manifests.json"), "w") as f:
@@ -476,7 +489,8 @@ def main():
         rep = run_train_dropout(case)
         summary["train_dropout"].append(rep)
         print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
-    manifests["T2D"] = manifest(build_ref("T2D", 24)[2])
+    for cn in ("T2D", "TS0D"):
+        manifests[cn] = manifest(build_ref(cn, 24)[2])
     with open(os.path.join(GOLD, "cases.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(GOLD, "manifests.json"), "w") as f:
