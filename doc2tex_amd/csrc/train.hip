@@ -191,7 +191,17 @@ struct Tr {  // builder / runner bound to one context and stream
             const TT* xin, const TT* yout, float* dst, int layout) {
     const int tile = (M <= 64 || N <= 64) ? 64 : 128;
     const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps;
-    long long S = std::max<long long>(1, std::min<long long>((P + 511) / 512, (1536 + tiles - 1) / tiles));
+    // split the rows into S chunks so that tiles * S blocks fill whole rounds of the 512 block slots (two 64 KB-LDS
+    // blocks per CU on 256 CUs): among the S that give >= ~2 rounds pick the one wasting least of its last round
+    const long long smax = std::max<long long>(1, (P + 511) / 512);
+    long long S = 1;
+    double best = -1.0;
+    for (long long cand = 1; cand <= std::min<long long>(smax, 64); ++cand) {
+      const long long blocks = tiles * cand, rounds = (blocks + 511) / 512;
+      double eff = (double)blocks / (double)(rounds * 512);
+      if (blocks < 1024 && cand < smax) eff *= 0.5;  // prefer enough blocks to hide the tile prologue / epilogue
+      if (eff > best + 1e-9) { best = eff; S = cand; }
+    }
     long long chunk = ((P + S - 1) / S + 31) / 32 * 32;
     S = (P + chunk - 1) / chunk;
     RC(ensure_part((size_t)S * taps * M * N));
