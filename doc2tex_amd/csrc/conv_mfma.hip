@@ -162,8 +162,9 @@ static hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
 hipError_t launch_conv(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
   if (p.in_hi) return launch_conv_bf16x3(p, s);  // split-bf16 input planes: only that kernel reads them
-  if (p.w_hi && p.w_lo && p.Cout >= 64 && (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= 128)
-    return launch_conv_bf16x3(p, s);
+  // bf16 weight planes select the split-bf16 kernel whatever the problem size, so that a row's result never depends on
+  // how many other rows (batch size, shard) share the launch
+  if (p.w_hi && p.w_lo && p.Cout >= 64) return launch_conv_bf16x3(p, s);
   if (p.Cin % BK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
   const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   if (p.Cout <= 64) {

@@ -525,8 +525,9 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
   __syncthreads();
   // ---- cross-attention over the memory K/V, wave = head ----
   {
-    const float* Kc = p.ck + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
-    const float* Vc = p.cv + (size_t)b * p.c_batch_stride + (size_t)wave * p.T * HD;
+    const int cb = p.c_row_map ? p.c_row_map[b] : b;
+    const float* Kc = p.ck + (size_t)cb * p.c_batch_stride + (size_t)wave * p.T * HD;
+    const float* Vc = p.cv + (size_t)cb * p.c_batch_stride + (size_t)wave * p.T * HD;
     row_attention<HD, 8>(q2_s + wave * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + wave * HD, lane);
   }
   __syncthreads();
@@ -568,7 +569,18 @@ hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t*
 
 __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits,
                                                         const float* __restrict__ scores, int M, int V, int k,
-                                                        float* __restrict__ topv, int* __restrict__ topi) {
+                                                        float* __restrict__ topv, int* __restrict__ topi,
+                                                        const int* __restrict__ seg, int kmax) {
+  if (seg) {  // batched form: this block's segment of rows
+    const int off = seg[blockIdx.x * 3];
+    M = seg[blockIdx.x * 3 + 1];
+    k = seg[blockIdx.x * 3 + 2];
+    if (M <= 0 || k <= 0) return;  // block-uniform
+    logits += (size_t)off * V;
+    scores += off;
+    topv += (size_t)blockIdx.x * kmax;
+    topi += (size_t)blockIdx.x * kmax;
+  }
   __shared__ float s_lse[16];
   __shared__ float r_v[4];
   __shared__ int r_i[4];
@@ -624,7 +636,13 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
 hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
                             hipStream_t s) {
   if (M < 1 || M > 16 || k < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(256), 0, s, logits, scores, M, V, k, topv, topi);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(256), 0, s, logits, scores, M, V, k, topv, topi, nullptr, 0);
+  return hipGetLastError();
+}
+hipError_t launch_beam_topk_batch(const float* logits, const float* scores, const int* seg, int N, int V, int kmax,
+                                  float* topv, int* topi, hipStream_t s) {
+  if (N < 1 || kmax < 1 || kmax > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(N), dim3(256), 0, s, logits, scores, 0, V, 0, topv, topi, seg, kmax);
   return hipGetLastError();
 }
 

@@ -136,7 +136,9 @@ hipError_t linear_big(d2t_ctx* c, hipStream_t s, const float* x, const LinW& w, 
 
 hipError_t linear_any(d2t_ctx* c, hipStream_t s, const float* x, const LinW& w, const float* res, float* y, int M,
                       int act) {
-  if (M > 64 && w.K % 32 == 0) return linear_big(c, s, x, w, res, y, M, act);
+  // always the MFMA GEMM when the shape allows it (not only for M > 64): a row's result must not depend on how many
+  // rows share the launch, or a sample would decode differently alone and inside a batch
+  if (w.K % 32 == 0) return linear_big(c, s, x, w, res, y, M, act);
   SkinnyP p{};
   p.x = x; p.w = w.w; p.bias = w.b; p.res = res; p.y = y;
   p.M = M; p.K = w.K; p.N = w.N; p.ldx = w.K; p.ldy = w.N; p.ldres = w.N; p.act = act;
@@ -866,14 +868,16 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 // All position-dependent values come from the device step counter (graph-replayable).
 // shared_mem: cross K/V of sample 0 shared by every row (beam search over one sample).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
-                       float* logits, long long logit_row_stride, long long logit_step_stride) {
+                       float* logits, long long logit_row_stride, long long logit_step_stride, int ckvB = -1,
+                       const int* row_map = nullptr) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
   hipError_t e;
 #define TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
   const size_t skv_layer = (size_t)kvB * heads * Lmax * hd;
-  const size_t ckv_slab = (size_t)(shared_mem ? 1 : kvB) * heads * T * hd;
+  // batched beam search: ckvB samples' cross K/V, row b attends over sample row_map[b]
+  const size_t ckv_slab = (size_t)(shared_mem ? 1 : (ckvB > 0 ? ckvB : kvB)) * heads * T * hd;
   for (int l = 0; l < g.dec_layers; ++l) {
     const DecLayer& L = c->dec[l];
     if (l == 0) {
@@ -887,6 +891,7 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.s_batch_stride = (long long)heads * Lmax * hd; r.s_Lmax = Lmax;
     r.ck = c->ckv + (size_t)(2 * l) * ckv_slab; r.cv = c->ckv + (size_t)(2 * l + 1) * ckv_slab;
     r.c_batch_stride = shared_mem ? 0 : (long long)heads * T * hd;  // beam: every hypothesis reads sample 0
+    r.c_row_map = row_map;
     r.T = T;
     r.wo_t = L.sa_out_t; r.bo = L.sa_out.b; r.ln1_g = L.n1.g; r.ln1_b = L.n1.b; r.eps = 1e-5f;
     r.wq_t = L.ca_q_t; r.bq = L.ca_q.b; r.wco_t = L.ca_out_t; r.bco = L.ca_out.b;
@@ -1353,6 +1358,150 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   for (int i = 0; i < n; ++i) seq_out[i] = bh.seq[i];
   *len_out = n;
   *score_out = bh.score;
+  return done(D2T_OK);
+}
+
+int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
+                          int32_t* len_out, float* score_out, d2t_stream stream) {
+  // forward_beam (tfm.py:145-186) + Beam (tools/beam.py) for N samples AT ONCE: the hypotheses of all samples are rows
+  // of one step loop (each row attends over its own sample's cross K/V through a row map), log_softmax + top-k run per
+  // sample segment, the bookkeeping of every sample is the single-sample one.  Results equal N calls of
+  // d2t_decode_beam; the point is throughput (one host round trip per step instead of N).
+  if (!c || !memory || !seq_out || !len_out || !score_out || N < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
+  if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "beam search is implemented for the TFM decoder only");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  const d2t_config& g = c->cfg;
+  const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = N * beam_size;
+  const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
+  if ((long long)beam_size * V > 16 * 4096) return fail(c, D2T_EINVAL, "beam_size * vocab too large");
+  select_chain(c, 0);
+  hipStream_t user = (hipStream_t)stream, s = c->dstream;
+  DecBufs bf;
+  int rc = dec_prepare(c, cap, T, &bf);
+  if (rc) return rc;
+  const size_t skv_bytes = (size_t)g.dec_layers * 2 * cap * Lmax * d * 4;
+  if ((rc = ensure(c, &c->skv_alt, &c->skv_alt_cap, skv_bytes))) return rc;
+  // workspace: logits [cap][V] | scores [cap] | topv [cap] | tok [cap] i64 | topi [cap] | prev [cap] | rowmap [cap] | seg [N][3]
+  const size_t nf = (size_t)cap * V + 2 * (size_t)cap;
+  const size_t tok_off = (nf + 1) & ~(size_t)1;
+  const size_t ws_bytes = tok_off * 4 + (size_t)cap * 8 + (3 * (size_t)cap + 3 * (size_t)N) * 4 + 64;
+  if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, ws_bytes))) return rc;
+  float* d_logits = c->beam_ws;
+  float* d_scores = d_logits + (size_t)cap * V;
+  float* d_topv = d_scores + cap;
+  int64_t* d_tok = reinterpret_cast<int64_t*>(d_logits + tok_off);
+  int* d_topi = reinterpret_cast<int*>(d_tok + cap);
+  int* d_prev = d_topi + cap;
+  int* d_map = d_prev + cap;
+  int* d_seg = d_map + cap;
+  char* hp = nullptr;
+  const size_t hbytes = 16 + (size_t)cap * (8 + 4 * 5) + (size_t)N * 12 + 64;
+  if (hipHostMalloc(reinterpret_cast<void**>(&hp), hbytes, hipHostMallocDefault) != hipSuccess)
+    return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
+  int* h_step = reinterpret_cast<int*>(hp);
+  int64_t* h_tok = reinterpret_cast<int64_t*>(hp + 16);
+  float* h_scores = reinterpret_cast<float*>(hp + 16 + (size_t)cap * 8);
+  float* h_topv = h_scores + cap;
+  int* h_topi = reinterpret_cast<int*>(h_topv + cap);
+  int* h_prev = h_topi + cap;
+  int* h_map = h_prev + cap;
+  int* h_seg = h_map + cap;
+  auto done = [&](int code) { hipHostFree(hp); return code; };
+#define BCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return done(fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  BCHK(hipEventRecord(c->ev_in, user));
+  BCHK(hipStreamWaitEvent(s, c->ev_in, 0));
+  BCHK(hipMemsetAsync(c->dstate, 0, (size_t)(4 + cap) * 4, s));
+  c->ckv = c->ckv2[0];
+  BCHK(cross_kv(c, s, memory, N, T));
+  c->skv_cur = c->skv;
+  float* skv_other = c->skv_alt;
+
+  struct Hyp { std::vector<int64_t> seq; float score; };
+  std::vector<std::vector<Hyp>> hyps((size_t)N, std::vector<Hyp>(1)), completed((size_t)N);
+  std::vector<std::vector<int64_t>> last((size_t)N, std::vector<int64_t>{TOK_GO});
+  std::vector<char> finished((size_t)N, 0);
+  for (int i = 0; i < N; ++i) hyps[i][0].score = 0.f;
+  for (int step = 0; step < S; ++step) {
+    int rows = 0, live_samples = 0;
+    for (int i = 0; i < N; ++i) {
+      const int M = finished[i] ? 0 : (int)hyps[i].size();
+      h_seg[3 * i] = rows; h_seg[3 * i + 1] = M; h_seg[3 * i + 2] = finished[i] ? 0 : beam_size - (int)completed[i].size();
+      for (int j = 0; j < M; ++j) { h_tok[rows + j] = last[i][j]; h_scores[rows + j] = hyps[i][j].score; h_map[rows + j] = i; }
+      rows += M;
+      live_samples += M > 0;
+    }
+    if (!rows) break;
+    *h_step = step;
+    BCHK(hipMemcpyAsync(c->dstate, h_step, 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)rows * 8, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_map, h_map, (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_seg, h_seg, (size_t)N * 12, hipMemcpyHostToDevice, s));
+    BCHK(launch_embed_tokens(c->word_embed, c->word_pe, d_tok, c->dstate, bf.x, rows, d, s));
+    BCHK(decode_step(c, s, bf, rows, T, cap, false, d_logits, V, 0, N, d_map));
+    BCHK(launch_beam_topk_batch(d_logits, d_scores, d_seg, N, V, beam_size, d_topv, d_topi, s));
+    BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    int nrows = 0;
+    for (int i = 0; i < N; ++i) {  // Beam.advance (tools/beam.py:68-105) per sample
+      if (finished[i]) continue;
+      const int off = h_seg[3 * i], live = h_seg[3 * i + 2];
+      std::vector<Hyp> next;
+      std::vector<int64_t> nl;
+      std::vector<int> pv;
+      for (int r = 0; r < live; ++r) {
+        const int idx = h_topi[(size_t)i * beam_size + r], prev = idx / V, word = idx % V;
+        Hyp h;
+        h.seq = hyps[i][prev].seq;
+        h.seq.push_back(word);
+        h.score = h_topv[(size_t)i * beam_size + r];
+        if (word == TOK_END) {
+          completed[i].push_back(std::move(h));
+        } else {
+          nl.push_back(word);
+          pv.push_back(off + prev);
+          next.push_back(std::move(h));
+        }
+      }
+      hyps[i].swap(next);
+      last[i].swap(nl);
+      if ((int)completed[i].size() == beam_size) { finished[i] = 1; continue; }  // Beam.done: its rows drop out
+      for (int v : pv) h_prev[nrows++] = v;  // the survivors' caches move to their new row positions
+    }
+    if (nrows && step + 1 < S) {
+      BCHK(hipMemcpyAsync(d_prev, h_prev, (size_t)nrows * 4, hipMemcpyHostToDevice, s));
+      BCHK(launch_cache_gather(c->skv_cur, skv_other, d_prev, g.dec_layers * 2, cap, nrows, heads, Lmax, hd, step + 1, s));
+      std::swap(c->skv_cur, skv_other);
+    }
+    (void)live_samples;
+  }
+  BCHK(hipStreamSynchronize(s));
+#undef BCHK
+  for (int i = 0; i < N; ++i) {
+    std::vector<Hyp>& comp = completed[i];
+    if (comp.empty()) {  // Beam.set_hypothesis (beam.py:132-140)
+      Hyp h = hyps[i].empty() ? Hyp{} : hyps[i][0];
+      h.seq.resize((size_t)g.max_seq_len + 1, TOK_PAD);
+      comp.push_back(std::move(h));
+    }
+    size_t best = 0;
+    for (size_t j = 1; j < comp.size(); ++j)
+      if ((double)comp[j].score / (double)std::max<size_t>(1, comp[j].seq.size()) >
+          (double)comp[best].score / (double)std::max<size_t>(1, comp[best].seq.size()))
+        best = j;
+    const Hyp& bh = comp[best];
+    const int n = (int)std::min<size_t>(bh.seq.size(), (size_t)S);
+    for (int j = 0; j < n; ++j) seq_out[(size_t)i * S + j] = bh.seq[j];
+    len_out[i] = n;
+    score_out[i] = bh.score;
+  }
   return done(D2T_OK);
 }
 

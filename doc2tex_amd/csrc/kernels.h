@@ -177,6 +177,7 @@ struct DecRowP {
   const float* xres;                  // [M][D]
   float* sk; float* sv; long long s_batch_stride; int s_Lmax;
   const float* ck; const float* cv; long long c_batch_stride; int T;
+  const int* c_row_map;               // optional: row b reads the cross K/V of sample c_row_map[b] (batched beam search)
   const float* wo_t; const float* bo;
   const float* ln1_g; const float* ln1_b; float eps;
   const float* wq_t; const float* bq;
@@ -214,6 +215,9 @@ hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t*
 // are written to topv[k], topi[k].  One block; M*V <= 16 * 4096.
 hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
                             hipStream_t s);
+// the same for N independent segments of rows: seg[i] = {first row, rows, k}; results at topv/topi[i * kmax ...]
+hipError_t launch_beam_topk_batch(const float* logits, const float* scores, const int* seg, int N, int V, int kmax,
+                                  float* topv, int* topi, hipStream_t s);
 // dst[slab][i][...] = src[slab][prev[i]][...] for the first `rows` positions of every head
 // (self-attention KV cache reorder after a beam step); caches are [slabs][cap][heads][Lmax][hd].
 hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, int slabs, int cap, int M, int heads,

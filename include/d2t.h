@@ -164,6 +164,12 @@ int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
+/* Beam search for N samples at once (not in the reference, whose forward_beam is single-sample): the same results as
+ * N calls of d2t_decode_beam, with the hypotheses of all samples advanced by one shared step loop.  memory [N][T][d];
+ * seq_out (host) [N][max_seq_len + 1]; len_out, score_out (host) [N]. */
+int d2t_decode_beam_batch(d2t_ctx* ctx, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
+                          int32_t* len_out, float* score_out, d2t_stream stream);
+
 /* LSTM-attention beam search for ONE sample (reference: Attention.forward_beam, prediction_head/seq2seq.py:83-222;
  * AttentionV2.forward_beam, seq2seq_v2.py:12-174 -- what config/test.yaml runs with beam_size 5 / 10).  Coverage
  * attention only.  memory [1][T][256]; seq_out (host, >= batch_max_length + 1 entries) receives the token ids without

@@ -44,7 +44,8 @@ def test_greedy_vs_reference_fixture(cases, name):
     scale = max(1.0, c["mem_absmax"])
     rows = z["mem_rows"].tolist()
     dmem = float(np.abs(mem[:, rows].numpy() - z["mem_sample"]).max()) / scale
-    assert dmem <= 1e-4, f"encoder memory rel err {dmem}"
+    # fp32 arithmetic: 1e-4; the default split-bf16 arithmetic (2^-16 relative per product through 32 convolutions): 5e-4
+    assert dmem <= (1e-4 if m.conv_precision == "fp32" else 5e-4), f"encoder memory rel err {dmem}"
     assert preds.shape[1] == c["steps"], (preds.shape, c["steps"])
     assert np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
     steps = z["logit_steps"].tolist()
@@ -196,6 +197,23 @@ def test_attn_beam_vs_oracle_other_seeds(cases, manifests):
             oseq, oscore, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=True)
         assert seq[0].tolist() == oseq[0].tolist(), (iseed, eb, beam)
         assert abs(float(score) - oscore) <= 1e-3
+
+
+def test_batched_beam_equals_per_sample_beam(cases):
+    """Model.beam_search_batch (hypotheses of all samples in one step loop) returns, for every sample, exactly what
+    the reference-shaped single-sample call returns -- including samples that finish at different steps."""
+    c = _case(cases, "beam", "t2_beam5")
+    for eb, beam in [(1.8, 5), (1.75, 3), (0.0, 4)]:
+        cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], eb, beam_size=beam)
+        img = synth.synth_images(7, c["H"], c["W"], seed=c["iseed"]).cuda()
+        text = torch.full((1, 1), R.GO, dtype=torch.long, device="cuda")
+        with torch.no_grad():
+            single = [m(img[i:i + 1], text, is_train=False, is_test=True)[:2] for i in range(7)]
+            batch = m.beam_search_batch(img)
+        assert len({tuple(s[0].tolist()) for s, _ in single}) > 1 or eb == 0.0
+        for (s1, v1), (s2, v2) in zip(single, batch):
+            assert torch.equal(s1, s2), (eb, beam)
+            assert v1 == v2
 
 
 def test_beam_rejects_batches():

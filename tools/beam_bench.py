@@ -28,11 +28,17 @@ def run():
         return [m.forward_decoder(mem[i:i + 1], go, is_train=False, is_test=True)[0] for i in range(n)]
 
 
-run()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-out = run()
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"C4 beam {beam}, {H}x{W}, {n} samples: {dt * 1e3 / n:.1f} ms per formula = {n / dt:.1f} formulas/s "
-      f"(sequence lengths {sorted(set(int(o.shape[1]) for o in out))})")
+def run_batched():
+    with torch.no_grad():
+        return [s for s, _ in m.beam_search_batch(img, beam)]
+
+
+for name, fn in (("per sample (reference API)", run), ("batched (Model.beam_search_batch)", run_batched)):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"C4 beam {beam}, {H}x{W}, {n} samples, {name}: {dt * 1e3 / n:.1f} ms per formula = {n / dt:.1f} formulas/s "
+          f"(sequence lengths {sorted(set(int(o.shape[1]) for o in out))})")
