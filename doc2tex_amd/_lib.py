@@ -44,6 +44,7 @@ SIGNATURES = {
     "d2t_decode_wait": (_I, [_P, _P, _I]),
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_decode_beam_batch": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
+    "d2t_decode_attn_beam_batch": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_decode_attn_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_set_conv_precision": (_I, [_P, _I]),
     "d2t_set_reserved_blocks": (_I, [_P, _I]),

@@ -125,12 +125,12 @@ class Model(nn.Module):
     def beam_search_batch(self, input, beam_size=None):
         """Extension (the reference's beam search takes one sample per call, tfm.py:146-148): encode the whole batch
         and advance the hypotheses of all samples in one step loop.  Returns [(LongTensor [1, len], score)] per
-        sample, each identical to `forward(input[i:i+1], ...)` with `beam_size` set.  TFM head only."""
-        if self.stages["Pred"] != "TFM":
-            raise NotImplementedError("batched beam search is implemented for the TFM head")
+        sample, each identical to `forward(input[i:i+1], ...)` with `beam_size` set."""
         beam = int(beam_size or self.opt.get("beam_size", 1))
         memory, _, _ = self.forward_encoder(input)
-        return self.engine().decode_beam_batch(memory.contiguous(), beam)
+        if self.stages["Pred"] == "TFM":
+            return self.engine().decode_beam_batch(memory.contiguous(), beam)
+        return self.engine().decode_attn_beam_batch(memory.contiguous(), beam)
 
     def synchronize(self, host_sync=True):
         """Order the current stream (and optionally the host) after every outstanding pipelined decode."""

@@ -1217,6 +1217,177 @@ int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t bea
   return done(D2T_OK);
 }
 
+int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
+                               int32_t* len_out, float* score_out, d2t_stream stream) {
+  // Attention / AttentionV2.forward_beam for N samples in one step loop: rows = live hypotheses of all samples, each
+  // attending over its own sample's keys (row map); log_softmax + top-k per sample segment; per-sample bookkeeping
+  // exactly as in d2t_decode_attn_beam (whose results this reproduces sample by sample).
+  if (!c || !memory || !seq_out || !len_out || !score_out || N < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  const d2t_config& g = c->cfg;
+  if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
+  if (!g.attn_coverage) return fail(c, D2T_ESTATE, "LSTM beam search is implemented for attn_type 'coverage' only");
+  if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
+  const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = N * beam_size;
+  const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
+  const int Tk = T - key_off;
+  if (Tk < 1 || Tk > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure(c, &c->dws, &c->dws_cap, ((size_t)N * T * Hh + 16) * 4))) return rc;
+  float* kp = c->dws;
+  const size_t nf = (size_t)cap * V + 2 * (size_t)cap + 4 * (size_t)cap * Hh + 2 * (size_t)cap * Tk;
+  const size_t tok_off = (nf + 1) & ~(size_t)1;
+  const size_t ws_bytes = tok_off * 4 + 2 * (size_t)cap * 8 + (5 * (size_t)cap + 3 * (size_t)N) * 4 + 64;
+  if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, ws_bytes))) return rc;
+  float* d_logits = c->beam_ws;
+  float* d_scores = d_logits + (size_t)cap * V;
+  float* d_topv = d_scores + cap;
+  float* st[6];
+  st[0] = d_topv + cap;
+  st[1] = st[0] + (size_t)cap * Hh;
+  st[2] = st[1] + (size_t)cap * Hh;
+  st[3] = st[2] + (size_t)cap * Hh;
+  st[4] = st[3] + (size_t)cap * Hh;
+  st[5] = st[4] + (size_t)cap * Tk;
+  int64_t* d_tok = reinterpret_cast<int64_t*>(d_logits + tok_off);
+  int64_t* d_dummy = d_tok + cap;
+  int* d_topi = reinterpret_cast<int*>(d_dummy + cap);
+  int* d_idxh = d_topi + cap;
+  int* d_idxm = d_idxh + cap;
+  int* d_end = d_idxm + cap;
+  int* d_map = d_end + cap;
+  int* d_seg = d_map + cap;
+  char* hp = nullptr;
+  const size_t hbytes = (size_t)cap * (8 + 4 * 6) + (size_t)N * 12 + 64;
+  if (hipHostMalloc(reinterpret_cast<void**>(&hp), hbytes, hipHostMallocDefault) != hipSuccess)
+    return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
+  int64_t* h_tok = reinterpret_cast<int64_t*>(hp);
+  float* h_scores = reinterpret_cast<float*>(hp + (size_t)cap * 8);
+  float* h_topv = h_scores + cap;
+  int* h_topi = reinterpret_cast<int*>(h_topv + cap);
+  int* h_idxh = h_topi + cap;
+  int* h_idxm = h_idxh + cap;
+  int* h_map = h_idxm + cap;
+  int* h_seg = h_map + cap;
+  auto done = [&](int code) { hipHostFree(hp); return code; };
+#define BCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return done(fail(c, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
+  BCHK(linear_any(nullptr, s, memory, c->attn.key, nullptr, kp, N * T, ACT_NONE));
+  AttnDecP p{};
+  p.mem = memory; p.T = T; p.D = Hh; p.key_off = key_off;
+  p.init_mode = !g.attn_enc_init ? 0 : (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN ? 1 : 2);
+  p.kp = kp; p.wq_t = c->attn.wq_t; p.bq = c->attn.bq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
+  p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
+  p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
+  p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
+  p.emb = c->attn.emb; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
+  p.S = 1; p.V = V; p.H = Hh; p.E = Hh; p.coverage = 1; p.end_token = 1;
+  p.step_mode = 1;
+  p.st_h_in = st[0]; p.st_c_in = st[1]; p.st_mem_in = st[4];
+  p.st_h_out = st[2]; p.st_c_out = st[3]; p.st_mem_out = st[5];
+  p.tok_in = d_tok; p.row_sample = d_map;
+
+  struct Smp {
+    std::vector<std::vector<int64_t>> seqs, complete;
+    std::vector<float> live, cscores;
+    int k;
+    bool last_completed = false, finished = false;
+  };
+  std::vector<Smp> sm((size_t)N);
+  for (auto& x : sm) {
+    x.seqs.assign((size_t)beam_size, std::vector<int64_t>{0});
+    x.live.assign((size_t)beam_size, 0.f);
+    x.k = beam_size;
+  }
+  for (int step = 0; step < S; ++step) {
+    int rows = 0;
+    for (int i = 0; i < N; ++i) {
+      Smp& x = sm[i];
+      const int M = x.finished ? 0 : (int)x.seqs.size();
+      // step 0: all rows of a sample are identical and the reference ranks its row 0 only
+      h_seg[3 * i] = rows; h_seg[3 * i + 1] = M ? (step == 0 ? 1 : M) : 0; h_seg[3 * i + 2] = x.finished ? 0 : x.k;
+      for (int j = 0; j < M; ++j) { h_scores[rows + j] = x.live[j]; h_map[rows + j] = i; }
+      rows += M;
+    }
+    if (!rows) break;
+    BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_map, h_map, (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_seg, h_seg, (size_t)N * 12, hipMemcpyHostToDevice, s));
+    p.B = rows; p.first = step == 0;
+    BCHK(launch_attn_decode(p, s));
+    BCHK(launch_beam_topk_batch(d_logits, d_scores, d_seg, N, V, beam_size, d_topv, d_topi, s));
+    BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    int nrows = 0;
+    for (int i = 0; i < N; ++i) {
+      Smp& x = sm[i];
+      if (x.finished) continue;
+      const int off = h_seg[3 * i];
+      std::vector<std::vector<int64_t>> nseqs;
+      std::vector<float> nscores;
+      std::vector<int> ih, im;
+      std::vector<int64_t> nt;
+      x.last_completed = false;
+      for (int r = 0; r < x.k; ++r) {
+        const int idx = h_topi[(size_t)i * beam_size + r], prev = idx / V, word = idx % V;
+        std::vector<int64_t> sq = x.seqs[prev];
+        sq.push_back(word);
+        if (word == 1) {
+          x.complete.push_back(std::move(sq));
+          x.cscores.push_back(h_topv[(size_t)i * beam_size + r]);
+          x.last_completed = true;
+        } else {
+          ih.push_back(off + prev);  // LSTM state: hidden[prev_word_inds[incomplete]]
+          im.push_back(off + r);     // coverage memory: (alpha_cum + alpha)[incomplete]
+          nt.push_back(word);
+          nseqs.push_back(std::move(sq));
+          nscores.push_back(h_topv[(size_t)i * beam_size + r]);
+        }
+      }
+      x.seqs.swap(nseqs);
+      x.live.swap(nscores);
+      x.k = (int)x.seqs.size();
+      if (x.k == 0) { x.finished = true; continue; }
+      for (size_t j = 0; j < ih.size(); ++j) { h_idxh[nrows] = ih[j]; h_idxm[nrows] = im[j]; h_tok[nrows] = nt[j]; ++nrows; }
+    }
+    if (nrows && step + 1 < S) {
+      BCHK(hipMemcpyAsync(d_idxh, h_idxh, (size_t)nrows * 4, hipMemcpyHostToDevice, s));
+      BCHK(hipMemcpyAsync(d_idxm, h_idxm, (size_t)nrows * 4, hipMemcpyHostToDevice, s));
+      BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)nrows * 8, hipMemcpyHostToDevice, s));
+      BCHK(launch_gather_rows(st[2], st[0], d_idxh, nrows, Hh, s));
+      BCHK(launch_gather_rows(st[3], st[1], d_idxh, nrows, Hh, s));
+      BCHK(launch_gather_rows(st[5], st[4], d_idxm, nrows, Tk, s));
+    }
+  }
+  BCHK(hipStreamSynchronize(s));
+#undef BCHK
+  for (int i = 0; i < N; ++i) {
+    Smp& x = sm[i];
+    std::vector<int64_t> out;
+    float score;
+    if (!x.last_completed) {  // seq2seq.py:209-216
+      out.assign(x.seqs[0].begin() + 1, x.seqs[0].end());
+      score = x.live[0];
+    } else {
+      size_t best = 0;
+      for (size_t j = 1; j < x.complete.size(); ++j)
+        if ((double)x.cscores[j] / (double)x.complete[j].size() > (double)x.cscores[best] / (double)x.complete[best].size()) best = j;
+      out.assign(x.complete[best].begin() + 1, x.complete[best].end());
+      score = *std::max_element(x.cscores.begin(), x.cscores.end());
+    }
+    const int n = (int)std::min<size_t>(out.size(), (size_t)S);
+    for (int j = 0; j < n; ++j) seq_out[(size_t)i * S + j] = out[j];
+    len_out[i] = n;
+    score_out[i] = score;
+  }
+  return done(D2T_OK);
+}
+
 int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
                             int64_t* tokens, float* logits, d2t_stream stream) {
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");

@@ -108,6 +108,7 @@ struct AttnDecP {
   const float *st_h_in, *st_c_in, *st_mem_in;  // [B][H], [B][H], [B][T - key_off]
   float *st_h_out, *st_c_out, *st_mem_out;
   const int64_t* tok_in;                        // [B] input token of this step
+  const int* row_sample;                        // step mode, optional [B]: the sample whose keys row b attends over (default 0)
   // Training forward (teacher forcing, seq2seq.py:311-316): the input token of step t is teacher[b*S + t]; the
   // recurrent state of every step is saved for the backward pass (all optional).
   const int64_t* teacher;

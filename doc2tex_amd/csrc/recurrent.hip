@@ -132,7 +132,8 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   __shared__ __attribute__((aligned(16))) float wloc_s[11 * H];  // folded location filter, [tap][n]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int Tk = p.T - p.key_off;
-  const int bm = p.step_mode ? 0 : b;  // beam search: every hypothesis attends over sample 0
+  // beam search: every hypothesis attends over its sample's keys (sample 0 unless a row map is given)
+  const int bm = p.step_mode ? (p.row_sample ? p.row_sample[b] : 0) : b;
   const float* keys = p.mem + ((size_t)bm * p.T + p.key_off) * p.D;
   const float* kp = p.kp + ((size_t)bm * p.T + p.key_off) * H;
   float* ctx_s = x_s;

@@ -308,6 +308,18 @@ class Engine:
                                                   C.byref(n), C.byref(score), _lib.stream_of(memory)), "decode_attn_beam")
         return torch.LongTensor(list(seq[: n.value])).unsqueeze(0), torch.tensor(float(score.value))
 
+    def decode_attn_beam_batch(self, memory, beam_size):
+        """LSTM-attention beam search for every sample of memory [N,T,256] in one step loop."""
+        memory = memory.float().contiguous()
+        N, S = memory.shape[0], self.cfg.batch_max_length + 1
+        seq = (C.c_int64 * (N * S))()
+        n = (C.c_int32 * N)()
+        score = (C.c_float * N)()
+        self._check(self.lib.d2t_decode_attn_beam_batch(self.ctx, _lib.ptr(memory), N, memory.shape[1], int(beam_size), seq,
+                                                        n, score, _lib.stream_of(memory)), "decode_attn_beam_batch")
+        return [(torch.LongTensor(list(seq[i * S: i * S + n[i]])).unsqueeze(0), torch.tensor(float(score[i])))
+                for i in range(N)]
+
     def decode_beam_batch(self, memory, beam_size):
         """Beam search for every sample of memory [N,T,d] in one shared step loop: [(LongTensor [1,len], score)] * N,
         each equal to decode_beam on that sample alone."""

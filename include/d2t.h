@@ -164,6 +164,11 @@ int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
+/* d2t_decode_attn_beam for N samples in one step loop (extension, like d2t_decode_beam_batch).  memory [N][T][256];
+ * seq_out (host) [N][batch_max_length + 1]; len_out, score_out (host) [N]. */
+int d2t_decode_attn_beam_batch(d2t_ctx* ctx, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
+                               int32_t* len_out, float* score_out, d2t_stream stream);
+
 /* Beam search for N samples at once (not in the reference, whose forward_beam is single-sample): the same results as
  * N calls of d2t_decode_beam, with the hypotheses of all samples advanced by one shared step loop.  memory [N][T][d];
  * seq_out (host) [N][max_seq_len + 1]; len_out, score_out (host) [N]. */

@@ -216,6 +216,20 @@ def test_batched_beam_equals_per_sample_beam(cases):
             assert v1 == v2
 
 
+def test_batched_attn_beam_equals_per_sample_beam(cases):
+    """The same for the LSTM-attention head (Attnv2 on the ViT encoder, Attn on VGG + BiLSTM)."""
+    for cname, H, W, L, eb, beam in [("TS0", 48, 64, 14, 0.3, 5), ("TS0", 48, 64, 8, 0.0, 3), ("C0", 32, 320, 12, 0.17, 4)]:
+        cfg, m = engine_model(cname, L, 1234, eb, beam_size=beam)
+        img = synth.synth_images(6, H, W, seed=1200).cuda()
+        text = torch.zeros(1, L + 1, dtype=torch.long, device="cuda")
+        with torch.no_grad():
+            single = [m(img[i:i + 1], text, is_train=False, is_test=True)[:2] for i in range(6)]
+            batch = m.beam_search_batch(img)
+        for (s1, v1), (s2, v2) in zip(single, batch):
+            assert torch.equal(s1, s2), (cname, eb, beam)
+            assert float(v1) == float(v2)
+
+
 def test_beam_rejects_batches():
     cfg, m = engine_model("T2", 8, beam_size=3)
     img = synth.synth_images(2, 48, 64).cuda()
