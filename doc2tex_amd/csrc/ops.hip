@@ -332,7 +332,107 @@ __global__ __launch_bounds__(512) void vit_attention_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// ViT attention on the fp32 matrix cores.  One block per (image, head); wave w owns the 32 queries [32w, 32w+32) and
+// walks the 32-key tiles flash-style: S = (scale Q) K^T by 16 v_mfma_f32_32x32x2_f32, running row maximum (the
+// accumulator holds a row in one register across 32 lanes, so the row maximum is a 5-step lane reduction), rescale,
+// P = exp(S - max) staged through a per-wave LDS tile to turn accumulator layout into the A-operand layout, O += P V by
+// 16 more MFMAs.  K rows are padded to 33 floats (conflict-free B-operand reads), V rows are read lane-contiguous.
+// head_dim = 32, N <= 512.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ y,
+                                                                  int N, int heads, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Np = tiles * 32;
+  float* Ks = sm;                          // [Np][33]
+  float* Vs = Ks + (size_t)Np * 33;        // [Np][32]
+  float* Pw = Vs + (size_t)Np * 32;        // [waves][32][33]
+  const int b = blockIdx.x / heads, hh = blockIdx.x % heads, C = heads * 32;
+  const float* base = qkv + (size_t)b * N * 3 * C;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthreads = blockDim.x;
+  for (int i = tid; i < Np * 8; i += nthreads) {  // 8 float4 per key row; rows >= N are zero
+    const int j = i >> 3, c = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (j < N) {
+      kv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + C + hh * 32 + c);
+      vv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + 2 * C + hh * 32 + c);
+    }
+    float* kd = Ks + j * 33 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + j * 32 + c) = vv;
+  }
+  __syncthreads();
+  const int r = lane & 31, h = lane >> 5, q0 = wave * 32;
+  // A operand of S: lane (r, h) supplies Q[q0 + r][h + 2 kk]
+  float qa[16];
+  {
+    const int row = q0 + r < N ? q0 + r : N - 1;  // clamp: rows beyond N are computed and discarded
+    const float* qp = base + (size_t)row * 3 * C + hh * 32;
+    const float scale = 0.17677669529663687f;     // 32^-0.5
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) qa[kk] = qp[2 * kk + h] * scale;
+  }
+  f32x16 o;
+  float mrun[16], lrun[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[e] = 0.f; mrun[e] = -INFINITY; lrun[e] = 0.f; }
+  float* P = Pw + (size_t)wave * 32 * 33;
+  for (int t = 0; t < tiles; ++t) {
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    const float* kb = Ks + (size_t)(t * 32 + r) * 33 + h;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], kb[2 * kk], sacc, 0, 0, 0);
+    // this lane's column is key t*32 + r; accumulator register e holds query row (e&3) + 8 (e>>2) + 4 h
+    const bool valid = t * 32 + r < N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = valid ? sacc[e] : -INFINITY;
+      float mx = v;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));  // within the 32-lane half
+      const float mnew = fmaxf(mrun[e], mx);
+      const float corr = expf(mrun[e] - mnew);  // 0 on the first tile (mrun = -inf)
+      const float pe = expf(v - mnew);
+      lrun[e] = lrun[e] * corr + pe;
+      o[e] *= corr;
+      mrun[e] = mnew;
+      P[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = pe;  // P[m][n]
+    }
+    // O += P V_t : A[i][k] = P[i][k], B[k][j] = V[t*32 + k][j]
+    const float* vb = Vs + (size_t)(t * 32 + h) * 32 + r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(P[r * 33 + 2 * kk + h], vb[(size_t)2 * kk * 32], o, 0, 0, 0);
+  }
+  // row sums: every lane holds a partial over its key columns
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float l = lrun[e];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+    const int row = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (row < N) y[((size_t)b * N + row) * C + hh * 32 + r] = o[e] / l;
+  }
+}
+
 hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s) {
+  static const bool valu = getenv("D2T_VIT_ATTN_VALU") != nullptr;
+  if (!valu && N <= 512) {
+    const int tiles = (N + 31) / 32;
+    const size_t lds2 = ((size_t)tiles * 32 * 33 + (size_t)tiles * 32 * 32 + (size_t)tiles * 32 * 33) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_mfma_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr2 = true;
+    }
+    if (lds2 <= 160 * 1024) {
+      hipLaunchKernelGGL(vit_attention_mfma_kernel, dim3(B * heads), dim3(tiles * 64), lds2, s, qkv, y, N, heads, tiles);
+      return hipGetLastError();
+    }
+  }
   if (N > 64 * VA_MAXKPL) return hipErrorInvalidValue;
   const size_t lds = ((((size_t)N * 33 + 3) & ~(size_t)3) + (size_t)N * 32 + 8 * (size_t)N) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
