@@ -323,3 +323,24 @@ def test_odd_crop_shapes_and_batch_sizes(manifests, cname, H, W, B, precision):
     assert float((mem.cpu() - omem).abs().max()) / scale <= (5e-4 if precision == "bf16x3" else 1e-4)
     assert torch.equal(preds.cpu(), opreds)
     assert float((logits.cpu() - ologits).abs().max()) <= LOGIT_TOL
+
+
+def test_error_paths_raise_instead_of_crashing():
+    """Misuse is reported through status codes / Python exceptions (the library never aborts): a crop larger than the
+    positional table, a CPU tensor, a wrong channel count, a missing weight, a second backward without a forward."""
+    cfg, m = engine_model("T2", 8)
+    text = torch.full((1, 1), R.GO, dtype=torch.long, device="cuda")
+    with pytest.raises(RuntimeError):  # 96x128 > max_dimension 48x64: pos_embed too short (the reference fails here too)
+        m(synth.synth_images(1, 96, 128).cuda(), text, is_train=False)
+    with pytest.raises(RuntimeError):
+        m(synth.synth_images(1, 48, 64), text.cpu(), is_train=False)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 48, 64, device="cuda"), text, is_train=False)
+    # the engine keeps working after the failures
+    preds, logits, _ = m(synth.synth_images(1, 48, 64).cuda(), text, is_train=False)
+    assert preds.shape == (1, 9)
+    eng = m.engine()
+    with pytest.raises(RuntimeError):
+        eng.train_backward(torch.zeros(1, 9, synth.VOCAB, device="cuda"))  # no preceding training forward
+    with pytest.raises(RuntimeError):
+        eng.read_weight("no.such.tensor", torch.zeros(4, device="cuda"))
