@@ -58,11 +58,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                          const float* __restrict__ bias, uint16_t* __restrict__ out,
                                                          int B, int H, int W, int Cout, int act) {
-  const int cq = Cout >> 2;
+  const int cq = Cout >> 2;  // == 8: the stride of the loop below is a multiple of 8, so a thread keeps its 4 channels
   const long long total = (long long)B * H * W * cq;
+  const int c4 = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % cq);
+  float wr[4][9], br[4];  // this thread's filter taps, loaded once (36 loads per pixel otherwise)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    br[c] = bias ? bias[c4 * 4 + c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[c][t] = w[(c4 * 4 + c) * 9 + t];
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % cq);
     const long long pix = idx / cq;
     const int x = (int)(pix % W);
     const int y = (int)((pix / W) % H);
@@ -79,11 +86,10 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
     uint16_t hi[4], lo[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int oc = c4 * 4 + c;
       float a = 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) a = fmaf(v[t], w[oc * 9 + t], a);
-      a += bias ? bias[oc] : 0.f;
+      for (int t = 0; t < 9; ++t) a = fmaf(v[t], wr[c][t], a);
+      a += br[c];
       split_f32(act == ACT_RELU ? fmaxf(a, 0.f) : a, hi[c], lo[c]);
     }
     const size_t o = plane_idx((size_t)pix, c4 * 4, Cout);
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
 
 hipError_t launch_stem_split(const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
                              int Cout, int act, hipStream_t s) {
-  if (Cout % 32) return hipErrorInvalidValue;
+  if (Cout != 32) return hipErrorInvalidValue;  // 8 channel quads per pixel: see the kernel's hoisted weights
   const long long total = (long long)B * H * W * (Cout / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(stem_split_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, out, B, H, W, Cout, act);
