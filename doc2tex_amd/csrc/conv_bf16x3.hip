@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16x3g_128x128_w8_k4608(const Co
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
   conv_bf16x3g_body<128, 128, 4>(p, smem);
 }
-__global__ __launch_bounds__(256, 2) void conv_bf16x3g_128x64(const ConvP p) {
+__global__ __launch_bounds__(256, 3) void conv_bf16x3g_128x64(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 64 * XROW)];
   conv_bf16x3g_body<128, 64, 2>(p, smem);
 }
@@ -438,7 +438,11 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
     int tiles = mt * ((p.Cout + (p.Cout <= 64 ? 63 : 127)) / (p.Cout <= 64 ? 64 : 128));
     const int grid = (p.max_blocks > 0 && tiles > p.max_blocks) ? p.max_blocks : tiles;
     if (p.Cout <= 64) {
-      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid), dim3(256), 0, s, p);
+      // 48 KB of LDS and 4 waves per block: three blocks fit on a CU, and this short-K layer (conv0_2: 9 K-steps per
+      // tile) lives on overlapping the prologue / epilogue of one tile with the MFMAs of another
+      const int cap3 = p.max_blocks + p.max_blocks / 2;
+      const int grid3 = (p.max_blocks > 0 && tiles > cap3) ? cap3 : tiles;
+      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid3), dim3(256), 0, s, p);
     } else {
       // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
       static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
