@@ -252,6 +252,7 @@ struct WgradP {
   int taps, geom;   // geom != 0: rows are output pixels of a convolution with the geometry below
   int H, W, OH, OW, KW, SH, SW, PH, PW;
   int S, chunk;     // split over row chunks of `chunk` rows
+  int bf16x3;       // 128 x 128 tiles only: split-bf16 arithmetic (three bf16 MFMAs per product)
 };
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,

@@ -208,6 +208,7 @@ struct Tr {  // builder / runner bound to one context and stream
     WgradP p{};
     p.a = a; p.b = b; p.part = st->part; p.P = P; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.taps = taps;
     p.KW = 1; p.S = (int)S; p.chunk = (int)chunk;
+    p.bf16x3 = c->conv_bf16x3 ? 1 : 0;
     if (geom) {
       p.geom = 1; p.H = xin->H; p.W = xin->W; p.OH = yout->H; p.OW = yout->W;
       p.KW = geom->KW; p.SH = geom->SH; p.SW = geom->SW; p.PH = geom->PH; p.PW = geom->PW;

@@ -152,6 +152,141 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 weight gradient (conv_precision = bf16x3): the same TN GEMM on v_mfma_f32_32x32x16_bf16 with
+// dz = hi + lo, x = hi + lo and three MFMAs per product.  Both operand tiles stay pixel-major in LDS (rows = pixels,
+// exactly as they are loaded and split); the MFMA wants, per lane, eight consecutive K (= pixel) values of ONE column,
+// which is what gfx950's transposing LDS read delivers: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of
+// a 4-row x 16-column block.  Two of them per fragment.  LDS rows are 320 B (256 B of data + 64 B pad): a 32-lane
+// half reads 4 rows x 64 B, and a row stride of 64 (mod 256) bytes makes those 256 bytes hit all 64 banks once.
+// Block tile 128 x 128, 4 waves (wave tile 64 x 64), K-step = 16 pixels, double-buffered, 40 KB of LDS.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s4_t* lds_s4_ptr;
+
+__device__ __forceinline__ void split4_bf16(const float4 v, uint2& hi, uint2& lo) {
+  const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
+  hi.x = (x0 >> 16) | (x1 & 0xFFFF0000u);
+  hi.y = (x2 >> 16) | (x3 & 0xFFFF0000u);
+  const __bf16 l0 = (__bf16)(v.x - __uint_as_float(x0 & 0xFFFF0000u)), l1 = (__bf16)(v.y - __uint_as_float(x1 & 0xFFFF0000u));
+  const __bf16 l2 = (__bf16)(v.z - __uint_as_float(x2 & 0xFFFF0000u)), l3 = (__bf16)(v.w - __uint_as_float(x3 & 0xFFFF0000u));
+  lo.x = (unsigned)*reinterpret_cast<const unsigned short*>(&l0) | ((unsigned)*reinterpret_cast<const unsigned short*>(&l1) << 16);
+  lo.y = (unsigned)*reinterpret_cast<const unsigned short*>(&l2) | ((unsigned)*reinterpret_cast<const unsigned short*>(&l3) << 16);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradP p) {
+  constexpr int BM = 128, BN = 128, BK = 16, LDR = 160;  // LDR: uint16 per LDS row (320 B)
+  constexpr int PLANE = BK * LDR;                         // uint16 per plane per stage
+  __shared__ __attribute__((aligned(16))) unsigned short sm[2][4][PLANE];  // [stage][A_hi, A_lo, B_hi, B_lo]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int tap = blockIdx.y, kh = tap / p.KW, kw = tap % p.KW;
+  const long long r_begin = (long long)blockIdx.z * p.chunk;
+  const long long r_end = r_begin + p.chunk < p.P ? r_begin + p.chunk : p.P;
+  const int ohow = p.OH * p.OW;
+  // staging: 16 rows x 32 float4 per operand = 512 float4 -> two per thread
+  float4 ra[2], rb[2];
+  auto fetch = [&](long long r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256, row = idx >> 5, c4 = (idx & 31) * 4;
+      const long long r = r0 + row;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (r < r_end) {
+        if (m0 + c4 < p.M) va = *reinterpret_cast<const float4*>(p.a + r * p.lda + m0 + c4);
+        if (n0 + c4 < p.N) {
+          long long src = r;
+          bool ok = true;
+          if (p.geom) {
+            const int b = (int)(r / ohow), rem = (int)(r - (long long)b * ohow);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih = oh * p.SH - p.PH + kh, iw = ow * p.SW - p.PW + kw;
+            ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            src = ((long long)b * p.H + ih) * p.W + iw;
+          }
+          if (ok) vb = *reinterpret_cast<const float4*>(p.b + src * p.ldb + n0 + c4);
+        }
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256, row = idx >> 5, c4 = (idx & 31) * 4;
+      uint2 hi, lo;
+      split4_bf16(ra[i], hi, lo);
+      *reinterpret_cast<uint2*>(&sm[buf][0][row * LDR + c4]) = hi;
+      *reinterpret_cast<uint2*>(&sm[buf][1][row * LDR + c4]) = lo;
+      split4_bf16(rb[i], hi, lo);
+      *reinterpret_cast<uint2*>(&sm[buf][2][row * LDR + c4]) = hi;
+      *reinterpret_cast<uint2*>(&sm[buf][3][row * LDR + c4]) = lo;
+    }
+  };
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  // transposing read: group g = lane / 16 covers columns 16 (g & 1) .. +15 of a 32-column fragment and K rows 8 (g >> 1) .. +7
+  const int g = lane >> 4, l16 = lane & 15;
+  const int tr_off = ((8 * (g >> 1) + (l16 >> 2)) * LDR + 16 * (g & 1) + 4 * (l16 & 3));  // uint16 units, rows +0..3
+  auto frag = [&](const unsigned short* plane, int col0) -> bf16x8_t {
+    const unsigned short* q = plane + tr_off + col0;
+    const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(q));
+    const s4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(q + 4 * LDR));
+    s8_t v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int steps = (int)((r_end - r_begin + BK - 1) / BK);
+  if (steps > 0) { fetch(r_begin); stash(0); }
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < steps) fetch(r_begin + (long long)(st + 1) * BK);
+    bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = frag(sm[cur][0], wm * 64 + i * 32);
+      al[i] = frag(sm[cur][1], wm * 64 + i * 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = frag(sm[cur][2], wn * 64 + j * 32);
+      bl[j] = frag(sm[cur][3], wn * 64 + j * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (st + 1 < steps) stash(cur ^ 1);
+    __syncthreads();
+  }
+  float* out = p.part + ((size_t)blockIdx.z * p.taps + tap) * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (m < p.M) out[(size_t)m * p.N + n] = acc[i][j][reg];
+      }
+    }
+}
+
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.P <= 0) return hipSuccess;
   if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
@@ -160,7 +295,8 @@ hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
     hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, p);
   } else {
     dim3 grid(((p.M + 127) / 128) * ((p.N + 127) / 128), p.taps, p.S);
-    hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    if (p.bf16x3) hipLaunchKernelGGL(wgrad_bf16x3_kernel, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }
