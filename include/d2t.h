@@ -20,6 +20,15 @@
  *        <- Attention.forward_greedy seq2seq.py:224-331, AttentionV2.forward_greedy seq2seq_v2.py:176-293
  *   d2t_decode_beam
  *        <- TransformerPrediction.forward_beam tfm.py:145-186 + Beam tools/beam.py:38-140
+ *   d2t_decode_attn_beam
+ *        <- Attention.forward_beam seq2seq.py:83-222, AttentionV2.forward_beam seq2seq_v2.py:12-174
+ *   d2t_train_forward / d2t_train_backward / d2t_train_grad (+ dropout, scheduled-sampling setters)
+ *        <- Model.forward under module.train() and loss.backward(): forward_step / train_one_step
+ *           engine/training.py:76-164 (tfm.py:103-118, seq2seq.py:224-331 with is_train)
+ *   d2t_decode_greedy_async / d2t_decode_wait, d2t_set_reserved_blocks / d2t_set_decode_chains,
+ *   d2t_decode_beam_batch / d2t_decode_attn_beam_batch
+ *        -- serving extensions without a reference counterpart (cross-batch pipelining, batched beam search);
+ *           their results equal the corresponding reference-shaped calls bit for bit
  *   d2t_op_*  -- single-kernel entry points used by the parity tests.
  *
  * Conventions
@@ -27,7 +36,8 @@
  *   - every pointer named *dev* / marked [device] is a raw HIP device pointer
  *     owned by the CALLER (e.g. a torch tensor's data_ptr()); the engine writes
  *     outputs in place and keeps its own packed copies of the weights;
- *   - all arithmetic fp32, token ids int64;
+ *   - all tensors fp32, token ids int64; arithmetic fp32 on the matrix cores, or (d2t_set_conv_precision) large
+ *     convolutions / GEMMs as three bf16 MFMAs per product with fp32 accumulation (tokens bit-exact, logits within 1e-3);
  *   - every launch goes to the caller's hipStream_t (`stream`, may be NULL for
  *     the default stream); calls are asynchronous unless they return host
  *     scalars (d2t_decode_greedy's steps_out, d2t_decode_beam);
