@@ -102,6 +102,68 @@ def cpu_baseline(cfg_name, H, W, max_len, sample_b):
     }
 
 
+def train_bench(args, rank, world, dev, dist):
+    """BASELINE configs[3]: HybridViT + TFM-6 training step, CE loss on synthetic labels, per-GPU batch 32, data-parallel
+    with the gradient all-reduce of doc2tex_amd.dist.GradSync.  One step = forward + loss + backward + clip + AdamW."""
+    from doc2tex_amd.dist import GradSync
+    name = "C3"
+    H, W = synth.crop_shape(name)
+    B = args.batch or synth.batch_size(name)
+    cfg = synth.make_config(name, device=str(dev))
+    L = cfg["Prediction"]["params"]["max_seq_len"]
+    model = Model(cfg)
+    tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
+    model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
+    model.to(dev).train()
+    model.conv_precision = args.precision
+    if world > 1:
+        model.grad_sync = GradSync()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    img = synth.synth_images(B, H, W, seed=3000 + rank).to(dev)
+    text = synth.synth_labels(B, max_len=L, seed=3000 + rank).to(dev)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0, reduction="none")
+
+    def step():
+        _, preds, _ = model(img, text[:, :-1])
+        loss = crit(preds.view(-1, preds.shape[-1]), text[:, 1:].contiguous().view(-1)).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        model.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "formulas/s (training step, 128x512 crops, CE loss)", "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "formulas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "config": {"workload": f"C3: HybridViT + TFM-6 training step, {H}x{W} crops, {L + 1}-token labels, "
+                                   "forward + CE + backward + clip + AdamW",
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world} (per-rank batches, gradient all-reduce-mean in 64 MB buckets over RCCL)"},
+            "loss": round(float(loss), 4)}), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +178,10 @@ def main():
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
                     help="pipelined mode: decode loops in flight side by side")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary mode (BASELINE configs[3]): time the training step of config C3 -- forward under "
+                         "module.train(), CE, backward in the HIP engine, bucketed RCCL gradient all-reduce when more than "
+                         "one rank runs, clip, AdamW -- and print its own JSON line instead of the headline metric")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish each batch's decode before the next batch's encoder starts")
     ap.add_argument("--cpu-sample", type=int, default=24, help="crops in the CPU-baseline sample (~10-30 s of CPU work)")
@@ -136,6 +202,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.train:
+        return train_bench(args, rank, world, dev, dist)
     name = args.config
     H, W = synth.crop_shape(name)
     B = args.batch or synth.batch_size(name)

@@ -26,8 +26,24 @@ class D2TConfig(C.Structure):
         "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb")]
 
 
+class D2TPrepConfig(C.Structure):  # include/d2t_prep.h d2t_prep_config
+    _fields_ = [(n, C.c_int32) for n in ("max_h", "max_w", "min_h", "min_w", "downsample", "variant")] + \
+               [("mean", C.c_float), ("std", C.c_float)]
+
+
+class D2TPrepPlan(C.Structure):  # include/d2t_prep.h d2t_prep_plan
+    _fields_ = [(n, C.c_int32) for n in ("src_h", "src_w", "ds_h", "ds_w", "rs_h", "rs_w", "out_h", "out_w",
+                                         "min_branch", "status")]
+
+
+PREP_DEMO, PREP_API = 0, 1
+PREP_OK, PREP_UNBOUND_LOCAL, PREP_FALLBACK = 0, 1, 2
+PREP_FLAG_PASTE_MISMATCH = 1
+POST_NONE, POST_API, POST_DEMO = 0, 1, 2
+
 _P = C.c_void_p
 _I = C.c_int32
+_L = C.c_int64
 # name -> (restype, argtypes); must list every symbol include/d2t.h declares
 SIGNATURES = {
     "d2t_create": (_I, [C.POINTER(D2TConfig), C.POINTER(_P)]),
@@ -69,6 +85,20 @@ SIGNATURES = {
     "d2t_op_vit_attention": (_I, [_P, _P, _I, _I, _I, _P]),
     "d2t_op_decode_attention": (_I, [_P] * 4 + [_I] * 5 + [_P]),
 }
+# include/d2t_prep.h
+SIGNATURES_PREP = {
+    "d2t_prep_plan_image": (_I, [C.POINTER(D2TPrepConfig), _I, _I, C.POINTER(D2TPrepPlan)]),
+    "d2t_prep_plan_fallback": (_I, [C.POINTER(D2TPrepConfig), _I, _I, C.POINTER(D2TPrepPlan)]),
+    "d2t_prep_create": (_I, [C.POINTER(D2TPrepConfig), C.POINTER(_P)]),
+    "d2t_prep_destroy": (None, [_P]),
+    "d2t_prep_last_error": (C.c_char_p, [_P]),
+    "d2t_prep_run": (_I, [_P, _I, C.POINTER(D2TPrepPlan), _P, C.POINTER(_L), _P, _I, _I, _P, _P]),
+    "d2t_prep_lanczos_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "d2t_vocab_create": (_I, [C.POINTER(C.c_char_p), _I, C.POINTER(_P)]),
+    "d2t_vocab_destroy": (None, [_P]),
+    "d2t_post_decode": (_I, [_P, C.POINTER(_L), _I, _I, C.c_char_p, _I, _I, C.c_char_p, _L, C.POINTER(_L), C.POINTER(_L)]),
+    "d2t_post_strip_whitespace": (_I, [C.c_char_p, _I, C.c_char_p, _L]),
+}
 
 _lib = None
 
@@ -83,7 +113,7 @@ def load():
             f"doc2tex_amd: {LIB_PATH} is not built (run doc2tex_amd/csrc/build.sh or "
             "__graft_entry__.build()); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_PREP.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,578 @@
+// Pre-processing of formula images on the MI355X (include/d2t_prep.h).
+//
+// Replaces the pixel work of resize() (doc2tex/utils/predict_utils.py:14-115, demo/HybridViT/helper.py:134-207): optional
+// cv2 INTER_AREA downsample, Pillow LANCZOS resize to max_dimension, paste on a 255 canvas for min_dimension, normalise,
+// and the collate into one [n,1,H,W] float32 batch.  Byte / integer work, HBM-bound: every source byte is read once into
+// LDS (horizontal pass) or by coalesced column-parallel loads (vertical pass); the output is written once, coalesced.
+//
+// Host side: the size arithmetic (double precision, the same IEEE operations the Python reference performs) and Pillow's
+// coefficient tables (double-precision windowed sinc through libm's sin, as Pillow computes them; cached per
+// (in_size, out_size)).  Device side: integer multiply-accumulate in 32 bits, 22-bit fixed point, uint8 intermediate.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/d2t.h"
+#include "../../include/d2t_prep.h"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;  // Pillow Resample.c
+
+// One resampling table for one axis: bounds[2*i] = first source index, bounds[2*i+1] = taps, coef[i*ksize + k] = tap k
+// (int32 fixed point for LANCZOS, float bits for INTER_AREA).
+struct AxisTab {
+  int ksize = 0;
+  std::vector<int32_t> bounds, coef;
+};
+
+double sinc_filter(double x) {
+  if (x == 0.0) return 1.0;
+  x = x * M_PI;
+  return sin(x) / x;
+}
+double lanczos_filter(double x) { return (-3.0 <= x && x < 3.0) ? sinc_filter(x) * sinc_filter(x / 3) : 0.0; }
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for the box (0, in_size).
+void build_lanczos(int in_size, int out_size, AxisTab& t) {
+  const float in0 = 0.f, in1 = (float)in_size;
+  double scale = (double)(in1 - in0) / out_size, filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 3.0 * filterscale;
+  t.ksize = (int)ceil(support) * 2 + 1;
+  t.bounds.assign((size_t)out_size * 2, 0);
+  t.coef.assign((size_t)out_size * t.ksize, 0);
+  std::vector<double> k(t.ksize);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = in0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x) {
+      if (ww != 0.0) k[x] /= ww;
+      t.coef[(size_t)xx * t.ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PRECISION_BITS))
+                                                  : (int)(0.5 + k[x] * (1 << PRECISION_BITS));
+    }
+    t.bounds[2 * xx] = xmin;
+    t.bounds[2 * xx + 1] = xmax;
+  }
+}
+
+// OpenCV computeResizeAreaTab (imgproc/resize.cpp) regrouped per destination index.
+void build_area(int ssize, int dsize, AxisTab& t) {
+  const double scale = (double)ssize / dsize;
+  t.ksize = (int)ceil(scale) + 2;
+  t.bounds.assign((size_t)dsize * 2, 0);
+  t.coef.assign((size_t)dsize * t.ksize, 0);
+  auto put = [&](int d, int& n, int& first, int si, float a) {
+    if (n == 0) first = si;
+    int32_t bits;
+    memcpy(&bits, &a, 4);
+    t.coef[(size_t)d * t.ksize + n++] = bits;
+  };
+  for (int dx = 0; dx < dsize; ++dx) {
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale, cell = std::min(scale, ssize - fsx1);
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    int n = 0, first = sx1;
+    if (sx1 - fsx1 > 1e-3) put(dx, n, first, sx1 - 1, (float)((sx1 - fsx1) / cell));
+    for (int sx = sx1; sx < sx2; ++sx) put(dx, n, first, sx, float(1.0 / cell));
+    if (fsx2 - sx2 > 1e-3) put(dx, n, first, sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell));
+    t.bounds[2 * dx] = first;
+    t.bounds[2 * dx + 1] = n;
+  }
+}
+
+// ---- size arithmetic (doubles, as Python computes them) ----------------------------------------------------------
+// get_divisible_size: returns false where the reference leaves a result unassigned (variant API).
+bool divisible_size(double ori_h, double ori_w, int max_h, int max_w, int variant, int64_t* nh, int64_t* nw) {
+  const double sf = 32.0;
+  bool has_h = variant == D2T_PREP_DEMO, has_w = has_h;
+  double new_h = ori_h, new_w = ori_w;
+  if (fmod(ori_h, sf) != 0.0) {
+    new_h = ceil(ori_h / sf) * sf;
+    if (new_h > max_h) new_h = floor(ori_h / sf) * sf;
+    has_h = true;
+  }
+  if (fmod(ori_w, sf) != 0.0) {
+    new_w = ceil(ori_w / sf) * sf;
+    if (new_w > max_w) new_w = floor(ori_w / sf) * sf;
+    has_w = true;
+  }
+  if (!has_h || !has_w) return false;
+  *nh = (int64_t)new_h;
+  *nw = (int64_t)new_w;
+  return true;
+}
+
+void plan_fallback(const d2t_prep_config* c, d2t_prep_plan* p) {
+  p->rs_h = p->ds_h;  // predict_utils.py:87 normalises `img` as it is at that point (after the downsample)
+  p->rs_w = p->ds_w;
+  p->out_h = c->max_h;
+  p->out_w = c->max_w;
+  p->min_branch = 0;
+  p->status = D2T_PREP_FALLBACK;
+}
+
+int plan_image(const d2t_prep_config* c, int src_h, int src_w, d2t_prep_plan* p) {
+  if (!c || !p || src_h <= 0 || src_w <= 0 || c->max_h <= 0 || c->max_w <= 0 || c->downsample < 0) return D2T_EINVAL;
+  memset(p, 0, sizeof(*p));
+  p->src_h = p->ds_h = src_h;
+  p->src_w = p->ds_w = src_w;
+  if (c->variant == D2T_PREP_API && c->downsample > 0) {  // predict_utils.py:31-44
+    const double r = c->downsample;
+    if (src_h / r >= c->min_h && src_w / r >= c->min_w) {
+      p->ds_h = (int)(src_h / r);
+      p->ds_w = (int)(src_w / r);
+    }
+  }
+  int64_t h = p->ds_h, w = p->ds_w;
+  {  // data_utils.py:64-68
+    const double rh = (double)h / c->max_h, rw = (double)w / c->max_w;
+    if (rh > 1 || rw > 1) {
+      const double m = std::max(rh, rw);
+      int64_t nh, nw;
+      if (!divisible_size((double)h / m, (double)w / m, c->max_h, c->max_w, c->variant, &nh, &nw)) {
+        p->status = D2T_PREP_UNBOUND_LOCAL;
+        return D2T_OK;
+      }
+      if (nh <= 0 || nw <= 0) {  // Image.resize raises ValueError("height and width must be > 0")
+        plan_fallback(c, p);
+        return D2T_OK;
+      }
+      h = nh;
+      w = nw;
+    }
+  }
+  p->rs_h = p->out_h = (int)h;
+  p->rs_w = p->out_w = (int)w;
+  if (c->min_h > 0 && c->min_w > 0) {  // data_utils.py:70-81
+    const double rh = (double)h / c->min_h, rw = (double)w / c->min_w;
+    if (rh < 1 || rw < 1) {
+      const double m = std::min(rh, rw);
+      int64_t nh, nw;
+      if (!divisible_size((double)h / m, (double)w / m, c->max_h, c->max_w, c->variant, &nh, &nw)) {
+        p->status = D2T_PREP_UNBOUND_LOCAL;
+        return D2T_OK;
+      }
+      if (nh < h || nw < w || nh <= 0 || nw <= 0) {  // canvas smaller than the image: paste raises ValueError
+        plan_fallback(c, p);
+        return D2T_OK;
+      }
+      p->out_h = (int)nh;
+      p->out_w = (int)nw;
+      p->min_branch = 1;
+    }
+  }
+  return D2T_OK;
+}
+
+// ---- device side -------------------------------------------------------------------------------------------------
+struct PrepDesc {
+  int64_t src_off, ds_off, hp_off;  // byte offsets: source pixels; work buffer (downsampled image, horizontal-pass image)
+  int32_t src_h, src_w, ds_h, ds_w, rs_h, rs_w;
+  int32_t do_ds, do_h, do_v;  // do_ds: 1 = 2x2 mean, 2 = integer factor, 3 = fractional area tables
+  int32_t ds_fx, ds_fy;       // integer factors (do_ds == 2)
+  int32_t axb, axk, axs, ayb, ayk, ays;  // area tables: bounds / coefficient word offsets, ksize
+  int32_t hb, hk, hks, vb, vk, vks;      // LANCZOS tables; the horizontal coefficients are stored transposed [k][out]
+  int32_t min_branch, fallback;
+  float fill;
+};
+
+__device__ __forceinline__ uint8_t clip8(int ss) {
+  int v = ss >> PRECISION_BITS;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// cv2.resize(..., INTER_AREA): one thread per destination pixel (the footprint is a few source pixels).
+__global__ __launch_bounds__(256) void prep_area_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                        uint8_t* __restrict__ work, const int32_t* __restrict__ tabs) {
+  const PrepDesc d = descs[blockIdx.z];
+  if (!d.do_ds) return;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= d.ds_w || y >= d.ds_h) return;
+  const uint8_t* S = src + d.src_off;
+  uint8_t* D = work + d.ds_off;
+  const int sw = d.src_w;
+  if (d.do_ds == 1) {
+    const uint8_t* r0 = S + (size_t)(2 * y) * sw + 2 * x;
+    D[(size_t)y * d.ds_w + x] = (uint8_t)((r0[0] + r0[1] + r0[sw] + r0[sw + 1] + 2) >> 2);
+    return;
+  }
+  float v;
+  if (d.do_ds == 2) {
+    int sum = 0;
+    for (int ky = 0; ky < d.ds_fy; ++ky)
+      for (int kx = 0; kx < d.ds_fx; ++kx) sum += S[(size_t)(y * d.ds_fy + ky) * sw + x * d.ds_fx + kx];
+    v = __fmul_rn((float)sum, 1.f / (float)(d.ds_fx * d.ds_fy));
+  } else {
+    const int x0 = tabs[d.axb + 2 * x], nx = tabs[d.axb + 2 * x + 1];
+    const int y0 = tabs[d.ayb + 2 * y], ny = tabs[d.ayb + 2 * y + 1];
+    const float* ax = reinterpret_cast<const float*>(tabs + d.axk) + (size_t)x * d.axs;
+    const float* ay = reinterpret_cast<const float*>(tabs + d.ayk) + (size_t)y * d.ays;
+    v = 0.f;
+    for (int ky = 0; ky < ny; ++ky) {
+      float buf = 0.f;
+      for (int kx = 0; kx < nx; ++kx) buf = __fadd_rn(buf, __fmul_rn(ax[kx], (float)S[(size_t)(y0 + ky) * sw + x0 + kx]));
+      v = ky == 0 ? __fmul_rn(ay[0], buf) : __fadd_rn(v, __fmul_rn(ay[ky], buf));
+    }
+  }
+  int r = (int)rintf(v);  // saturate_cast<uchar>(float): round half to even, clamp
+  D[(size_t)y * d.ds_w + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+// Horizontal LANCZOS pass: one block per source row; the row is staged in LDS once (4-byte loads over the aligned middle).
+__global__ __launch_bounds__(256) void prep_hpass_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                         uint8_t* __restrict__ work, const int32_t* __restrict__ tabs) {
+  extern __shared__ uint8_t row[];
+  const PrepDesc d = descs[blockIdx.y];
+  const int y = blockIdx.x;
+  if (!d.do_h || y >= d.ds_h) return;
+  const uint8_t* in = (d.do_ds ? work + d.ds_off : src + d.src_off) + (size_t)y * d.ds_w;
+  const int w = d.ds_w;
+  const int head = min(w, (int)((4 - (reinterpret_cast<uintptr_t>(in) & 3)) & 3));
+  const int words = (w - head) >> 2;
+  // LDS byte i + pad holds source byte i, pad chosen so that the word part is 4-byte aligned in LDS as well
+  const int pad = (4 - head) & 3;
+  for (int i = threadIdx.x; i < head; i += 256) row[pad + i] = in[i];
+  const uint32_t* in4 = reinterpret_cast<const uint32_t*>(in + head);
+  uint32_t* row4 = reinterpret_cast<uint32_t*>(row + pad + head);
+  for (int i = threadIdx.x; i < words; i += 256) row4[i] = in4[i];
+  for (int i = head + 4 * words + threadIdx.x; i < w; i += 256) row[pad + i] = in[i];
+  __syncthreads();
+  const int ow = d.rs_w;
+  uint8_t* out = work + d.hp_off + (size_t)y * ow;
+  const int32_t* hb = tabs + d.hb;
+  const int32_t* hk = tabs + d.hk;
+  for (int xx = threadIdx.x; xx < ow; xx += 256) {
+    const int xmin = hb[2 * xx], cnt = hb[2 * xx + 1];
+    int ss = 1 << (PRECISION_BITS - 1);
+    const uint8_t* r = row + pad + xmin;
+    for (int k = 0; k < cnt; ++k) ss += (int)r[k] * hk[(size_t)k * ow + xx];
+    out[xx] = clip8(ss);
+  }
+}
+
+// Vertical LANCZOS pass (when the height changes) + canvas / padding + normalisation table + paste check.  One block per
+// output row of the batch tensor, 256 columns per block: the row index is block-uniform, so the coefficients are scalar
+// loads, and every tap reads 256 consecutive bytes of one intermediate row.
+__global__ __launch_bounds__(256) void prep_finish_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                          const uint8_t* __restrict__ work, const int32_t* __restrict__ tabs,
+                                                          const float* __restrict__ lut, float* __restrict__ out, int out_h,
+                                                          int out_w, int32_t* __restrict__ bits) {
+  const PrepDesc d = descs[blockIdx.z];
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  const uint8_t* in = d.do_h ? work + d.hp_off : (d.do_ds ? work + d.ds_off : src + d.src_off);
+  const int iw = d.rs_w;  // width of `in` (the horizontal pass, when there is one, has already produced rs_w columns)
+  float o = d.fill;
+  int mybits = 0;
+  if (x < out_w && y < d.rs_h && x < d.rs_w) {
+    int v;
+    if (d.do_v) {
+      const int ymin = tabs[d.vb + 2 * y], cnt = tabs[d.vb + 2 * y + 1];
+      const int32_t* vk = tabs + d.vk + (size_t)y * d.vks;
+      int ss = 1 << (PRECISION_BITS - 1);
+      for (int k = 0; k < cnt; ++k) ss += (int)in[(size_t)(ymin + k) * iw + x] * vk[k];
+      v = clip8(ss);
+    } else {
+      v = in[(size_t)y * iw + x];
+    }
+    o = lut[v];  // the fallback normalises with the same transform (predict_utils.py:89)
+    if (d.min_branch && v) mybits = 1 | (y == 0 ? 2 : 0) | (y == d.rs_h - 1 ? 4 : 0) | (x == 0 ? 8 : 0) | (x == d.rs_w - 1 ? 16 : 0);
+  }
+  if (x < out_w) out[((size_t)blockIdx.z * out_h + y) * out_w + x] = o;
+  if (d.min_branch) {
+    for (int s = 32; s; s >>= 1) mybits |= __shfl_xor(mybits, s);
+    if ((threadIdx.x & 63) == 0 && mybits) atomicOr(&bits[blockIdx.z], mybits);
+  }
+}
+
+__global__ void prep_flags_kernel(const PrepDesc* __restrict__ descs, const int32_t* __restrict__ bits, int32_t* __restrict__ flags,
+                                  int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = bits[i];
+  // getbbox() is None (all zero): paste(img, None) succeeds; otherwise the box must be the whole image
+  flags[i] = (descs[i].min_branch && (b & 1) && (b & 30) != 30) ? D2T_PREP_FLAG_PASTE_MISMATCH : 0;
+}
+
+}  // namespace
+
+struct d2t_prep {
+  d2t_prep_config cfg;
+  std::string err;
+  float* lut = nullptr;  // [256] normalisation table
+  std::map<std::pair<int, int>, AxisTab> lanczos, area;
+  // per-call staging: descriptors + tables in one pinned host block, mirrored on the device
+  char* h_stage = nullptr;
+  char* d_stage = nullptr;
+  size_t stage_cap = 0;
+  uint8_t* d_work = nullptr;
+  size_t work_cap = 0;
+  int32_t* d_bits = nullptr;
+  int bits_cap = 0;
+  hipEvent_t staged = nullptr;
+  bool staged_pending = false;
+};
+
+namespace {
+int fail(d2t_prep* p, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (p) p->err = buf;
+  return code;
+}
+#define PHIP(p, expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(p, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+const AxisTab& cached(std::map<std::pair<int, int>, AxisTab>& m, int in, int out, void (*build)(int, int, AxisTab&)) {
+  auto key = std::make_pair(in, out);
+  auto it = m.find(key);
+  if (it == m.end()) {
+    if (m.size() > 4096) m.clear();
+    it = m.emplace(key, AxisTab()).first;
+    build(in, out, it->second);
+  }
+  return it->second;
+}
+}  // namespace
+
+extern "C" {
+
+int d2t_prep_plan_image(const d2t_prep_config* cfg, int src_h, int src_w, d2t_prep_plan* plan) {
+  return plan_image(cfg, src_h, src_w, plan);
+}
+
+int d2t_prep_plan_fallback(const d2t_prep_config* cfg, int src_h, int src_w, d2t_prep_plan* plan) {
+  int rc = plan_image(cfg, src_h, src_w, plan);
+  if (rc != D2T_OK) return rc;
+  plan_fallback(cfg, plan);
+  return D2T_OK;
+}
+
+int d2t_prep_lanczos_coeffs(int in_size, int out_size, int32_t* ksize_out, int32_t* bounds, int32_t* kk) {
+  if (in_size <= 0 || out_size <= 0 || !ksize_out) return D2T_EINVAL;
+  AxisTab t;
+  build_lanczos(in_size, out_size, t);
+  *ksize_out = t.ksize;
+  if (bounds) memcpy(bounds, t.bounds.data(), t.bounds.size() * 4);
+  if (kk) memcpy(kk, t.coef.data(), t.coef.size() * 4);
+  return D2T_OK;
+}
+
+int d2t_prep_create(const d2t_prep_config* cfg, d2t_prep** out) {
+  if (!cfg || !out) return D2T_EINVAL;
+  d2t_prep* p = new d2t_prep();
+  p->cfg = *cfg;
+  *out = p;
+  if (cfg->max_h <= 0 || cfg->max_w <= 0 || cfg->downsample < 0 || !(cfg->std != 0.f))
+    return fail(p, D2T_EINVAL, "bad pre-processing config");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(p, D2T_EHIP, "no HIP device visible (the pre-processing has no CPU path)");
+  // albumentations Normalize(mean, std, max_pixel_value=255) in float32 (math_transform.py:43-52)
+  float host[258];
+  const float m = cfg->mean * 255.0f;
+  volatile float sd = cfg->std * 255.0f;
+  const float dnm = 1.0f / sd;
+  for (int v = 0; v < 256; ++v) {
+    volatile float t = (float)v - m;
+    host[v] = t * dnm;
+  }
+  host[256] = m;
+  host[257] = dnm;
+  PHIP(p, hipMalloc(&p->lut, sizeof host));
+  PHIP(p, hipMemcpy(p->lut, host, sizeof host, hipMemcpyHostToDevice));
+  PHIP(p, hipEventCreateWithFlags(&p->staged, hipEventDisableTiming));
+  return D2T_OK;
+}
+
+void d2t_prep_destroy(d2t_prep* p) {
+  if (!p) return;
+  if (p->staged_pending) hipEventSynchronize(p->staged);
+  if (p->lut) hipFree(p->lut);
+  if (p->d_stage) hipFree(p->d_stage);
+  if (p->h_stage) hipHostFree(p->h_stage);
+  if (p->d_work) hipFree(p->d_work);
+  if (p->d_bits) hipFree(p->d_bits);
+  if (p->staged) hipEventDestroy(p->staged);
+  delete p;
+}
+
+const char* d2t_prep_last_error(const d2t_prep* p) { return p ? p->err.c_str() : "null handle"; }
+
+int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* src_dev, const int64_t* src_offsets,
+                 float* out_dev, int out_h, int out_w, int32_t* flags_dev, void* stream_) {
+  if (!p) return D2T_EINVAL;
+  if (n <= 0 || !plans || !src_dev || !src_offsets || !out_dev || out_h <= 0 || out_w <= 0)
+    return fail(p, D2T_EINVAL, "d2t_prep_run: bad argument");
+  if (!p->lut) return fail(p, D2T_ESTATE, "d2t_prep_run: handle was not created on a HIP device");
+  hipStream_t stream = (hipStream_t)stream_;
+  const d2t_prep_config& c = p->cfg;
+
+  // ---- validate the plans against the configuration (a plan must be what d2t_prep_plan_image would produce) -------
+  std::vector<PrepDesc> descs(n);
+  std::vector<int32_t> tabs;
+  auto add = [&](const std::vector<int32_t>& v) {
+    const int32_t off = (int32_t)tabs.size();
+    tabs.insert(tabs.end(), v.begin(), v.end());
+    return off;
+  };
+  size_t work = 0;
+  int max_ds_w = 1, max_ds_h = 1, max_rows_h = 0, any_min = 0, any_ds = 0, any_h = 0;
+  for (int i = 0; i < n; ++i) {
+    const d2t_prep_plan& pl = plans[i];
+    d2t_prep_plan want;
+    int rc = pl.status == D2T_PREP_FALLBACK ? d2t_prep_plan_fallback(&c, pl.src_h, pl.src_w, &want)
+                                            : plan_image(&c, pl.src_h, pl.src_w, &want);
+    if (rc != D2T_OK || memcmp(&want, &pl, sizeof want) != 0)
+      return fail(p, D2T_EINVAL, "d2t_prep_run: plan %d does not match the configuration (status %d)", i, pl.status);
+    if (pl.status == D2T_PREP_UNBOUND_LOCAL)
+      return fail(p, D2T_EINVAL, "d2t_prep_run: plan %d has status UNBOUND_LOCAL (the reference raises for this image)", i);
+    if (pl.out_h != out_h || pl.out_w != out_w)
+      return fail(p, D2T_EINVAL, "d2t_prep_run: plan %d produces %dx%d, the call's output is %dx%d", i, pl.out_h, pl.out_w,
+                  out_h, out_w);
+    if (pl.min_branch && !flags_dev) return fail(p, D2T_EINVAL, "d2t_prep_run: plan %d needs flags_dev (paste check)", i);
+    if (pl.ds_w > 65000) return fail(p, D2T_EINVAL, "d2t_prep_run: image %d is wider than 65000 pixels", i);
+    PrepDesc& d = descs[i];
+    memset(&d, 0, sizeof d);
+    d.src_off = src_offsets[i];
+    d.src_h = pl.src_h, d.src_w = pl.src_w, d.ds_h = pl.ds_h, d.ds_w = pl.ds_w, d.rs_h = pl.rs_h, d.rs_w = pl.rs_w;
+    d.fallback = pl.status == D2T_PREP_FALLBACK;
+    d.min_branch = pl.min_branch;
+    d.fill = d.fallback ? 1.0f : 0.f;  // non-fallback: lut[255], patched below on the host copy of the table
+    if (pl.ds_h != pl.src_h || pl.ds_w != pl.src_w) {
+      const double sx = (double)pl.src_w / pl.ds_w, sy = (double)pl.src_h / pl.ds_h;
+      if (sx == 2.0 && sy == 2.0) {
+        d.do_ds = 1;
+      } else if (sx == floor(sx) && sy == floor(sy)) {
+        d.do_ds = 2, d.ds_fx = (int)sx, d.ds_fy = (int)sy;
+      } else {
+        d.do_ds = 3;
+        const AxisTab& ax = cached(p->area, pl.src_w, pl.ds_w, build_area);
+        d.axb = add(ax.bounds), d.axk = add(ax.coef), d.axs = ax.ksize;
+        const AxisTab& ay = cached(p->area, pl.src_h, pl.ds_h, build_area);
+        d.ayb = add(ay.bounds), d.ayk = add(ay.coef), d.ays = ay.ksize;
+      }
+      d.ds_off = (int64_t)work;
+      work += ((size_t)pl.ds_h * pl.ds_w + 15) & ~(size_t)15;
+      any_ds = 1;
+      max_ds_w = std::max(max_ds_w, pl.ds_w), max_ds_h = std::max(max_ds_h, pl.ds_h);
+    }
+    if (!d.fallback && pl.rs_w != pl.ds_w) {  // ImagingResample: horizontal pass only when the width changes
+      d.do_h = 1;
+      const AxisTab& t = cached(p->lanczos, pl.ds_w, pl.rs_w, build_lanczos);
+      d.hb = add(t.bounds);
+      d.hks = t.ksize;
+      d.hk = (int32_t)tabs.size();
+      tabs.resize(tabs.size() + t.coef.size());
+      for (int xx = 0; xx < pl.rs_w; ++xx)
+        for (int k = 0; k < t.ksize; ++k) tabs[d.hk + (size_t)k * pl.rs_w + xx] = t.coef[(size_t)xx * t.ksize + k];
+      d.hp_off = (int64_t)work;
+      work += ((size_t)pl.ds_h * pl.rs_w + 15) & ~(size_t)15;
+      any_h = 1;
+      max_rows_h = std::max(max_rows_h, pl.ds_h);
+    }
+    if (!d.fallback && pl.rs_h != pl.ds_h) {
+      d.do_v = 1;
+      const AxisTab& t = cached(p->lanczos, pl.ds_h, pl.rs_h, build_lanczos);
+      d.vb = add(t.bounds), d.vk = add(t.coef), d.vks = t.ksize;
+    }
+    if (d.fallback) d.rs_h = std::min(pl.ds_h, out_h), d.rs_w = pl.ds_w;  // F.pad with a negative amount crops
+    any_min |= pl.min_branch;
+  }
+  // canvas colour 255 through the normalisation table
+  {
+    const float m = c.mean * 255.0f;
+    volatile float sd = c.std * 255.0f;
+    const float dnm = 1.0f / sd;
+    volatile float t = 255.0f - m;
+    const float fill = t * dnm;
+    for (auto& d : descs)
+      if (!d.fallback) d.fill = fill;
+  }
+
+  // ---- stage descriptors + tables -----------------------------------------------------------------------------------
+  const size_t desc_bytes = ((size_t)n * sizeof(PrepDesc) + 255) & ~(size_t)255;
+  const size_t need = desc_bytes + tabs.size() * 4 + 256;
+  if (p->staged_pending) {  // the previous call's copy out of the pinned block must have finished
+    PHIP(p, hipEventSynchronize(p->staged));
+    p->staged_pending = false;
+  }
+  if (need > p->stage_cap) {
+    if (p->d_stage) PHIP(p, hipFree(p->d_stage));
+    if (p->h_stage) PHIP(p, hipHostFree(p->h_stage));
+    p->d_stage = p->h_stage = nullptr;
+    p->stage_cap = 0;
+    const size_t cap = need * 2;
+    PHIP(p, hipHostMalloc((void**)&p->h_stage, cap, hipHostMallocDefault));
+    PHIP(p, hipMalloc((void**)&p->d_stage, cap));
+    p->stage_cap = cap;
+  }
+  if (work > p->work_cap) {
+    if (p->d_work) PHIP(p, hipFree(p->d_work));
+    p->d_work = nullptr, p->work_cap = 0;
+    PHIP(p, hipMalloc((void**)&p->d_work, work * 2));
+    p->work_cap = work * 2;
+  }
+  if (n > p->bits_cap) {
+    if (p->d_bits) PHIP(p, hipFree(p->d_bits));
+    p->d_bits = nullptr, p->bits_cap = 0;
+    PHIP(p, hipMalloc((void**)&p->d_bits, (size_t)n * 2 * 4));
+    p->bits_cap = n * 2;
+  }
+  memcpy(p->h_stage, descs.data(), (size_t)n * sizeof(PrepDesc));
+  if (!tabs.empty()) memcpy(p->h_stage + desc_bytes, tabs.data(), tabs.size() * 4);
+  PHIP(p, hipMemcpyAsync(p->d_stage, p->h_stage, need, hipMemcpyHostToDevice, stream));
+  PHIP(p, hipEventRecord(p->staged, stream));
+  p->staged_pending = true;
+  const PrepDesc* d_descs = reinterpret_cast<const PrepDesc*>(p->d_stage);
+  const int32_t* d_tabs = reinterpret_cast<const int32_t*>(p->d_stage + desc_bytes);
+
+  // ---- launches -------------------------------------------------------------------------------------------------------
+  if (any_ds)
+    hipLaunchKernelGGL(prep_area_kernel, dim3((max_ds_w + 63) / 64, (max_ds_h + 3) / 4, n), dim3(256), 0, stream, d_descs,
+                       src_dev, p->d_work, d_tabs);
+  if (any_h) {
+    int max_in_w = 1;
+    for (int i = 0; i < n; ++i)
+      if (descs[i].do_h) max_in_w = std::max(max_in_w, descs[i].ds_w);
+    const size_t lds = ((size_t)max_in_w + 8 + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(prep_hpass_kernel, dim3(max_rows_h, n), dim3(256), lds, stream, d_descs, src_dev, p->d_work, d_tabs);
+  }
+  if (any_min) PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));
+  hipLaunchKernelGGL(prep_finish_kernel, dim3((out_w + 255) / 256, out_h, n), dim3(256), 0, stream, d_descs, src_dev,
+                     (const uint8_t*)p->d_work, d_tabs, (const float*)p->lut, out_dev, out_h, out_w, p->d_bits);
+  if (flags_dev) {
+    if (!any_min) PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));
+    hipLaunchKernelGGL(prep_flags_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_descs, (const int32_t*)p->d_bits,
+                       flags_dev, n);
+  }
+  PHIP(p, hipGetLastError());
+  return D2T_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Image pre-processing on the MI355X: the step before `Model.forward`.
+
+Host-side mirror of the reference's `resize()` -- `doc2tex/utils/predict_utils.py:14-115` (what `api/infer.py:62`
+calls with an image path; variant "api") and `demo/HybridViT/helper.py:134-207` (what `demo/HybridViT/recog_flow.py:81`
+calls with a PIL image; variant "demo") -- for the configuration the shipped YAMLs use: `imgH: null`, no learned
+resizer, `pad: False`, grayscale.  Same argument meaning, same return value (a float32 `[1,1,H,W]` tensor, here on the
+GPU), same exceptions.  All pixel work runs in `libd2t.so` (`d2t_prep_run`, include/d2t_prep.h): there is no CPU path.
+
+The two reference copies differ in `get_divisible_size`: the "api" copy (`utils/data_utils.py:48-60`) leaves its result
+unassigned when a scaled size is already a multiple of 32 and raises `UnboundLocalError` -- for nearly every image that
+needs resizing -- while the "demo" copy (`helper.py:95-107`) is repaired.  Both behaviours are mirrored; "demo" is the
+default for arrays / PIL images, "api" for paths, as in the reference.
+
+`Preprocessor.batch()` is the serving extension: many images per call, grouped by output size into `[n,1,H,W]` batches
+(the bucketed batches `data/collate_fn.py:15-47` builds), each image bit-identical to its single-image `resize()`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def _as_gray_array(img):
+    """uint8 [h, w]: what `Image.open(path).convert("L")` / `img.convert("L")` holds (predict_utils.py:16, helper.py:136)."""
+    if isinstance(img, np.ndarray):
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise TypeError("expected a uint8 [h, w] grayscale array")
+        return np.ascontiguousarray(img)
+    from PIL import Image
+    if isinstance(img, (str, os.PathLike)):
+        img = Image.open(img)
+    return np.ascontiguousarray(np.asarray(img.convert("L"), dtype=np.uint8))
+
+
+class Preprocessor:
+    def __init__(self, opt, variant="demo", device=None):
+        import torch
+        assert isinstance(opt, dict)
+        assert "imgH" in opt and "imgW" in opt  # predict_utils.py:18-19
+        if opt["imgH"] is not None:
+            raise NotImplementedError("doc2tex_amd.preprocess: only the `imgH: null` branch (the shipped configs) is built")
+        if opt.get("rgb", False):
+            raise NotImplementedError("doc2tex_amd.preprocess: grayscale only (rgb: False in every shipped config)")
+        if opt.get("pad", False):
+            raise NotImplementedError("doc2tex_amd.preprocess: `pad: True` (cv2 bounding-box crop) is not built")
+        if opt.get("use_resizer", False):
+            raise NotImplementedError("doc2tex_amd.preprocess: the learned resizer loop is not on this path")
+        if variant not in ("demo", "api"):
+            raise ValueError("variant must be 'demo' or 'api'")
+        ds = opt.get("downsample", None) if variant == "api" else None
+        if ds is not None and (int(ds) != ds or ds < 1):
+            raise NotImplementedError("doc2tex_amd.preprocess: integer `downsample` ratios only")
+        self.variant = variant
+        self.lib = _lib.require_device()
+        self.device = torch.device(device if device is not None else opt.get("device", "cuda"))
+        if self.device.type != "cuda":
+            raise RuntimeError("doc2tex_amd.preprocess runs on the GPU only (no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg = _lib.D2TPrepConfig(
+            max_h=opt["max_dimension"][0], max_w=opt["max_dimension"][1],
+            min_h=opt["min_dimension"][0], min_w=opt["min_dimension"][1],
+            downsample=int(ds) if ds else 0, variant=_lib.PREP_API if variant == "api" else _lib.PREP_DEMO,
+            mean=float(opt["mean"]), std=float(opt["std"]))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.d2t_prep_create(C.byref(self.cfg), C.byref(h))
+        self.h = h
+        self._check(rc, "d2t_prep_create")
+
+    def _check(self, rc, what):
+        if rc != _lib.D2T_OK:
+            raise RuntimeError(f"libd2t {what} failed (code {rc}) {self.lib.d2t_prep_last_error(self.h).decode()}")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.d2t_prep_destroy(self.h)
+            self.h = None
+
+    def plan(self, h, w, fallback=False):
+        p = _lib.D2TPrepPlan()
+        fn = self.lib.d2t_prep_plan_fallback if fallback else self.lib.d2t_prep_plan_image
+        if fn(C.byref(self.cfg), int(h), int(w), C.byref(p)) != _lib.D2T_OK:
+            raise ValueError(f"bad image size {h}x{w}")
+        return p
+
+    def _run(self, arrays, plans, out_h, out_w):
+        """One d2t_prep_run: arrays[i] with plans[i] -> ([n,1,H,W] float32 on the device, flags tensor or None)."""
+        import torch
+        n = len(arrays)
+        offs = np.zeros(n, np.int64)
+        total = 0
+        for i, a in enumerate(arrays):
+            offs[i] = total
+            total += (a.size + 15) & ~15
+        host = torch.empty(total, dtype=torch.uint8).pin_memory()
+        hv = host.numpy()
+        for a, o in zip(arrays, offs):
+            hv[o:o + a.size] = a.reshape(-1)
+        with torch.cuda.device(self.device):
+            src = host.to(self.device, non_blocking=True)
+            out = torch.empty((n, 1, out_h, out_w), dtype=torch.float32, device=self.device)
+            need_flags = any(p.min_branch for p in plans)
+            flags = torch.empty(n, dtype=torch.int32, device=self.device) if need_flags else None
+            rc = self.lib.d2t_prep_run(self.h, n, (_lib.D2TPrepPlan * n)(*plans), _lib.ptr(src),
+                                       offs.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(out), out_h, out_w,
+                                       _lib.ptr(flags), _lib.stream_of(out))
+            src.record_stream(torch.cuda.current_stream(self.device))
+        self._check(rc, "d2t_prep_run")
+        return out, flags
+
+    def batch(self, images):
+        """images: paths / PIL images / uint8 [h,w] arrays -> (tensors, errors): tensors[i] is image i's [1,1,H,W] result
+        (a view into the [n,1,H,W] batch of its size bucket; `tensors[i]._base` is the bucket), errors[i] the exception
+        instance the reference's resize() raises for image i (tensors[i] is None then)."""
+        arrays = [_as_gray_array(im) for im in images]
+        plans = [self.plan(*a.shape) for a in arrays]
+        tensors, errors = [None] * len(arrays), [None] * len(arrays)
+        pending = list(range(len(arrays)))
+        for attempt in range(2):
+            buckets = {}
+            for i in pending:
+                p = plans[i]
+                if p.status == _lib.PREP_UNBOUND_LOCAL:
+                    errors[i] = UnboundLocalError("local variable 'new_h' referenced before assignment "
+                                                  "(get_divisible_size, utils/data_utils.py:48-60)")
+                elif p.status == _lib.PREP_FALLBACK and self.variant == "api":
+                    # predict_utils.py:87-88: the grayscale array is 2-D, the assert on its shape fails
+                    errors[i] = AssertionError()
+                else:
+                    buckets.setdefault((p.out_h, p.out_w), []).append(i)
+            redo = []
+            for (oh, ow), idx in buckets.items():
+                out, flags = self._run([arrays[i] for i in idx], [plans[i] for i in idx], oh, ow)
+                bad = set()
+                if flags is not None:  # only tiny images pasted on the min_dimension canvas get here
+                    fl = flags.cpu().numpy()
+                    bad = {k for k in range(len(idx)) if fl[k] & _lib.PREP_FLAG_PASTE_MISMATCH}
+                for k, i in enumerate(idx):
+                    if k in bad:  # `padded_im.paste(img, img.getbbox())` raised ValueError -> the except branch
+                        print("Error:", "images do not match")
+                        plans[i] = self.plan(*arrays[i].shape, fallback=True)
+                        redo.append(i)
+                    else:
+                        tensors[i] = out[k:k + 1]
+            pending = redo
+            if not pending:
+                break
+        return tensors, errors
+
+    def __call__(self, img):
+        tensors, errors = self.batch([img])
+        if errors[0] is not None:
+            raise errors[0]
+        return tensors[0]
+
+
+_cache = {}
+
+
+def resize(resizer, img, opt, variant=None):
+    """Drop-in for `resize(resizer, img_path, opt)` (predict_utils.py:14) / `resize(resizer, img, opt)` (helper.py:134)."""
+    if resizer is not None and resizer is not False:
+        raise NotImplementedError("doc2tex_amd.preprocess: the learned resizer loop is not on this path")
+    if variant is None:
+        variant = "api" if isinstance(img, (str, os.PathLike)) else "demo"
+    key = (variant, tuple(opt["max_dimension"]), tuple(opt["min_dimension"]), opt.get("downsample", None),
+           float(opt["mean"]), float(opt["std"]), str(opt.get("device", "cuda")))
+    pre = _cache.get(key)
+    if pre is None:
+        pre = _cache[key] = Preprocessor(opt, variant)
+    return pre(img)

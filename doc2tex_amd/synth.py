@@ -262,3 +262,23 @@ def synth_labels(batch, max_len=MAX_LEN, seed=2000, vocab=VOCAB):
         text[b, 1:1 + n] = g.integers(4, vocab, size=n)
         text[b, 1 + n] = 2
     return torch.from_numpy(text)
+
+
+def synth_formula_image(h, w, seed=4000, zero_border=False, blank=None):
+    """uint8 [h, w] grayscale stand-in for a rendered formula image (what `Image.open(path).convert("L")` holds before
+    utils/predict_utils.py:14 resizes it): white page, dark strokes of a few pixels with grey anti-aliased edges.
+    `zero_border` blackens the first row (the case in which the reference's paste raises); `blank` = a constant page."""
+    rng = np.random.default_rng(seed)
+    if blank is not None:
+        return np.full((h, w), blank, np.uint8)
+    img = np.full((h, w), 255, np.int32)
+    for _ in range(max(4, h * w // 600)):
+        y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+        dy, dx = (int(rng.integers(1, 4)), int(rng.integers(2, 24))) if rng.random() < 0.5 else \
+                 (int(rng.integers(2, 24)), int(rng.integers(1, 4)))
+        img[y:y + dy, x:x + dx] = int(rng.integers(0, 60))
+    img = img + rng.integers(-12, 1, (h, w))  # page noise keeps the resampler's rounding exercised
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    if zero_border:
+        img[0, :] = 0
+    return img

@@ -1,0 +1,131 @@
+"""GPU parity of the pre-processing row: doc2tex_amd.preprocess (libd2t's d2t_prep_run) against
+oracle/preprocess.py -- which is pinned on Pillow and on the reference's own minmax_size (tests/test_prep_post_cpu.py).
+Integer pixel work: the uint8 image behind the float tensor must be bit-exact, so the float tensors are compared with ==."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, engine_model, oracle_state_dict
+from doc2tex_amd import synth
+from oracle import preprocess as P
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "prep_cases.json")))
+ARR = np.load(os.path.join(GOLD, "prep_cases.npz"))
+
+
+def _opt(maxd, mind=(32, 32), **kw):
+    o = {"imgH": None, "imgW": None, "max_dimension": list(maxd), "min_dimension": list(mind), "mean": 0.5, "std": 0.5,
+         "rgb": False, "pad": False, "use_resizer": False, "device": "cuda"}
+    o.update(kw)
+    return o
+
+
+def _pre(opt, variant):
+    from doc2tex_amd.preprocess import Preprocessor
+    return Preprocessor(opt, variant)
+
+
+@pytest.mark.parametrize("case", [c for c in META["cases"] if c["variant"] == "demo"], ids=lambda c: c["name"])
+def test_reference_fixture_cases(case, capsys):
+    img = synth.synth_formula_image(case["h"], case["w"], case["seed"], zero_border=case["zero_border"], blank=case["blank"])
+    opt = _opt(case["max_dimension"], case["min_dimension"])
+    got = _pre(opt, "demo")(img).cpu().numpy()
+    want = P.resize(img, opt, variant="demo")
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got, want)
+    if case["raises"] is None:  # the REFERENCE's minmax_size output, through the normalisation table
+        assert np.array_equal(got[0, 0], P.normalize_lut(0.5, 0.5)[ARR[case["name"]]])
+    else:  # ValueError inside the reference -> its except branch: max_dimension canvas of ones
+        assert got.shape[2:] == tuple(case["max_dimension"]) and "Error:" in capsys.readouterr().out
+
+
+def test_api_variant_raises_what_the_reference_raises():
+    pre = _pre(_opt([128, 512], downsample=None), "api")
+    for c in [c for c in META["cases"] if c["variant"] == "api"]:
+        img = synth.synth_formula_image(c["h"], c["w"], c["seed"], zero_border=c["zero_border"], blank=c["blank"])
+        if c["max_dimension"] != [128, 512]:
+            continue
+        if c["raises"] == "UnboundLocalError":
+            with pytest.raises(UnboundLocalError):
+                pre(img)
+        else:
+            assert np.array_equal(pre(img).cpu().numpy()[0, 0], P.normalize_lut(0.5, 0.5)[ARR[c["name"]]])
+
+
+@pytest.mark.parametrize("maxd", [(128, 512), (448, 960), (64, 256)])
+def test_random_sizes_bit_exact(maxd):
+    rng = np.random.default_rng(maxd[0])
+    pre = _pre(_opt(maxd), "demo")
+    imgs = []
+    for i in range(48):
+        h = int(rng.integers(1, 4 * maxd[0]))
+        w = int(rng.integers(1, 4 * maxd[1]))
+        imgs.append(synth.synth_formula_image(h, w, 5000 + i, zero_border=(i % 11 == 0), blank=(0 if i % 13 == 0 else None)))
+    tensors, errors = pre.batch(imgs)
+    assert all(e is None for e in errors)
+    buckets = set()
+    for img, t in zip(imgs, tensors):
+        want = P.resize(img, _opt(maxd), variant="demo")
+        got = t.cpu().numpy()
+        assert got.shape == want.shape, (img.shape, got.shape, want.shape)
+        assert np.array_equal(got, want), img.shape
+        buckets.add(t._base.data_ptr() if t._base is not None else t.data_ptr())
+        assert np.array_equal(pre(img).cpu().numpy(), got)  # single-image call == batched call
+    assert len(buckets) < len(imgs)  # images of one output size share one [n,1,H,W] batch
+
+
+def test_api_variant_downsample_matches_oracle():
+    """cv2.INTER_AREA is restated, not pinned (cv2 is not in the image): engine == oracle on even (2x2 mean), odd
+    (fractional area weights) and factor-3 sizes."""
+    for ds in (2, 3):
+        opt = _opt((448, 960), downsample=ds)
+        pre = _pre(opt, "api")
+        n_ok = 0
+        for i, (h, w) in enumerate([(200, 600), (201, 601), (199, 600), (90, 301), (64, 64), (63, 65), (40, 500), (333, 777)]):
+            img = synth.synth_formula_image(h, w, 6000 + i)
+            try:
+                want = P.resize(img, opt, variant="api")
+            except UnboundLocalError:
+                with pytest.raises(UnboundLocalError):
+                    pre(img)
+                continue
+            got = pre(img).cpu().numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), (ds, h, w)
+            n_ok += 1
+        assert n_ok >= 4
+
+
+def test_unsupported_options_raise():
+    from doc2tex_amd.preprocess import Preprocessor, resize
+    with pytest.raises(NotImplementedError):
+        Preprocessor(_opt((128, 512), pad=True))
+    with pytest.raises(NotImplementedError):
+        Preprocessor(_opt((128, 512), imgH=32))
+    with pytest.raises(NotImplementedError):
+        resize(object(), np.zeros((4, 4), np.uint8), _opt((128, 512)))
+
+
+def test_resize_feeds_the_recognizer():
+    """resize() -> Model.forward on the GPU == oracle pre-processing -> oracle forward on the CPU (tokens exact)."""
+    from doc2tex_amd.preprocess import resize
+    from oracle import restatement as R
+    man = json.load(open(os.path.join(GOLD, "manifests.json")))
+    L = 10
+    cfg, m = engine_model("T2", L)
+    opt = _opt(cfg["max_dimension"])
+    img = synth.synth_formula_image(3 * cfg["max_dimension"][0] + 5, 3 * cfg["max_dimension"][1] + 11, 7000)
+    x = resize(None, img, opt)
+    want_x = torch.from_numpy(P.resize(img, opt, variant="demo"))
+    assert torch.equal(x.cpu(), want_x)
+    text = torch.full((1, 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        preds, logits, _ = m(x, text.cuda(), is_train=False)
+        ocfg, sd = oracle_state_dict("T2", man["T2"], L)
+        op, ol, _ = R.forward(ocfg, sd, want_x, text)
+    assert torch.equal(preds.cpu(), op)
+    assert float((logits.cpu() - ol).abs().max()) <= 1e-3

@@ -1,0 +1,185 @@
+"""CPU: the pre-/post-processing rows.
+
+* oracle/preprocess.py against the fixtures written from the REFERENCE's own function bodies
+  (tools/make_golden_prep.py) and against Pillow live;
+* the host-side half of the product (size planning, Pillow coefficient tables, the string post-processing: all host
+  code inside libd2t.so) against the oracle / the reference fixtures -- no device work is called here;
+* include/d2t_prep.h <-> exported symbols <-> ctypes signatures.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from doc2tex_amd import _lib, synth
+from oracle import preprocess as P
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "prep_cases.json")))
+ARR = np.load(os.path.join(GOLD, "prep_cases.npz"))
+POST = json.load(open(os.path.join(GOLD, "post_cases.json")))
+
+
+def _case_image(c):
+    return synth.synth_formula_image(c["h"], c["w"], c["seed"], zero_border=c["zero_border"], blank=c["blank"])
+
+
+def test_header_symbols_exported_and_bound():
+    text = open(os.path.join(ROOT, "include", "d2t_prep.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(d2t_[a-z0-9_]+)\s*\(", text)))
+    lib = _lib.load()
+    for s in syms:
+        assert hasattr(lib, s), f"libd2t.so does not export {s}"
+    assert sorted(_lib.SIGNATURES_PREP) == syms
+    for struct, name in ((_lib.D2TPrepConfig, "d2t_prep_config"), (_lib.D2TPrepPlan, "d2t_prep_plan")):
+        body = re.search(r"typedef struct \{([^}]*)\} %s;" % name, text, re.S).group(1)
+        names = [n.strip() for decl in re.findall(r"(?:int32_t|float)([^;]+);", body) for n in decl.split(",")]
+        assert names == [f[0] for f in struct._fields_]
+
+
+@pytest.mark.parametrize("case", META["cases"], ids=lambda c: c["name"])
+def test_oracle_matches_reference_fixture(case):
+    img = _case_image(case)
+    if case["raises"]:
+        with pytest.raises({"UnboundLocalError": UnboundLocalError, "ValueError": ValueError}[case["raises"]]):
+            P.minmax_size(img, case["max_dimension"], case["min_dimension"], variant=case["variant"])
+        return
+    got = P.minmax_size(img, case["max_dimension"], case["min_dimension"], variant=case["variant"])
+    assert list(got.shape) == case["out_shape"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == case["sha256"]
+    assert np.array_equal(got, ARR[case["name"]])
+
+
+def test_oracle_lanczos_equals_pillow_live():
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    for i in range(12):
+        h, w = int(rng.integers(3, 200)), int(rng.integers(3, 500))
+        nh, nw = int(rng.integers(1, 150)), int(rng.integers(1, 300))
+        if i % 4 == 0:
+            nh = h
+        if i % 5 == 0:
+            nw = w
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img, "L").resize((nw, nh), Image.LANCZOS))
+        assert np.array_equal(P.lanczos_resize(img, nw, nh), ref), (h, w, nh, nw)
+        box = Image.fromarray(img, "L").getbbox()
+        assert P.getbbox(img) == box
+
+
+def test_native_plan_matches_oracle_sizes():
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    dims = [([128, 512], [32, 32]), ([448, 960], [32, 32]), ([64, 256], [32, 32]), ([800, 800], [32, 32])]
+    sizes = [(int(rng.integers(1, 1500)), int(rng.integers(1, 4000))) for _ in range(1500)]
+    sizes += [(256, 1024), (128, 512), (129, 512), (32, 32), (31, 33), (1, 1), (1, 5000), (3000, 2), (64, 64), (20, 50)]
+    for variant in ("demo", "api"):
+        for ds in ((None, 2, 3) if variant == "api" else (None,)):
+            for maxd, mind in dims:
+                cfg = _lib.D2TPrepConfig(max_h=maxd[0], max_w=maxd[1], min_h=mind[0], min_w=mind[1], downsample=ds or 0,
+                                         variant=_lib.PREP_API if variant == "api" else _lib.PREP_DEMO, mean=0.5, std=0.5)
+                for h, w in sizes:
+                    plan = _lib.D2TPrepPlan()
+                    assert lib.d2t_prep_plan_image(C.byref(cfg), h, w, C.byref(plan)) == 0
+                    # the oracle's control flow on sizes alone: a blank white page has a full bounding box
+                    dh, dw = h, w
+                    if ds and h / ds >= mind[0] and w / ds >= mind[1]:
+                        dh, dw = int(h / ds), int(w / ds)
+                    assert (plan.ds_h, plan.ds_w) == (dh, dw)
+                    try:
+                        oh, ow = _oracle_sizes(dh, dw, maxd, mind, variant)
+                        assert plan.status == _lib.PREP_OK and (plan.out_h, plan.out_w) == (oh, ow), (variant, h, w, maxd)
+                    except UnboundLocalError:
+                        assert plan.status == _lib.PREP_UNBOUND_LOCAL, (variant, h, w, maxd)
+                    except ValueError:
+                        assert plan.status == _lib.PREP_FALLBACK and (plan.out_h, plan.out_w) == tuple(maxd)
+
+
+def _oracle_sizes(h, w, maxd, mind, variant):
+    """minmax_size's size arithmetic without pixels (oracle functions only)."""
+    ratios = [h / maxd[0], w / maxd[1]]
+    if any(r > 1 for r in ratios):
+        size = np.array((w, h)) / max(ratios)
+        h, w = P.get_divisible_size(size[1], size[0], maxd, variant=variant)
+        if h <= 0 or w <= 0:
+            raise ValueError
+    ratios = [h / mind[0], w / mind[1]]
+    if any(r < 1 for r in ratios):
+        nh, nw = P.get_divisible_size(h / min(ratios), w / min(ratios), maxd, variant=variant)
+        if nh < h or nw < w:
+            raise ValueError
+        h, w = nh, nw
+    return h, w
+
+
+def test_native_lanczos_tables_equal_oracle():
+    lib = _lib.load()
+    for ins, outs in [(1400, 512), (300, 128), (50, 96), (7, 3), (2000, 512), (100, 100), (5, 64), (961, 960)]:
+        ks = C.c_int32()
+        assert lib.d2t_prep_lanczos_coeffs(ins, outs, C.byref(ks), None, None) == 0
+        bounds = np.zeros((outs, 2), np.int32)
+        kk = np.zeros((outs, ks.value), np.int32)
+        assert lib.d2t_prep_lanczos_coeffs(ins, outs, C.byref(ks), bounds.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           kk.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        oks, ob, okk = P.lanczos_coeffs(ins, outs)
+        assert ks.value == oks and np.array_equal(bounds, ob) and np.array_equal(kk, okk), (ins, outs)
+
+
+# ---- post-processing -------------------------------------------------------------------------------------------------
+def test_whitespace_pass_matches_reference_fixture():
+    from doc2tex_amd.postprocess import Postprocessing, demo_postprocess
+    for c in POST["strings"]:
+        assert Postprocessing.remove_unused_whitespace(c["s"]) == c["api"], repr(c["s"])
+        assert demo_postprocess(c["s"]) == c["demo"], repr(c["s"])
+
+
+def test_whitespace_pass_matches_python_re_live():
+    """The same patterns through Python's re on fresh random strings (the fixture covers the reference's own code)."""
+    import random
+    from doc2tex_amd.postprocess import Postprocessing
+    noletter, letter = r"[\W_^\d]", "[a-zA-Z]"
+
+    def fixed_point(s):
+        news = s
+        while True:
+            s = news
+            news = re.sub(r"(?!\\ )(%s)\s+?(%s)" % (noletter, noletter), r"\1\2", s)
+            news = re.sub(r"(?!\\ )(%s)\s+?(%s)" % (noletter, letter), r"\1\2", news)
+            news = re.sub(r"(%s)\s+?(%s)" % (letter, noletter), r"\1\2", news)
+            if news == s:
+                return s
+    rnd = random.Random(9)
+    alphabet = ["a", "Z", "1", "_", "^", "\\", " ", "\t", "{", "}", "é", "β", "٣", "²", " ", "+", "\\ "]
+    for _ in range(3000):
+        s = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 20)))
+        assert Postprocessing.remove_unused_whitespace(s) == fixed_point(s), repr(s)
+
+
+def test_decode_cut_and_cleanup_match_reference_fixture():
+    from doc2tex_amd.postprocess import LabelDecoder
+    dec = LabelDecoder(POST["vocab"], head="TFM")
+    for c in POST["decode"]:
+        ids = np.array(c["ids"], np.int64)
+        assert dec.decode(ids, c["token_level"]) == c["decode"]
+        assert dec.to_latex(ids, c["token_level"], postprocess=True) == c["latex_api"]
+        assert dec.to_latex(ids, c["token_level"], postprocess="demo") == c["latex_demo"]
+        assert dec.to_latex(ids, c["token_level"], postprocess=False) == c["latex_none"]
+    with pytest.raises(IndexError):
+        dec.decode(np.array([[10 ** 6]]))
+
+
+def test_preprocessor_fails_loudly_without_a_device():
+    import torch
+    from doc2tex_amd.preprocess import Preprocessor
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible")
+    opt = {"imgH": None, "imgW": None, "max_dimension": [128, 512], "min_dimension": [32, 32], "mean": 0.5, "std": 0.5,
+           "rgb": False, "pad": False}
+    with pytest.raises(RuntimeError):
+        Preprocessor(opt)
