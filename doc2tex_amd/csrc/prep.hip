@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/d2t.h"
@@ -204,6 +205,9 @@ __device__ __forceinline__ uint8_t clip8(int ss) {
 // cv2.resize(..., INTER_AREA): one thread per destination pixel (the footprint is a few source pixels).
 __global__ __launch_bounds__(256) void prep_area_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
                                                         uint8_t* __restrict__ work, const int32_t* __restrict__ tabs) {
+  // separate float32 multiplies and adds, as in the CPU code this restates: HIP's default would contract them into fused
+  // multiply-adds (the __fmul_rn / __fadd_rn wrappers of this ROCm inline to contractable operators too), which moves results that sit on a rounding tie
+#pragma clang fp contract(off)
   const PrepDesc d = descs[blockIdx.z];
   if (!d.do_ds) return;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void prep_area_kernel(const PrepDesc* __restri
     int sum = 0;
     for (int ky = 0; ky < d.ds_fy; ++ky)
       for (int kx = 0; kx < d.ds_fx; ++kx) sum += S[(size_t)(y * d.ds_fy + ky) * sw + x * d.ds_fx + kx];
-    v = __fmul_rn((float)sum, 1.f / (float)(d.ds_fx * d.ds_fy));
+    v = (float)sum * (1.f / (float)(d.ds_fx * d.ds_fy));
   } else {
     const int x0 = tabs[d.axb + 2 * x], nx = tabs[d.axb + 2 * x + 1];
     const int y0 = tabs[d.ayb + 2 * y], ny = tabs[d.ayb + 2 * y + 1];
@@ -230,43 +234,61 @@ __global__ __launch_bounds__(256) void prep_area_kernel(const PrepDesc* __restri
     v = 0.f;
     for (int ky = 0; ky < ny; ++ky) {
       float buf = 0.f;
-      for (int kx = 0; kx < nx; ++kx) buf = __fadd_rn(buf, __fmul_rn(ax[kx], (float)S[(size_t)(y0 + ky) * sw + x0 + kx]));
-      v = ky == 0 ? __fmul_rn(ay[0], buf) : __fadd_rn(v, __fmul_rn(ay[ky], buf));
+      for (int kx = 0; kx < nx; ++kx) buf = buf + ax[kx] * (float)S[(size_t)(y0 + ky) * sw + x0 + kx];
+      v = ky == 0 ? ay[0] * buf : v + ay[ky] * buf;
     }
   }
   int r = (int)rintf(v);  // saturate_cast<uchar>(float): round half to even, clamp
   D[(size_t)y * d.ds_w + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
 }
 
-// Horizontal LANCZOS pass: one block per source row; the row is staged in LDS once (4-byte loads over the aligned middle).
+// Horizontal LANCZOS pass: one block per R consecutive source rows, staged in LDS once (4-byte loads over the aligned
+// middle of each row).  A thread owns output columns and keeps R accumulators, so a coefficient (4 bytes, from L2) is
+// fetched once per R pixels (1 byte each, from LDS) -- with one row per block the table traffic was 4x the pixel traffic.
+template <int R>
 __global__ __launch_bounds__(256) void prep_hpass_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
-                                                         uint8_t* __restrict__ work, const int32_t* __restrict__ tabs) {
-  extern __shared__ uint8_t row[];
+                                                         uint8_t* __restrict__ work, const int32_t* __restrict__ tabs,
+                                                         int lds_stride) {
+  extern __shared__ uint8_t rows[];
   const PrepDesc d = descs[blockIdx.y];
-  const int y = blockIdx.x;
-  if (!d.do_h || y >= d.ds_h) return;
-  const uint8_t* in = (d.do_ds ? work + d.ds_off : src + d.src_off) + (size_t)y * d.ds_w;
+  const int y0 = blockIdx.x * R;
+  if (!d.do_h || y0 >= d.ds_h) return;
   const int w = d.ds_w;
-  const int head = min(w, (int)((4 - (reinterpret_cast<uintptr_t>(in) & 3)) & 3));
-  const int words = (w - head) >> 2;
-  // LDS byte i + pad holds source byte i, pad chosen so that the word part is 4-byte aligned in LDS as well
-  const int pad = (4 - head) & 3;
-  for (int i = threadIdx.x; i < head; i += 256) row[pad + i] = in[i];
-  const uint32_t* in4 = reinterpret_cast<const uint32_t*>(in + head);
-  uint32_t* row4 = reinterpret_cast<uint32_t*>(row + pad + head);
-  for (int i = threadIdx.x; i < words; i += 256) row4[i] = in4[i];
-  for (int i = head + 4 * words + threadIdx.x; i < w; i += 256) row[pad + i] = in[i];
+  const uint8_t* base = d.do_ds ? work + d.ds_off : src + d.src_off;
+  int pads[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    pads[r] = 0;
+    if (y0 + r >= d.ds_h) continue;
+    const uint8_t* in = base + (size_t)(y0 + r) * w;
+    uint8_t* row = rows + (size_t)r * lds_stride;
+    const int head = min(w, (int)((4 - (reinterpret_cast<uintptr_t>(in) & 3)) & 3));
+    const int words = (w - head) >> 2;
+    const int pad = (4 - head) & 3;  // LDS byte pad + i holds source byte i; pad + head is 4-byte aligned
+    pads[r] = pad;
+    for (int i = threadIdx.x; i < head; i += 256) row[pad + i] = in[i];
+    const uint32_t* in4 = reinterpret_cast<const uint32_t*>(in + head);
+    uint32_t* row4 = reinterpret_cast<uint32_t*>(row + pad + head);
+    for (int i = threadIdx.x; i < words; i += 256) row4[i] = in4[i];
+    for (int i = head + 4 * words + threadIdx.x; i < w; i += 256) row[pad + i] = in[i];
+  }
   __syncthreads();
   const int ow = d.rs_w;
-  uint8_t* out = work + d.hp_off + (size_t)y * ow;
   const int32_t* hb = tabs + d.hb;
   const int32_t* hk = tabs + d.hk;
   for (int xx = threadIdx.x; xx < ow; xx += 256) {
     const int xmin = hb[2 * xx], cnt = hb[2 * xx + 1];
-    int ss = 1 << (PRECISION_BITS - 1);
-    const uint8_t* r = row + pad + xmin;
-    for (int k = 0; k < cnt; ++k) ss += (int)r[k] * hk[(size_t)k * ow + xx];
-    out[xx] = clip8(ss);
+    int ss[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ss[r] = 1 << (PRECISION_BITS - 1);
+    for (int k = 0; k < cnt; ++k) {
+      const int c = hk[(size_t)k * ow + xx];
+#pragma unroll
+      for (int r = 0; r < R; ++r) ss[r] += (int)rows[(size_t)r * lds_stride + pads[r] + xmin + k] * c;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (y0 + r < d.ds_h) work[d.hp_off + (size_t)(y0 + r) * ow + xx] = clip8(ss[r]);
   }
 }
 
@@ -315,11 +337,22 @@ __global__ void prep_flags_kernel(const PrepDesc* __restrict__ descs, const int3
 
 }  // namespace
 
+struct TabKey {
+  int in, out, kind;
+  bool operator<(const TabKey& o) const { return in != o.in ? in < o.in : (out != o.out ? out < o.out : kind < o.kind); }
+  bool operator==(const TabKey& o) const { return in == o.in && out == o.out && kind == o.kind; }
+};
+struct DevTab {
+  int32_t b, k, ks;  // word offsets of bounds / coefficients in the arena, coefficients per output position
+};
+
 struct d2t_prep {
   d2t_prep_config cfg;
   std::string err;
   float* lut = nullptr;  // [256] normalisation table
-  std::map<std::pair<int, int>, AxisTab> lanczos, area;
+  std::map<TabKey, DevTab> dev_tabs;
+  int32_t* d_arena = nullptr;  // resident resampling tables
+  size_t arena_cap = 0, arena_used = 0;  // in int32 words
   // per-call staging: descriptors + tables in one pinned host block, mirrored on the device
   char* h_stage = nullptr;
   char* d_stage = nullptr;
@@ -348,16 +381,6 @@ int fail(d2t_prep* p, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(p, D2T_EHIP, "%s: %s", #expr, hipGetErrorString(e_));        \
   } while (0)
 
-const AxisTab& cached(std::map<std::pair<int, int>, AxisTab>& m, int in, int out, void (*build)(int, int, AxisTab&)) {
-  auto key = std::make_pair(in, out);
-  auto it = m.find(key);
-  if (it == m.end()) {
-    if (m.size() > 4096) m.clear();
-    it = m.emplace(key, AxisTab()).first;
-    build(in, out, it->second);
-  }
-  return it->second;
-}
 }  // namespace
 
 extern "C" {
@@ -417,6 +440,7 @@ void d2t_prep_destroy(d2t_prep* p) {
   if (p->d_stage) hipFree(p->d_stage);
   if (p->h_stage) hipHostFree(p->h_stage);
   if (p->d_work) hipFree(p->d_work);
+  if (p->d_arena) hipFree(p->d_arena);
   if (p->d_bits) hipFree(p->d_bits);
   if (p->staged) hipEventDestroy(p->staged);
   delete p;
@@ -434,15 +458,6 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
   const d2t_prep_config& c = p->cfg;
 
   // ---- validate the plans against the configuration (a plan must be what d2t_prep_plan_image would produce) -------
-  std::vector<PrepDesc> descs(n);
-  std::vector<int32_t> tabs;
-  auto add = [&](const std::vector<int32_t>& v) {
-    const int32_t off = (int32_t)tabs.size();
-    tabs.insert(tabs.end(), v.begin(), v.end());
-    return off;
-  };
-  size_t work = 0;
-  int max_ds_w = 1, max_ds_h = 1, max_rows_h = 0, any_min = 0, any_ds = 0, any_h = 0;
   for (int i = 0; i < n; ++i) {
     const d2t_prep_plan& pl = plans[i];
     d2t_prep_plan want;
@@ -457,68 +472,80 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
                   out_h, out_w);
     if (pl.min_branch && !flags_dev) return fail(p, D2T_EINVAL, "d2t_prep_run: plan %d needs flags_dev (paste check)", i);
     if (pl.ds_w > 65000) return fail(p, D2T_EINVAL, "d2t_prep_run: image %d is wider than 65000 pixels", i);
-    PrepDesc& d = descs[i];
-    memset(&d, 0, sizeof d);
-    d.src_off = src_offsets[i];
-    d.src_h = pl.src_h, d.src_w = pl.src_w, d.ds_h = pl.ds_h, d.ds_w = pl.ds_w, d.rs_h = pl.rs_h, d.rs_w = pl.rs_w;
-    d.fallback = pl.status == D2T_PREP_FALLBACK;
-    d.min_branch = pl.min_branch;
-    d.fill = d.fallback ? 1.0f : 0.f;  // non-fallback: lut[255], patched below on the host copy of the table
-    if (pl.ds_h != pl.src_h || pl.ds_w != pl.src_w) {
-      const double sx = (double)pl.src_w / pl.ds_w, sy = (double)pl.src_h / pl.ds_h;
-      if (sx == 2.0 && sy == 2.0) {
-        d.do_ds = 1;
-      } else if (sx == floor(sx) && sy == floor(sy)) {
-        d.do_ds = 2, d.ds_fx = (int)sx, d.ds_fy = (int)sy;
-      } else {
-        d.do_ds = 3;
-        const AxisTab& ax = cached(p->area, pl.src_w, pl.ds_w, build_area);
-        d.axb = add(ax.bounds), d.axk = add(ax.coef), d.axs = ax.ksize;
-        const AxisTab& ay = cached(p->area, pl.src_h, pl.ds_h, build_area);
-        d.ayb = add(ay.bounds), d.ayk = add(ay.coef), d.ays = ay.ksize;
-      }
-      d.ds_off = (int64_t)work;
-      work += ((size_t)pl.ds_h * pl.ds_w + 15) & ~(size_t)15;
-      any_ds = 1;
-      max_ds_w = std::max(max_ds_w, pl.ds_w), max_ds_h = std::max(max_ds_h, pl.ds_h);
-    }
-    if (!d.fallback && pl.rs_w != pl.ds_w) {  // ImagingResample: horizontal pass only when the width changes
-      d.do_h = 1;
-      const AxisTab& t = cached(p->lanczos, pl.ds_w, pl.rs_w, build_lanczos);
-      d.hb = add(t.bounds);
-      d.hks = t.ksize;
-      d.hk = (int32_t)tabs.size();
-      tabs.resize(tabs.size() + t.coef.size());
-      for (int xx = 0; xx < pl.rs_w; ++xx)
-        for (int k = 0; k < t.ksize; ++k) tabs[d.hk + (size_t)k * pl.rs_w + xx] = t.coef[(size_t)xx * t.ksize + k];
-      d.hp_off = (int64_t)work;
-      work += ((size_t)pl.ds_h * pl.rs_w + 15) & ~(size_t)15;
-      any_h = 1;
-      max_rows_h = std::max(max_rows_h, pl.ds_h);
-    }
-    if (!d.fallback && pl.rs_h != pl.ds_h) {
-      d.do_v = 1;
-      const AxisTab& t = cached(p->lanczos, pl.ds_h, pl.rs_h, build_lanczos);
-      d.vb = add(t.bounds), d.vk = add(t.coef), d.vks = t.ksize;
-    }
-    if (d.fallback) d.rs_h = std::min(pl.ds_h, out_h), d.rs_w = pl.ds_w;  // F.pad with a negative amount crops
-    any_min |= pl.min_branch;
-  }
-  // canvas colour 255 through the normalisation table
-  {
-    const float m = c.mean * 255.0f;
-    volatile float sd = c.std * 255.0f;
-    const float dnm = 1.0f / sd;
-    volatile float t = 255.0f - m;
-    const float fill = t * dnm;
-    for (auto& d : descs)
-      if (!d.fallback) d.fill = fill;
   }
 
-  // ---- stage descriptors + tables -----------------------------------------------------------------------------------
+  // ---- resampling tables: resident in a device arena, keyed by (in, out, kind); the ones this call needs and the arena
+  // does not hold yet are built on a few host threads (two libm sin() per LANCZOS tap, ~25 k per image = 0.3 ms on one
+  // core) and appended with one copy ------------------------------------------------------------------------------------
+  enum { K_VERT = 0, K_HORZ = 1, K_AREA = 2 };  // K_HORZ: coefficients transposed [k][out]
+  struct Miss {
+    TabKey key;
+    AxisTab t;
+  };
+  std::vector<Miss> miss;
+  auto need_tab = [&](int in, int out, int kind) {
+    TabKey key{in, out, kind};
+    if (p->dev_tabs.count(key)) return;
+    for (auto& m : miss)
+      if (m.key == key) return;
+    miss.push_back(Miss{key, AxisTab()});
+  };
+  auto collect = [&]() {
+    miss.clear();
+    for (int i = 0; i < n; ++i) {
+      const d2t_prep_plan& pl = plans[i];
+      if (pl.ds_h != pl.src_h || pl.ds_w != pl.src_w) {
+        const double sx = (double)pl.src_w / pl.ds_w, sy = (double)pl.src_h / pl.ds_h;
+        if (!(sx == floor(sx) && sy == floor(sy))) need_tab(pl.src_w, pl.ds_w, K_AREA), need_tab(pl.src_h, pl.ds_h, K_AREA);
+      }
+      if (pl.status != D2T_PREP_OK) continue;
+      if (pl.rs_w != pl.ds_w) need_tab(pl.ds_w, pl.rs_w, K_HORZ);
+      if (pl.rs_h != pl.ds_h) need_tab(pl.ds_h, pl.rs_h, K_VERT);
+    }
+  };
+  collect();
+  size_t new_words = 0;
+  for (auto& m : miss) {
+    const double scale = (double)m.key.in / m.key.out;
+    const int ks = m.key.kind == K_AREA ? (int)ceil(scale) + 2 : (int)ceil(3.0 * std::max(scale, 1.0)) * 2 + 1;
+    new_words += (size_t)m.key.out * (2 + ks);
+  }
+  if (p->arena_used + new_words > p->arena_cap) {  // start over (rare): everything queued so far must have finished
+    PHIP(p, hipStreamSynchronize(stream));
+    p->dev_tabs.clear();
+    p->arena_used = 0;
+    collect();
+    new_words = 0;
+    for (auto& m : miss) {
+      const double scale = (double)m.key.in / m.key.out;
+      const int ks = m.key.kind == K_AREA ? (int)ceil(scale) + 2 : (int)ceil(3.0 * std::max(scale, 1.0)) * 2 + 1;
+      new_words += (size_t)m.key.out * (2 + ks);
+    }
+    if (new_words > p->arena_cap) {
+      if (p->d_arena) PHIP(p, hipFree(p->d_arena));
+      p->d_arena = nullptr, p->arena_cap = 0;
+      const size_t cap = std::max<size_t>(new_words * 2, (size_t)16 << 20);  // >= 64 MB of int32
+      PHIP(p, hipMalloc((void**)&p->d_arena, cap * 4));
+      p->arena_cap = cap;
+    }
+  }
+  if (miss.size() > 1) {
+    const int nt = (int)std::min<size_t>(std::min<size_t>(miss.size(), 8), std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&, t] {
+        for (size_t k = t; k < miss.size(); k += nt)
+          (miss[k].key.kind == K_AREA ? build_area : build_lanczos)(miss[k].key.in, miss[k].key.out, miss[k].t);
+      });
+    for (auto& x : th) x.join();
+  } else if (miss.size() == 1) {
+    (miss[0].key.kind == K_AREA ? build_area : build_lanczos)(miss[0].key.in, miss[0].key.out, miss[0].t);
+  }
+
+  // ---- stage descriptors + new tables ---------------------------------------------------------------------------------
   const size_t desc_bytes = ((size_t)n * sizeof(PrepDesc) + 255) & ~(size_t)255;
-  const size_t need = desc_bytes + tabs.size() * 4 + 256;
-  if (p->staged_pending) {  // the previous call's copy out of the pinned block must have finished
+  const size_t need = desc_bytes + new_words * 4 + 256;
+  if (p->staged_pending) {  // the previous call's copies out of the pinned block must have finished
     PHIP(p, hipEventSynchronize(p->staged));
     p->staged_pending = false;
   }
@@ -532,6 +559,86 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     PHIP(p, hipMalloc((void**)&p->d_stage, cap));
     p->stage_cap = cap;
   }
+  {
+    int32_t* hw = reinterpret_cast<int32_t*>(p->h_stage + desc_bytes);
+    size_t at = 0;
+    for (auto& m : miss) {
+      const AxisTab& t = m.t;
+      DevTab dt;
+      dt.ks = t.ksize;
+      dt.b = (int32_t)(p->arena_used + at);
+      memcpy(hw + at, t.bounds.data(), t.bounds.size() * 4);
+      at += t.bounds.size();
+      dt.k = (int32_t)(p->arena_used + at);
+      if (m.key.kind == K_HORZ) {
+        const int ow = m.key.out;
+        for (int xx = 0; xx < ow; ++xx)
+          for (int k = 0; k < t.ksize; ++k) hw[at + (size_t)k * ow + xx] = t.coef[(size_t)xx * t.ksize + k];
+      } else {
+        memcpy(hw + at, t.coef.data(), t.coef.size() * 4);
+      }
+      at += t.coef.size();
+      p->dev_tabs.emplace(m.key, dt);
+    }
+    if (at != new_words) return fail(p, D2T_EINVAL, "d2t_prep_run: internal table size mismatch");
+  }
+
+  // ---- descriptors ----------------------------------------------------------------------------------------------------
+  PrepDesc* descs = reinterpret_cast<PrepDesc*>(p->h_stage);
+  float canvas;  // canvas colour 255 through the normalisation table
+  {
+    const float m = c.mean * 255.0f;
+    volatile float sd = c.std * 255.0f;
+    const float dnm = 1.0f / sd;
+    volatile float t = 255.0f - m;
+    canvas = t * dnm;
+  }
+  size_t work = 0;
+  int max_ds_w = 1, max_ds_h = 1, max_rows_h = 0, any_min = 0, any_ds = 0, any_h = 0;
+  for (int i = 0; i < n; ++i) {
+    const d2t_prep_plan& pl = plans[i];
+    PrepDesc& d = descs[i];
+    memset(&d, 0, sizeof d);
+    d.src_off = src_offsets[i];
+    d.src_h = pl.src_h, d.src_w = pl.src_w, d.ds_h = pl.ds_h, d.ds_w = pl.ds_w, d.rs_h = pl.rs_h, d.rs_w = pl.rs_w;
+    d.fallback = pl.status == D2T_PREP_FALLBACK;
+    d.min_branch = pl.min_branch;
+    d.fill = d.fallback ? 1.0f : canvas;
+    if (pl.ds_h != pl.src_h || pl.ds_w != pl.src_w) {
+      const double sx = (double)pl.src_w / pl.ds_w, sy = (double)pl.src_h / pl.ds_h;
+      if (sx == 2.0 && sy == 2.0) {
+        d.do_ds = 1;
+      } else if (sx == floor(sx) && sy == floor(sy)) {
+        d.do_ds = 2, d.ds_fx = (int)sx, d.ds_fy = (int)sy;
+      } else {
+        d.do_ds = 3;
+        const DevTab& ax = p->dev_tabs.at(TabKey{pl.src_w, pl.ds_w, K_AREA});
+        d.axb = ax.b, d.axk = ax.k, d.axs = ax.ks;
+        const DevTab& ay = p->dev_tabs.at(TabKey{pl.src_h, pl.ds_h, K_AREA});
+        d.ayb = ay.b, d.ayk = ay.k, d.ays = ay.ks;
+      }
+      d.ds_off = (int64_t)work;
+      work += ((size_t)pl.ds_h * pl.ds_w + 15) & ~(size_t)15;
+      any_ds = 1;
+      max_ds_w = std::max(max_ds_w, pl.ds_w), max_ds_h = std::max(max_ds_h, pl.ds_h);
+    }
+    if (!d.fallback && pl.rs_w != pl.ds_w) {  // ImagingResample: horizontal pass only when the width changes
+      d.do_h = 1;
+      const DevTab& t = p->dev_tabs.at(TabKey{pl.ds_w, pl.rs_w, K_HORZ});
+      d.hb = t.b, d.hk = t.k, d.hks = t.ks;
+      d.hp_off = (int64_t)work;
+      work += ((size_t)pl.ds_h * pl.rs_w + 15) & ~(size_t)15;
+      any_h = 1;
+      max_rows_h = std::max(max_rows_h, pl.ds_h);
+    }
+    if (!d.fallback && pl.rs_h != pl.ds_h) {
+      d.do_v = 1;
+      const DevTab& t = p->dev_tabs.at(TabKey{pl.ds_h, pl.rs_h, K_VERT});
+      d.vb = t.b, d.vk = t.k, d.vks = t.ks;
+    }
+    if (d.fallback) d.rs_h = std::min(pl.ds_h, out_h), d.rs_w = pl.ds_w;  // F.pad with a negative amount crops
+    any_min |= pl.min_branch;
+  }
   if (work > p->work_cap) {
     if (p->d_work) PHIP(p, hipFree(p->d_work));
     p->d_work = nullptr, p->work_cap = 0;
@@ -544,13 +651,14 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     PHIP(p, hipMalloc((void**)&p->d_bits, (size_t)n * 2 * 4));
     p->bits_cap = n * 2;
   }
-  memcpy(p->h_stage, descs.data(), (size_t)n * sizeof(PrepDesc));
-  if (!tabs.empty()) memcpy(p->h_stage + desc_bytes, tabs.data(), tabs.size() * 4);
-  PHIP(p, hipMemcpyAsync(p->d_stage, p->h_stage, need, hipMemcpyHostToDevice, stream));
+  PHIP(p, hipMemcpyAsync(p->d_stage, p->h_stage, (size_t)n * sizeof(PrepDesc), hipMemcpyHostToDevice, stream));
+  if (new_words)
+    PHIP(p, hipMemcpyAsync(p->d_arena + p->arena_used, p->h_stage + desc_bytes, new_words * 4, hipMemcpyHostToDevice, stream));
+  p->arena_used += new_words;
   PHIP(p, hipEventRecord(p->staged, stream));
   p->staged_pending = true;
   const PrepDesc* d_descs = reinterpret_cast<const PrepDesc*>(p->d_stage);
-  const int32_t* d_tabs = reinterpret_cast<const int32_t*>(p->d_stage + desc_bytes);
+  const int32_t* d_tabs = p->d_arena;
 
   // ---- launches -------------------------------------------------------------------------------------------------------
   if (any_ds)
@@ -560,8 +668,13 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     int max_in_w = 1;
     for (int i = 0; i < n; ++i)
       if (descs[i].do_h) max_in_w = std::max(max_in_w, descs[i].ds_w);
-    const size_t lds = ((size_t)max_in_w + 8 + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(prep_hpass_kernel, dim3(max_rows_h, n), dim3(256), lds, stream, d_descs, src_dev, p->d_work, d_tabs);
+    const int stride = (max_in_w + 8 + 15) & ~15;
+    if (stride * 8 <= 60 * 1024)
+      hipLaunchKernelGGL(prep_hpass_kernel<8>, dim3((max_rows_h + 7) / 8, n), dim3(256), (size_t)stride * 8, stream, d_descs,
+                         src_dev, p->d_work, d_tabs, stride);
+    else
+      hipLaunchKernelGGL(prep_hpass_kernel<1>, dim3(max_rows_h, n), dim3(256), (size_t)stride, stream, d_descs, src_dev,
+                         p->d_work, d_tabs, stride);
   }
   if (any_min) PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));
   hipLaunchKernelGGL(prep_finish_kernel, dim3((out_w + 255) / 256, out_h, n), dim3(256), 0, stream, d_descs, src_dev,

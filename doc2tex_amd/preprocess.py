@@ -95,12 +95,20 @@ class Preprocessor:
         for i, a in enumerate(arrays):
             offs[i] = total
             total += (a.size + 15) & ~15
-        host = torch.empty(total, dtype=torch.uint8).pin_memory()
-        hv = host.numpy()
-        for a, o in zip(arrays, offs):
-            hv[o:o + a.size] = a.reshape(-1)
         with torch.cuda.device(self.device):
-            src = host.to(self.device, non_blocking=True)
+            # two pinned staging blocks, alternating; a block is reused only after the copy out of it has finished
+            slot = self._slot = 1 - getattr(self, "_slot", 0)
+            stage = self._stage = getattr(self, "_stage", [None, None])
+            if stage[slot] is None or stage[slot][0].numel() < total:
+                stage[slot] = (torch.empty(max(total, 1 << 20) * 5 // 4, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+            else:
+                stage[slot][1].synchronize()
+            host, copied = stage[slot]
+            hv = host.numpy()
+            for a, o in zip(arrays, offs):
+                hv[o:o + a.size] = a.reshape(-1)
+            src = host[:total].to(self.device, non_blocking=True)
+            copied.record()
             out = torch.empty((n, 1, out_h, out_w), dtype=torch.float32, device=self.device)
             need_flags = any(p.min_branch for p in plans)
             flags = torch.empty(n, dtype=torch.int32, device=self.device) if need_flags else None
