@@ -353,16 +353,21 @@ struct d2t_prep {
   std::map<TabKey, DevTab> dev_tabs;
   int32_t* d_arena = nullptr;  // resident resampling tables
   size_t arena_cap = 0, arena_used = 0;  // in int32 words
-  // per-call staging: descriptors + tables in one pinned host block, mirrored on the device
-  char* h_stage = nullptr;
-  char* d_stage = nullptr;
-  size_t stage_cap = 0;
+  // per-call staging (descriptors + new tables): pinned host block + device mirror, NSTAGE sets used in rotation so that
+  // the host waits for a copy queued NSTAGE calls ago, not for the one just behind the work in flight
+  static constexpr int NSTAGE = 4;
+  struct Stage {
+    char* h = nullptr;
+    char* d = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  } stage[NSTAGE];
+  uint64_t calls = 0;
   uint8_t* d_work = nullptr;
   size_t work_cap = 0;
   int32_t* d_bits = nullptr;
   int bits_cap = 0;
-  hipEvent_t staged = nullptr;
-  bool staged_pending = false;
 };
 
 namespace {
@@ -429,20 +434,22 @@ int d2t_prep_create(const d2t_prep_config* cfg, d2t_prep** out) {
   host[257] = dnm;
   PHIP(p, hipMalloc(&p->lut, sizeof host));
   PHIP(p, hipMemcpy(p->lut, host, sizeof host, hipMemcpyHostToDevice));
-  PHIP(p, hipEventCreateWithFlags(&p->staged, hipEventDisableTiming));
+  for (auto& st : p->stage) PHIP(p, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
   return D2T_OK;
 }
 
 void d2t_prep_destroy(d2t_prep* p) {
   if (!p) return;
-  if (p->staged_pending) hipEventSynchronize(p->staged);
+  for (auto& st : p->stage) {
+    if (st.pending) hipEventSynchronize(st.done);
+    if (st.d) hipFree(st.d);
+    if (st.h) hipHostFree(st.h);
+    if (st.done) hipEventDestroy(st.done);
+  }
   if (p->lut) hipFree(p->lut);
-  if (p->d_stage) hipFree(p->d_stage);
-  if (p->h_stage) hipHostFree(p->h_stage);
   if (p->d_work) hipFree(p->d_work);
   if (p->d_arena) hipFree(p->d_arena);
   if (p->d_bits) hipFree(p->d_bits);
-  if (p->staged) hipEventDestroy(p->staged);
   delete p;
 }
 
@@ -545,22 +552,23 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
   // ---- stage descriptors + new tables ---------------------------------------------------------------------------------
   const size_t desc_bytes = ((size_t)n * sizeof(PrepDesc) + 255) & ~(size_t)255;
   const size_t need = desc_bytes + new_words * 4 + 256;
-  if (p->staged_pending) {  // the previous call's copies out of the pinned block must have finished
-    PHIP(p, hipEventSynchronize(p->staged));
-    p->staged_pending = false;
+  d2t_prep::Stage& st = p->stage[p->calls++ % d2t_prep::NSTAGE];
+  if (st.pending) {  // the copies out of this pinned block (queued NSTAGE calls ago) must have finished
+    PHIP(p, hipEventSynchronize(st.done));
+    st.pending = false;
   }
-  if (need > p->stage_cap) {
-    if (p->d_stage) PHIP(p, hipFree(p->d_stage));
-    if (p->h_stage) PHIP(p, hipHostFree(p->h_stage));
-    p->d_stage = p->h_stage = nullptr;
-    p->stage_cap = 0;
+  if (need > st.cap) {
+    if (st.d) PHIP(p, hipFree(st.d));
+    if (st.h) PHIP(p, hipHostFree(st.h));
+    st.d = st.h = nullptr;
+    st.cap = 0;
     const size_t cap = need * 2;
-    PHIP(p, hipHostMalloc((void**)&p->h_stage, cap, hipHostMallocDefault));
-    PHIP(p, hipMalloc((void**)&p->d_stage, cap));
-    p->stage_cap = cap;
+    PHIP(p, hipHostMalloc((void**)&st.h, cap, hipHostMallocDefault));
+    PHIP(p, hipMalloc((void**)&st.d, cap));
+    st.cap = cap;
   }
   {
-    int32_t* hw = reinterpret_cast<int32_t*>(p->h_stage + desc_bytes);
+    int32_t* hw = reinterpret_cast<int32_t*>(st.h + desc_bytes);
     size_t at = 0;
     for (auto& m : miss) {
       const AxisTab& t = m.t;
@@ -584,7 +592,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
   }
 
   // ---- descriptors ----------------------------------------------------------------------------------------------------
-  PrepDesc* descs = reinterpret_cast<PrepDesc*>(p->h_stage);
+  PrepDesc* descs = reinterpret_cast<PrepDesc*>(st.h);
   float canvas;  // canvas colour 255 through the normalisation table
   {
     const float m = c.mean * 255.0f;
@@ -651,13 +659,13 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     PHIP(p, hipMalloc((void**)&p->d_bits, (size_t)n * 2 * 4));
     p->bits_cap = n * 2;
   }
-  PHIP(p, hipMemcpyAsync(p->d_stage, p->h_stage, (size_t)n * sizeof(PrepDesc), hipMemcpyHostToDevice, stream));
+  PHIP(p, hipMemcpyAsync(st.d, st.h, (size_t)n * sizeof(PrepDesc), hipMemcpyHostToDevice, stream));
   if (new_words)
-    PHIP(p, hipMemcpyAsync(p->d_arena + p->arena_used, p->h_stage + desc_bytes, new_words * 4, hipMemcpyHostToDevice, stream));
+    PHIP(p, hipMemcpyAsync(p->d_arena + p->arena_used, st.h + desc_bytes, new_words * 4, hipMemcpyHostToDevice, stream));
   p->arena_used += new_words;
-  PHIP(p, hipEventRecord(p->staged, stream));
-  p->staged_pending = true;
-  const PrepDesc* d_descs = reinterpret_cast<const PrepDesc*>(p->d_stage);
+  PHIP(p, hipEventRecord(st.done, stream));
+  st.pending = true;
+  const PrepDesc* d_descs = reinterpret_cast<const PrepDesc*>(st.d);
   const int32_t* d_tabs = p->d_arena;
 
   // ---- launches -------------------------------------------------------------------------------------------------------

@@ -96,9 +96,13 @@ class Preprocessor:
             offs[i] = total
             total += (a.size + 15) & ~15
         with torch.cuda.device(self.device):
-            # two pinned staging blocks, alternating; a block is reused only after the copy out of it has finished
-            slot = self._slot = 1 - getattr(self, "_slot", 0)
-            stage = self._stage = getattr(self, "_stage", [None, None])
+            # Everything is queued on the caller's stream (a private stream was tried: its kernels cannot get block slots
+            # next to the persistent convolution and the host then waits a whole encoder for its staging memory).
+            # Pinned staging blocks rotate; a block is reused only after the copy out of it has finished, which with four
+            # blocks is a copy queued three batches ago -- the host does not wait behind the encoder in flight.
+            self._slot = (getattr(self, "_slot", -1) + 1) % 4
+            stage = self._stage = getattr(self, "_stage", [None] * 4)
+            slot = self._slot
             if stage[slot] is None or stage[slot][0].numel() < total:
                 stage[slot] = (torch.empty(max(total, 1 << 20) * 5 // 4, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
             else:
@@ -115,7 +119,6 @@ class Preprocessor:
             rc = self.lib.d2t_prep_run(self.h, n, (_lib.D2TPrepPlan * n)(*plans), _lib.ptr(src),
                                        offs.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(out), out_h, out_w,
                                        _lib.ptr(flags), _lib.stream_of(out))
-            src.record_stream(torch.cuda.current_stream(self.device))
         self._check(rc, "d2t_prep_run")
         return out, flags
 
