@@ -116,6 +116,13 @@ class Model(nn.Module):
         self.reserved_blocks = 64
         # pipelined mode: decode loops in flight side by side (1 or 2)
         self.decode_chains = 1
+        # pipelined mode: decode the rows of this many consecutive forward() calls in ONE step loop.  The decode step is a
+        # chain of small latency-bound kernels whose duration barely depends on the row count, so two batches per loop halve
+        # the launches (and the interference with the next encoders) per formula.  Rows are independent and every kernel is
+        # dispatched by layer shape only, so each row's tokens / logits are bit-identical to an ungrouped decode.  Results
+        # of a group become valid after synchronize() (which also launches a group that is still incomplete).
+        self.decode_group = 1
+        self._grp = None
         # 'bf16x3' (default) = split-bf16 convolutions / large GEMMs (3 bf16 MFMAs per product, fp32 accumulate: tokens
         # bit-exact, logits within 1e-3 on every fixture); 'fp32' = exact fp32 matrix-core arithmetic
         self.conv_precision = os.environ.get("D2T_CONV_PRECISION", "bf16x3")
@@ -132,9 +139,47 @@ class Model(nn.Module):
             return self.engine().decode_beam_batch(memory.contiguous(), beam)
         return self.engine().decode_attn_beam_batch(memory.contiguous(), beam)
 
+    def _group_decode(self, eng, memory, start):
+        """pipelined + decode_group > 1: collect the encoder memories of consecutive calls, launch one decode per group."""
+        import torch
+        G = int(self.decode_group)
+        B, T, d = memory.shape
+        S, V = eng.cfg.max_seq_len + 1, eng.cfg.vocab
+        key = (G, B, T, d, S, V, memory.device)
+        g = self._grp
+        if g is None or g["key"] != key:
+            self._flush_group(eng)
+            eng.decode_wait(host_sync=True)
+            ring = [dict(mem=torch.empty((G * B, T, d), dtype=torch.float32, device=memory.device),
+                         start=torch.zeros((G * B,), dtype=torch.int64, device=memory.device),
+                         tokens=torch.zeros((G * B, S), dtype=torch.int64, device=memory.device),
+                         logits=torch.zeros((G * B, S, V), dtype=torch.float32, device=memory.device)) for _ in range(4)]
+            g = self._grp = {"key": key, "ring": ring, "pos": 0, "n": 0}
+        buf = g["ring"][g["pos"] % len(g["ring"])]
+        k = g["n"]
+        buf["mem"][k * B:(k + 1) * B].copy_(memory)
+        buf["start"][k * B:(k + 1) * B].copy_(start.to(device=memory.device, dtype=torch.int64))
+        out = buf["tokens"][k * B:(k + 1) * B], buf["logits"][k * B:(k + 1) * B]
+        g["n"] += 1
+        if g["n"] == G:
+            self._flush_group(eng)
+        return out
+
+    def _flush_group(self, eng):
+        g = self._grp
+        if g is None or g["n"] == 0:
+            return
+        buf = g["ring"][g["pos"] % len(g["ring"])]
+        B = g["key"][1]
+        rows = g["n"] * B
+        eng.decode_greedy_async_into(buf["mem"][:rows], buf["start"][:rows], buf["tokens"][:rows], buf["logits"][:rows])
+        g["pos"] += 1
+        g["n"] = 0
+
     def synchronize(self, host_sync=True):
         """Order the current stream (and optionally the host) after every outstanding pipelined decode."""
         if self._engine is not None:
+            self._flush_group(self._engine)
             self._engine.decode_wait(host_sync=host_sync)
 
     # -- engine plumbing -----------------------------------------------------
@@ -193,7 +238,9 @@ class Model(nn.Module):
         else:
             if text.dim() != 2 or text.shape[1] != 1:
                 raise ValueError("eval decoding expects text = [B,1] start tokens ([GO])")
-            if self.pipelined and not is_test:
+            if self.pipelined and not is_test and int(self.decode_group) > 1:
+                prediction, logits = self._group_decode(eng, contextual_feature.contiguous(), text[:, 0])
+            elif self.pipelined and not is_test:
                 prediction, logits = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0])
             else:
                 prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)

@@ -289,6 +289,14 @@ class Engine:
         self._wait_dev = memory.device
         return tokens, logits
 
+    def decode_greedy_async_into(self, memory, start, tokens, logits):
+        """d2t_decode_greedy_async on caller-held buffers (which must stay untouched until decode_wait)."""
+        B, T, _ = memory.shape
+        self._check(self.lib.d2t_decode_greedy_async(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start),
+                                                     _lib.ptr(tokens), _lib.ptr(logits), _lib.stream_of(memory)),
+                    "decode_greedy_async")
+        self._wait_dev = memory.device
+
     def decode_wait(self, host_sync=False):
         dev = getattr(self, "_wait_dev", None)
         if dev is None:

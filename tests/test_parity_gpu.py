@@ -112,8 +112,9 @@ def test_headline_shape_properties(cases):
 
 
 def test_headline_shape_in_the_benchmarked_serving_mode(cases):
-    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, 64 reserved block slots: four batches in
-    flight give exactly the synchronous results, and the fixture rows stay exact."""
+    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of two batches, no reserved
+    block slots (and the earlier serving configuration: ungrouped, 64 reserved slots): four batches in flight give exactly
+    the synchronous results, and the fixture rows stay exact."""
     c = _case(cases, "greedy", "c2_greedy")
     z = np.load(os.path.join(GOLD, "c2_greedy.npz"))
     cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
@@ -127,14 +128,15 @@ def test_headline_shape_in_the_benchmarked_serving_mode(cases):
     with torch.no_grad():
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
-        m.pipelined, m.decode_chains, m.reserved_blocks = True, 2, 64
-        got = [m(x, text, is_train=False)[:2] for x in imgs]  # ring of four result buffers
-        m.synchronize()
-        torch.cuda.synchronize()
-    for (p, l), (rp, rl) in zip(got, ref):
-        assert torch.equal(p, rp) and torch.equal(l, rl)
-        assert np.array_equal(p[: c["B"]].cpu().numpy(), z["tokens"])
-    m.pipelined = False
+        for group, reserve in ((2, 0), (1, 64)):
+            m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, group, reserve
+            got = [m(x, text, is_train=False)[:2] for x in imgs]  # rings of four result buffers
+            m.synchronize()
+            torch.cuda.synchronize()
+            for (p, l), (rp, rl) in zip(got, ref):
+                assert torch.equal(p, rp) and torch.equal(l, rl)
+                assert np.array_equal(p[: c["B"]].cpu().numpy(), z["tokens"])
+    m.pipelined, m.decode_group = False, 1
 
 
 @pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish"])
@@ -264,6 +266,31 @@ def test_pipelined_decode_equals_synchronous(cases, chains, precision):
         assert torch.equal(p, rp) and torch.equal(l, rl)
     m.pipelined = False
     # a synchronous call right after pipelined ones still matches
+    with torch.no_grad():
+        p, l, _ = m(imgs[0], text, is_train=False)
+    assert torch.equal(p, ref[0][0]) and torch.equal(l, ref[0][1])
+
+
+@pytest.mark.parametrize("group", [2, 3])
+def test_grouped_pipelined_decode_equals_synchronous(cases, group):
+    """model.decode_group: the rows of `group` consecutive forwards share one decode step loop; every forward still
+    returns exactly its synchronous result (rows are independent, kernels are dispatched by layer shape only).  Seven
+    forwards: the last group is incomplete and is launched by synchronize()."""
+    c = _case(cases, "greedy", "t2_greedy")
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    imgs = [synth.synth_images(3, c["H"], c["W"], seed=950 + i).cuda() for i in range(7)]
+    text = torch.full((3, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        ref = [m(x, text, is_train=False) for x in imgs]
+        ref = [(p.clone(), l.clone()) for p, l, _ in ref]
+        m.pipelined, m.decode_chains, m.decode_group = True, 2, group
+        got = [m(x, text, is_train=False)[:2] for x in imgs]
+        m.synchronize()
+        torch.cuda.synchronize()
+    # ring of four group buffers: the results of the last three groups are certainly still resident
+    for (p, l), (rp, rl) in list(zip(got, ref))[-(2 * group + 1):]:
+        assert p.shape == rp.shape and torch.equal(p, rp) and torch.equal(l, rl)
+    m.pipelined, m.decode_group = False, 1
     with torch.no_grad():
         p, l, _ = m(imgs[0], text, is_train=False)
     assert torch.equal(p, ref[0][0]) and torch.equal(l, ref[0][1])
