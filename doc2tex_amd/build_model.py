@@ -176,10 +176,13 @@ class Model(nn.Module):
         g["pos"] += 1
         g["n"] = 0
 
-    def synchronize(self, host_sync=True):
-        """Order the current stream (and optionally the host) after every outstanding pipelined decode."""
+    def synchronize(self, host_sync=True, flush=True):
+        """Order the current stream (and optionally the host) after every outstanding pipelined decode.  `flush` also
+        launches a decode group that is still incomplete (decode_group > 1); a serving loop that only wants to order a
+        consumer stream after the groups already launched passes flush=False."""
         if self._engine is not None:
-            self._flush_group(self._engine)
+            if flush:
+                self._flush_group(self._engine)
             self._engine.decode_wait(host_sync=host_sync)
 
     # -- engine plumbing -----------------------------------------------------

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--group", type=int, default=2, help="decode groups (batches per decode step loop)")
     ap.add_argument("--page-sets", type=int, default=4, help="distinct batches of pages cycled through")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -37,7 +38,7 @@ def main():
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.eval().to(dev)
-    model.pipelined, model.decode_chains, model.reserved_blocks = True, 2, 64
+    model.pipelined, model.decode_chains, model.decode_group, model.reserved_blocks = True, 2, args.group, 0 if args.group > 1 else 64
     opt = {"imgH": None, "imgW": None, "max_dimension": cfg["max_dimension"], "min_dimension": [32, 32], "mean": 0.5,
            "std": 0.5, "rgb": False, "pad": False, "device": str(dev)}
     pre = Preprocessor(opt, "demo")
@@ -52,10 +53,18 @@ def main():
     side = torch.cuda.Stream(dev)
     L = cfg["Prediction"]["params"]["max_seq_len"] + 1
     ring = [torch.empty((B, L), dtype=torch.int64).pin_memory() for _ in range(8)]
-    pending, done, t_pre, t_post, sample = [], 0, 0.0, 0.0, None
+    pending, waiting, done, t_pre, t_post, sample = [], [], 0, 0.0, 0.0, None
 
     def consume(block):
         nonlocal done, t_post, sample
+        if block and waiting:  # an incomplete last group: launch it and copy its batches out
+            model.synchronize(host_sync=False)
+            for k, tk in waiting:
+                ring[k % len(ring)].copy_(tk, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.extend((k, ev) for k, _ in waiting)
+            waiting.clear()
         while pending and (block or pending[0][1].query()):
             k, ev = pending.pop(0)
             ev.synchronize()
@@ -83,13 +92,17 @@ def main():
         x = nxt["x"] if nxt["x"] is not None else prepare(i)
         with torch.no_grad():
             tokens, _, _ = model(x, text, is_train=False, is_test=False)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            model.synchronize(host_sync=False)  # the side stream waits for the decodes in flight, the main one does not
-            ring[i % len(ring)].copy_(tokens, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        pending.append((i, ev))
+        waiting.append((i, tokens))
+        if (i + 1) % args.group == 0:  # this call completed a decode group: its batches can be copied out behind it
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                model.synchronize(host_sync=False, flush=False)  # the side stream waits for the decodes in flight, the main one does not
+                for k, tk in waiting:
+                    ring[k % len(ring)].copy_(tk, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            pending.extend((k, ev) for k, _ in waiting)
+            waiting.clear()
         nxt["x"] = prepare(i + 1)
         consume(False)
 
