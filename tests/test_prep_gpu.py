@@ -100,6 +100,33 @@ def test_api_variant_downsample_matches_oracle():
         assert n_ok >= 4
 
 
+def test_very_wide_and_very_tall_pages():
+    """Widths beyond 7.6 k pixels take the one-row-per-block horizontal pass (eight rows no longer fit in LDS); a page
+    that is only resampled vertically skips the horizontal pass altogether (Pillow does the same)."""
+    pre = _pre(_opt((128, 512)), "demo")
+    for h, w, seed in ((40, 9000, 7100), (61, 20011, 7101), (3000, 96, 7102), (2500, 512, 7103), (128, 7000, 7104)):
+        img = synth.synth_formula_image(h, w, seed)
+        want = P.resize(img, _opt((128, 512)), variant="demo")
+        got = pre(img).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (h, w)
+
+
+def test_table_arena_survives_many_sizes():
+    """More distinct page sizes than one upload holds: tables are appended to the resident arena call after call and every
+    result stays exact (a stale or misplaced table would show up as wrong pixels)."""
+    pre = _pre(_opt((64, 256)), "demo")
+    rng = np.random.default_rng(11)
+    for rnd in range(6):
+        imgs = [synth.synth_formula_image(int(rng.integers(70, 400)), int(rng.integers(260, 1200)), 7200 + 40 * rnd + i)
+                for i in range(24)]
+        tensors, errors = pre.batch(imgs)
+        for img, t in zip(imgs[::5], tensors[::5]):
+            assert np.array_equal(t.cpu().numpy(), P.resize(img, _opt((64, 256)), variant="demo"))
+    again, _ = pre.batch(imgs)  # sizes seen before: served from the arena
+    for a, b in zip(again, tensors):
+        assert torch.equal(a, b)
+
+
 def test_unsupported_options_raise():
     from doc2tex_amd.preprocess import Preprocessor, resize
     with pytest.raises(NotImplementedError):
