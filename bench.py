@@ -230,7 +230,8 @@ def main():
     if model.pipelined:
         # capture every decode graph the timed region can need before anything is timed: a group that synchronize() finds
         # incomplete is decoded at its own row count, on either decode chain
-        for n in range(1, max(1, args.group) + 1):
+        # (largest group first: the engine's buffers only grow, so the addresses the smaller graphs capture stay valid)
+        for n in range(max(1, args.group), 0, -1):
             for _ in range(2 * max(1, args.chains)):
                 for _ in range(n):
                     step()

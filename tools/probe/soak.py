@@ -13,6 +13,7 @@ for it in range(120):
     img = synth.synth_images(B, H, W, seed=it).cuda()
     go = torch.full((B, 1), 1, dtype=torch.long, device="cuda")
     m.pipelined = (it // 6) % 2 == 1
+    m.decode_chains, m.decode_group, m.reserved_blocks = 2, 1 + (it // 12) % 3, (0 if (it // 12) % 3 else 64)
     with torch.no_grad():
         out = m(img, go, is_train=False, is_test=(it % 5 == 0 and not m.pipelined))
     if it % 6 == 5:
