@@ -93,6 +93,10 @@ SIGNATURES_PREP = {
     "d2t_prep_destroy": (None, [_P]),
     "d2t_prep_last_error": (C.c_char_p, [_P]),
     "d2t_prep_run": (_I, [_P, _I, C.POINTER(D2TPrepPlan), _P, C.POINTER(_L), _P, _I, _I, _P, _P]),
+    "d2t_prep_pad_hist": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), _P, _P]),
+    "d2t_prep_pad_bbox": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), _P, _P, _P]),
+    "d2t_prep_pad_apply": (_I, [_P, _I, _P, C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P, _I, _P,
+                                C.POINTER(_L), C.POINTER(_I), C.POINTER(_I), _P, _P]),
     "d2t_prep_lanczos_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "d2t_vocab_create": (_I, [C.POINTER(C.c_char_p), _I, C.POINTER(_P)]),
     "d2t_vocab_destroy": (None, [_P]),

@@ -335,6 +335,80 @@ __global__ void prep_flags_kernel(const PrepDesc* __restrict__ descs, const int3
   flags[i] = (descs[i].min_branch && (b & 1) && (b & 30) != 30) ? D2T_PREP_FLAG_PASTE_MISMATCH : 0;
 }
 
+
+// ---- pad() passes (data_utils.py:10-45) ------------------------------------------------------------------------------
+struct PadDesc {
+  int64_t src_off, dst_off;
+  int32_t h, w;              // source
+  int32_t a, b, cw, ch;      // crop rectangle
+  int32_t dh, dw;            // destination (multiples of 32)
+  int32_t background;
+};
+
+__global__ __launch_bounds__(256) void pad_hist_kernel(const PadDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                       int32_t* __restrict__ hist) {
+  __shared__ int32_t bins[256];
+  const PadDesc d = descs[blockIdx.y];
+  bins[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t npx = (size_t)d.h * d.w;
+  const uint8_t* S = src + d.src_off;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (size_t)gridDim.x * 256) atomicAdd(&bins[S[i]], 1);
+  __syncthreads();
+  if (bins[threadIdx.x]) atomicAdd(&hist[blockIdx.y * 256 + threadIdx.x], bins[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void pad_bbox_kernel(const PadDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                       const uint8_t* __restrict__ masks, int32_t* __restrict__ bbox) {
+  __shared__ uint8_t mk[256];
+  __shared__ int32_t red[4];
+  const PadDesc d = descs[blockIdx.y];
+  mk[threadIdx.x] = masks[blockIdx.y * 256 + threadIdx.x];
+  if (threadIdx.x < 4) red[threadIdx.x] = threadIdx.x < 2 ? 0x7fffffff : -1;
+  __syncthreads();
+  const uint8_t* S = src + d.src_off;
+  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+  for (int y = blockIdx.x; y < d.h; y += gridDim.x)
+    for (int x = threadIdx.x; x < d.w; x += 256)
+      if (mk[S[(size_t)y * d.w + x]]) {
+        x0 = min(x0, x), x1 = max(x1, x), y0 = min(y0, y), y1 = max(y1, y);
+      }
+  if (x1 >= 0) {
+    atomicMin(&red[0], x0), atomicMin(&red[1], y0), atomicMax(&red[2], x1), atomicMax(&red[3], y1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && red[2] >= 0) {
+    int32_t* o = bbox + blockIdx.y * 4;
+    atomicMin(&o[0], red[0]), atomicMin(&o[1], red[1]), atomicMax(&o[2], red[2]), atomicMax(&o[3], red[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void pad_apply_kernel(const PadDesc* __restrict__ descs, const uint8_t* __restrict__ src,
+                                                        const uint8_t* __restrict__ luts, uint8_t* __restrict__ dst,
+                                                        int32_t* __restrict__ bits) {
+  __shared__ uint8_t lut[256];
+  const PadDesc d = descs[blockIdx.z];
+  lut[threadIdx.x] = luts[blockIdx.z * 256 + threadIdx.x];
+  __syncthreads();
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  int mybits = 0;
+  if (y < d.dh && x < d.dw) {
+    int v = d.background;
+    if (y < d.ch && x < d.cw) {
+      v = lut[src[d.src_off + (size_t)(d.b + y) * d.w + d.a + x]];
+      if (v) mybits = 1 | (y == 0 ? 2 : 0) | (y == d.ch - 1 ? 4 : 0) | (x == 0 ? 8 : 0) | (x == d.cw - 1 ? 16 : 0);
+    }
+    dst[d.dst_off + (size_t)y * d.dw + x] = (uint8_t)v;
+  }
+  for (int s = 32; s; s >>= 1) mybits |= __shfl_xor(mybits, s);
+  if ((threadIdx.x & 63) == 0 && mybits) atomicOr(&bits[blockIdx.z], mybits);
+}
+
+__global__ void pad_flags_kernel(const int32_t* __restrict__ bits, int32_t* __restrict__ flags, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = ((bits[i] & 1) && (bits[i] & 30) != 30) ? D2T_PREP_FLAG_PASTE_MISMATCH : 0;
+}
+
 }  // namespace
 
 struct TabKey {
@@ -368,6 +442,8 @@ struct d2t_prep {
   size_t work_cap = 0;
   int32_t* d_bits = nullptr;
   int bits_cap = 0;
+  char* d_pad = nullptr;  // pad() passes: descriptors + per-image 256-entry tables
+  size_t pad_cap = 0;
 };
 
 namespace {
@@ -450,6 +526,7 @@ void d2t_prep_destroy(d2t_prep* p) {
   if (p->d_work) hipFree(p->d_work);
   if (p->d_arena) hipFree(p->d_arena);
   if (p->d_bits) hipFree(p->d_bits);
+  if (p->d_pad) hipFree(p->d_pad);
   delete p;
 }
 
@@ -692,6 +769,118 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     hipLaunchKernelGGL(prep_flags_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_descs, (const int32_t*)p->d_bits,
                        flags_dev, n);
   }
+  PHIP(p, hipGetLastError());
+  return D2T_OK;
+}
+
+// ---- pad() entry points: descriptors / tables go through a small synchronous upload (these calls are followed by a
+// device-to-host read of their result anyway) --------------------------------------------------------------------------
+namespace {
+int pad_upload(d2t_prep* p, const std::vector<PadDesc>& descs, const uint8_t* tab_host, int n, PadDesc** d_descs,
+               uint8_t** d_tab, hipStream_t stream) {
+  const size_t db = ((size_t)n * sizeof(PadDesc) + 255) & ~(size_t)255, tb = tab_host ? (size_t)n * 256 : 0;
+  if (db + tb > p->pad_cap) {
+    if (p->d_pad) PHIP(p, hipFree(p->d_pad));
+    p->d_pad = nullptr, p->pad_cap = 0;
+    PHIP(p, hipMalloc((void**)&p->d_pad, (db + tb) * 2));
+    p->pad_cap = (db + tb) * 2;
+  }
+  // pageable source: the copy is staged by the runtime before the call returns
+  PHIP(p, hipMemcpyAsync(p->d_pad, descs.data(), (size_t)n * sizeof(PadDesc), hipMemcpyHostToDevice, stream));
+  if (tab_host) PHIP(p, hipMemcpyAsync(p->d_pad + db, tab_host, tb, hipMemcpyHostToDevice, stream));
+  PHIP(p, hipStreamSynchronize(stream));
+  *d_descs = reinterpret_cast<PadDesc*>(p->d_pad);
+  if (d_tab) *d_tab = reinterpret_cast<uint8_t*>(p->d_pad + db);
+  return D2T_OK;
+}
+int pad_common(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* offs, const int32_t* hs, const int32_t* ws,
+               std::vector<PadDesc>& descs, int* max_h, int* max_w) {
+  if (!p) return D2T_EINVAL;
+  if (n <= 0 || !src_dev || !offs || !hs || !ws) return fail(p, D2T_EINVAL, "pad: bad argument");
+  if (!p->lut) return fail(p, D2T_ESTATE, "pad: handle was not created on a HIP device");
+  descs.assign(n, PadDesc());
+  *max_h = *max_w = 1;
+  for (int i = 0; i < n; ++i) {
+    if (hs[i] <= 0 || ws[i] <= 0) return fail(p, D2T_EINVAL, "pad: image %d has size %dx%d", i, hs[i], ws[i]);
+    memset(&descs[i], 0, sizeof(PadDesc));
+    descs[i].src_off = offs[i], descs[i].h = hs[i], descs[i].w = ws[i];
+    *max_h = std::max(*max_h, hs[i]), *max_w = std::max(*max_w, ws[i]);
+  }
+  return D2T_OK;
+}
+}  // namespace
+
+int d2t_prep_pad_hist(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                      const int32_t* src_w, int32_t* hist_dev, void* stream_) {
+  std::vector<PadDesc> descs;
+  int mh, mw;
+  int rc = pad_common(p, n, src_dev, src_offsets, src_h, src_w, descs, &mh, &mw);
+  if (rc) return rc;
+  if (!hist_dev) return fail(p, D2T_EINVAL, "pad: hist_dev is null");
+  hipStream_t stream = (hipStream_t)stream_;
+  PadDesc* dd;
+  if ((rc = pad_upload(p, descs, nullptr, n, &dd, nullptr, stream))) return rc;
+  PHIP(p, hipMemsetAsync(hist_dev, 0, (size_t)n * 256 * 4, stream));
+  const int bx = (int)std::min<size_t>(256, ((size_t)mh * mw + 65535) / 65536 + 1);
+  hipLaunchKernelGGL(pad_hist_kernel, dim3(bx, n), dim3(256), 0, stream, (const PadDesc*)dd, src_dev, hist_dev);
+  PHIP(p, hipGetLastError());
+  return D2T_OK;
+}
+
+int d2t_prep_pad_bbox(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                      const int32_t* src_w, const uint8_t* mask_host, int32_t* bbox_dev, void* stream_) {
+  std::vector<PadDesc> descs;
+  int mh, mw;
+  int rc = pad_common(p, n, src_dev, src_offsets, src_h, src_w, descs, &mh, &mw);
+  if (rc) return rc;
+  if (!mask_host || !bbox_dev) return fail(p, D2T_EINVAL, "pad: mask / bbox is null");
+  hipStream_t stream = (hipStream_t)stream_;
+  PadDesc* dd;
+  uint8_t* dm;
+  if ((rc = pad_upload(p, descs, mask_host, n, &dd, &dm, stream))) return rc;
+  std::vector<int32_t> init((size_t)n * 4);
+  for (int i = 0; i < n; ++i) init[4 * i] = init[4 * i + 1] = 0x7fffffff, init[4 * i + 2] = init[4 * i + 3] = -1;
+  PHIP(p, hipMemcpyAsync(bbox_dev, init.data(), init.size() * 4, hipMemcpyHostToDevice, stream));
+  PHIP(p, hipStreamSynchronize(stream));
+  hipLaunchKernelGGL(pad_bbox_kernel, dim3(std::min(mh, 128), n), dim3(256), 0, stream, (const PadDesc*)dd, src_dev,
+                     (const uint8_t*)dm, bbox_dev);
+  PHIP(p, hipGetLastError());
+  return D2T_OK;
+}
+
+int d2t_prep_pad_apply(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                       const int32_t* src_w, const int32_t* rects, const uint8_t* lut_host, int32_t background,
+                       uint8_t* dst_dev, const int64_t* dst_offsets, const int32_t* dst_h, const int32_t* dst_w,
+                       int32_t* flags_dev, void* stream_) {
+  std::vector<PadDesc> descs;
+  int mh, mw;
+  int rc = pad_common(p, n, src_dev, src_offsets, src_h, src_w, descs, &mh, &mw);
+  if (rc) return rc;
+  if (!rects || !lut_host || !dst_dev || !dst_offsets || !dst_h || !dst_w || !flags_dev || background < 0 || background > 255)
+    return fail(p, D2T_EINVAL, "pad_apply: bad argument");
+  int odh = 1, odw = 1;
+  for (int i = 0; i < n; ++i) {
+    PadDesc& d = descs[i];
+    d.a = rects[4 * i], d.b = rects[4 * i + 1], d.cw = rects[4 * i + 2], d.ch = rects[4 * i + 3];
+    d.dh = dst_h[i], d.dw = dst_w[i], d.dst_off = dst_offsets[i], d.background = background;
+    if (d.a < 0 || d.b < 0 || d.cw <= 0 || d.ch <= 0 || d.a + d.cw > d.w || d.b + d.ch > d.h || d.dh < d.ch || d.dw < d.cw)
+      return fail(p, D2T_EINVAL, "pad_apply: rectangle %d is outside its image or larger than its destination", i);
+    odh = std::max(odh, d.dh), odw = std::max(odw, d.dw);
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  PadDesc* dd;
+  uint8_t* dl;
+  if ((rc = pad_upload(p, descs, lut_host, n, &dd, &dl, stream))) return rc;
+  if (n > p->bits_cap) {
+    if (p->d_bits) PHIP(p, hipFree(p->d_bits));
+    p->d_bits = nullptr, p->bits_cap = 0;
+    PHIP(p, hipMalloc((void**)&p->d_bits, (size_t)n * 2 * 4));
+    p->bits_cap = n * 2;
+  }
+  PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));
+  hipLaunchKernelGGL(pad_apply_kernel, dim3((odw + 255) / 256, odh, n), dim3(256), 0, stream, (const PadDesc*)dd, src_dev,
+                     (const uint8_t*)dl, dst_dev, p->d_bits);
+  hipLaunchKernelGGL(pad_flags_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, (const int32_t*)p->d_bits, flags_dev, n);
   PHIP(p, hipGetLastError());
   return D2T_OK;
 }

@@ -3,7 +3,8 @@
 Host-side mirror of the reference's `resize()` -- `doc2tex/utils/predict_utils.py:14-115` (what `api/infer.py:62`
 calls with an image path; variant "api") and `demo/HybridViT/helper.py:134-207` (what `demo/HybridViT/recog_flow.py:81`
 calls with a PIL image; variant "demo") -- for the configuration the shipped YAMLs use: `imgH: null`, no learned
-resizer, `pad: False`, grayscale.  Same argument meaning, same return value (a float32 `[1,1,H,W]` tensor, here on the
+resizer, grayscale; `pad: True` (contrast-normalise, crop to the text's bounding rectangle, extend to multiples of 32:
+`utils/data_utils.py:10-45`) is supported too.  Same argument meaning, same return value (a float32 `[1,1,H,W]` tensor, here on the
 GPU), same exceptions.  All pixel work runs in `libd2t.so` (`d2t_prep_run`, include/d2t_prep.h): there is no CPU path.
 
 The two reference copies differ in `get_divisible_size`: the "api" copy (`utils/data_utils.py:48-60`) leaves its result
@@ -43,8 +44,7 @@ class Preprocessor:
             raise NotImplementedError("doc2tex_amd.preprocess: only the `imgH: null` branch (the shipped configs) is built")
         if opt.get("rgb", False):
             raise NotImplementedError("doc2tex_amd.preprocess: grayscale only (rgb: False in every shipped config)")
-        if opt.get("pad", False):
-            raise NotImplementedError("doc2tex_amd.preprocess: `pad: True` (cv2 bounding-box crop) is not built")
+        self.pad = bool(opt.get("pad", False))
         if opt.get("use_resizer", False):
             raise NotImplementedError("doc2tex_amd.preprocess: the learned resizer loop is not on this path")
         if variant not in ("demo", "api"):
@@ -52,6 +52,8 @@ class Preprocessor:
         ds = opt.get("downsample", None) if variant == "api" else None
         if ds is not None and (int(ds) != ds or ds < 1):
             raise NotImplementedError("doc2tex_amd.preprocess: integer `downsample` ratios only")
+        if self.pad and ds:
+            raise NotImplementedError("doc2tex_amd.preprocess: `pad: True` together with `downsample` is not built")
         self.variant = variant
         self.lib = _lib.require_device()
         self.device = torch.device(device if device is not None else opt.get("device", "cuda"))
@@ -86,8 +88,8 @@ class Preprocessor:
             raise ValueError(f"bad image size {h}x{w}")
         return p
 
-    def _run(self, arrays, plans, out_h, out_w):
-        """One d2t_prep_run: arrays[i] with plans[i] -> ([n,1,H,W] float32 on the device, flags tensor or None)."""
+    def _upload(self, arrays):
+        """Pack the pixels of `arrays` into one device buffer: (uint8 tensor, int64 offsets)."""
         import torch
         n = len(arrays)
         offs = np.zeros(n, np.int64)
@@ -113,6 +115,14 @@ class Preprocessor:
                 hv[o:o + a.size] = a.reshape(-1)
             src = host[:total].to(self.device, non_blocking=True)
             copied.record()
+        return src, offs
+
+    def _run(self, src, offs, plans, out_h, out_w):
+        """One d2t_prep_run over device-resident sources -> ([n,1,H,W] float32 on the device, flags tensor or None)."""
+        import torch
+        n = len(plans)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        with torch.cuda.device(self.device):
             out = torch.empty((n, 1, out_h, out_w), dtype=torch.float32, device=self.device)
             need_flags = any(p.min_branch for p in plans)
             flags = torch.empty(n, dtype=torch.int32, device=self.device) if need_flags else None
@@ -122,14 +132,96 @@ class Preprocessor:
         self._check(rc, "d2t_prep_run")
         return out, flags
 
+    def _pad(self, arrays, src, offs):
+        """pad() of every image on the device (data_utils.py:10-45).  -> (padded uint8 buffer, offsets, [(h, w)], errors):
+        errors[i] is None, a ValueError (the reference's paste raised: resize() takes its except branch) or the exception
+        that propagates out of the reference."""
+        import torch
+        n = len(arrays)
+        I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        hs = np.array([a.shape[0] for a in arrays], np.int32)
+        ws = np.array([a.shape[1] for a in arrays], np.int32)
+        st = _lib.stream_of(src)
+        common = (self.h, n, _lib.ptr(src), offs.ctypes.data_as(I64), hs.ctypes.data_as(I32), ws.ctypes.data_as(I32))
+        with torch.cuda.device(self.device):
+            hist = torch.empty((n, 256), dtype=torch.int32, device=self.device)
+            self._check(self.lib.d2t_prep_pad_hist(*common, _lib.ptr(hist), st), "d2t_prep_pad_hist")
+            hist = hist.cpu().numpy().astype(np.int64)
+            # the reference's float64 arithmetic, per pixel VALUE instead of per pixel (data_utils.py:20-29)
+            masks = np.zeros((n, 256), np.uint8)
+            luts = np.zeros((n, 256), np.uint8)
+            errors = [None] * n
+            v = np.arange(256, dtype=np.uint8)
+            for i in range(n):
+                present = np.nonzero(hist[i])[0]
+                mn, mx = np.uint8(min(int(present[0]), 255)), np.uint8(255)  # the alpha plane of "LA" is 255 everywhere
+                if mx == mn:  # division by zero -> nan -> no text pixels -> cv2.boundingRect(None) fails in the reference
+                    errors[i] = RuntimeError("pad(): blank image (cv2.boundingRect of no points)")
+                    continue
+                f = (v - mn) / (mx - mn) * 255  # uint8 subtraction, float64 division: as numpy evaluates the reference line
+                mean = float((hist[i] * f)[present].sum() / hist[i].sum())
+                if mean > 128:
+                    masks[i], g = f < 128, f
+                else:
+                    masks[i], g = f > 128, 255 - f
+                luts[i, present] = g[present].astype(np.uint8)
+            bbox = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+            self._check(self.lib.d2t_prep_pad_bbox(*common, masks.ctypes.data_as(C.c_void_p), _lib.ptr(bbox), st),
+                        "d2t_prep_pad_bbox")
+            bbox = bbox.cpu().numpy()
+            rects = np.zeros((n, 4), np.int32)
+            dh, dw = np.zeros(n, np.int32), np.zeros(n, np.int32)
+            doffs = np.zeros(n, np.int64)
+            total = 0
+            for i in range(n):
+                x0, y0, x1, y1 = (int(t) for t in bbox[i])
+                if errors[i] is None and x1 < x0:
+                    errors[i] = RuntimeError("pad(): no text pixels (cv2.boundingRect of no points)")
+                if errors[i] is not None:
+                    rects[i] = (0, 0, 1, 1)
+                    dh[i] = dw[i] = 32
+                else:
+                    w, h = x1 - x0 + 1, y1 - y0 + 1
+                    rects[i] = (x0, y0, w, h)
+                    dw[i], dh[i] = -(-w // 32) * 32, -(-h // 32) * 32
+                doffs[i] = total
+                total += (int(dh[i]) * int(dw[i]) + 15) & ~15
+            dst = torch.empty(total, dtype=torch.uint8, device=self.device)
+            flags = torch.empty(n, dtype=torch.int32, device=self.device)
+            background = 255 if self.variant == "demo" else 0  # helper.py:89 / data_utils.py:43
+            self._check(self.lib.d2t_prep_pad_apply(*common, rects.ctypes.data_as(I32), luts.ctypes.data_as(C.c_void_p),
+                                                    background, _lib.ptr(dst), doffs.ctypes.data_as(I64),
+                                                    dh.ctypes.data_as(I32), dw.ctypes.data_as(I32), _lib.ptr(flags), st),
+                        "d2t_prep_pad_apply")
+            fl = flags.cpu().numpy()
+        for i in range(n):
+            if errors[i] is None and fl[i] & _lib.PREP_FLAG_PASTE_MISMATCH:
+                errors[i] = ValueError("images do not match")  # padded.paste(im, im.getbbox()), data_utils.py:44
+        return dst, doffs, [(int(dh[i]), int(dw[i])) for i in range(n)], errors
+
     def batch(self, images):
         """images: paths / PIL images / uint8 [h,w] arrays -> (tensors, errors): tensors[i] is image i's [1,1,H,W] result
         (a view into the [n,1,H,W] batch of its size bucket; `tensors[i]._base` is the bucket), errors[i] the exception
         instance the reference's resize() raises for image i (tensors[i] is None then)."""
         arrays = [_as_gray_array(im) for im in images]
-        plans = [self.plan(*a.shape) for a in arrays]
-        tensors, errors = [None] * len(arrays), [None] * len(arrays)
-        pending = list(range(len(arrays)))
+        n = len(arrays)
+        tensors, errors = [None] * n, [None] * n
+        src, offs = self._upload(arrays)
+        # per image: which device buffer holds its current source, at which offset and size (pad() replaces the source)
+        cur = [(src, int(offs[i]), arrays[i].shape) for i in range(n)]
+        fallback = [False] * n
+        if self.pad:
+            psrc, poffs, psizes, perr = self._pad(arrays, src, offs)
+            for i in range(n):
+                if perr[i] is None:
+                    cur[i] = (psrc, int(poffs[i]), psizes[i])
+                elif isinstance(perr[i], ValueError):  # caught by resize()'s `except ValueError` (predict_utils.py:85)
+                    print("Error:", perr[i])
+                    fallback[i] = True
+                else:
+                    errors[i] = perr[i]
+        plans = [None if errors[i] is not None else self.plan(*cur[i][2], fallback=fallback[i]) for i in range(n)]
+        pending = [i for i in range(n) if errors[i] is None]
         for attempt in range(2):
             buckets = {}
             for i in pending:
@@ -141,10 +233,10 @@ class Preprocessor:
                     # predict_utils.py:87-88: the grayscale array is 2-D, the assert on its shape fails
                     errors[i] = AssertionError()
                 else:
-                    buckets.setdefault((p.out_h, p.out_w), []).append(i)
+                    buckets.setdefault((p.out_h, p.out_w, cur[i][0].data_ptr()), []).append(i)
             redo = []
-            for (oh, ow), idx in buckets.items():
-                out, flags = self._run([arrays[i] for i in idx], [plans[i] for i in idx], oh, ow)
+            for (oh, ow, _), idx in buckets.items():
+                out, flags = self._run(cur[idx[0]][0], [cur[i][1] for i in idx], [plans[i] for i in idx], oh, ow)
                 bad = set()
                 if flags is not None:  # only tiny images pasted on the min_dimension canvas get here
                     fl = flags.cpu().numpy()
@@ -152,10 +244,13 @@ class Preprocessor:
                 for k, i in enumerate(idx):
                     if k in bad:  # `padded_im.paste(img, img.getbbox())` raised ValueError -> the except branch
                         print("Error:", "images do not match")
-                        plans[i] = self.plan(*arrays[i].shape, fallback=True)
+                        fallback[i] = True
                         redo.append(i)
                     else:
                         tensors[i] = out[k:k + 1]
+            for i in redo:  # the except branch works on the ORIGINAL image (predict_utils.py:87)
+                cur[i] = (src, int(offs[i]), arrays[i].shape)
+                plans[i] = self.plan(*arrays[i].shape, fallback=True)
             pending = redo
             if not pending:
                 break

@@ -93,6 +93,29 @@ const char* d2t_prep_last_error(const d2t_prep* p);
 int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* src_dev, const int64_t* src_offsets,
                  float* out_dev, int out_h, int out_w, int32_t* flags_dev, void* stream);
 
+/*
+ * pad() (doc2tex/utils/data_utils.py:10-45 == demo/HybridViT/helper.py:52-92; `pad: True`): contrast-normalise, find the
+ * bounding rectangle of the text pixels, crop to it and extend to multiples of 32.  The rectangle -- and with it every size
+ * downstream -- depends on the pixels, so the work is split into three device passes with the (tiny, 256-entry) float64
+ * table arithmetic between them on the host, where the reference does it:
+ *   d2t_prep_pad_hist    per-image histogram of the uint8 pixels                       -> hist_dev [n][256] int32
+ *   d2t_prep_pad_bbox    bounding rectangle of the pixels whose value is marked in mask -> bbox_dev [n][4] int32
+ *                        (x0, y0, x1, y1 inclusive; x0 > x1 when no pixel is marked: cv2.boundingRect(None) fails)
+ *   d2t_prep_pad_apply   dst = zero/`background`-extended crop of lut[src]             -> uint8 images + flags_dev [n]
+ *                        (flags bit 0: the crop's non-zero bounding box is not the whole crop, i.e. the reference's
+ *                         `padded.paste(im, im.getbbox())` raises ValueError)
+ * mask_host / lut_host: [n][256] uint8 on the host.  rects [n][4] = (a, b, w, h) of the crop; dst image i has
+ * dst_h[i] x dst_w[i] pixels at dst_dev + dst_offsets[i] and is then an ordinary source image for d2t_prep_run.
+ */
+int d2t_prep_pad_hist(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                      const int32_t* src_w, int32_t* hist_dev, void* stream);
+int d2t_prep_pad_bbox(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                      const int32_t* src_w, const uint8_t* mask_host, int32_t* bbox_dev, void* stream);
+int d2t_prep_pad_apply(d2t_prep* p, int n, const uint8_t* src_dev, const int64_t* src_offsets, const int32_t* src_h,
+                       const int32_t* src_w, const int32_t* rects, const uint8_t* lut_host, int32_t background,
+                       uint8_t* dst_dev, const int64_t* dst_offsets, const int32_t* dst_h, const int32_t* dst_w,
+                       int32_t* flags_dev, void* stream);
+
 /* Test hook: Pillow's integer LANCZOS coefficient table for one axis (host only).  ksize_out = coefficients per output
  * position; bounds[2*i] = first source index, bounds[2*i+1] = count; kk[i*ksize + k].  kk may be NULL to query ksize. */
 int d2t_prep_lanczos_coeffs(int in_size, int out_size, int32_t* ksize_out, int32_t* bounds, int32_t* kk);

@@ -174,6 +174,37 @@ def minmax_size(img, max_dimensions=None, min_dimensions=None, variant="demo"):
     return img
 
 
+def pad(img, divable=32, variant="demo"):
+    """pad() -- utils/data_utils.py:10-45 (variant "api": black canvas) == demo/HybridViT/helper.py:52-92 (variant "demo":
+    white canvas) on a uint8 [h, w] array.  cv2.findNonZero + cv2.boundingRect are restated as the bounding rectangle of the
+    non-zero pixels (PARITY UNPINNED: cv2 is absent); everything else is numpy / Pillow semantics."""
+    data = np.stack([img, np.full_like(img, 255)], axis=-1)  # img.convert("LA"): alpha 255
+    with np.errstate(divide="ignore", invalid="ignore"):
+        data = (data - data.min()) / (data.max() - data.min()) * 255
+    if data[..., 0].mean() > 128:
+        gray = 255 * (data[..., 0] < 128).astype(np.uint8)  # text = the dark pixels
+    else:
+        gray = 255 * (data[..., 0] > 128).astype(np.uint8)
+        data[..., 0] = 255 - data[..., 0]
+    ys, xs = np.nonzero(gray)
+    if len(ys) == 0:
+        raise RuntimeError("cv2.boundingRect(None): no text pixels")  # cv2.error in the reference
+    a, b = int(xs.min()), int(ys.min())
+    w, h = int(xs.max()) - a + 1, int(ys.max()) - b + 1
+    rect = data[b:b + h, a:a + w]
+    if rect[..., -1].var() == 0:
+        im = rect[..., 0].astype(np.uint8)
+    else:
+        im = (255 - rect[..., -1]).astype(np.uint8)
+    dw, dh = [divable * (x // divable + (1 if x % divable > 0 else 0)) for x in (w, h)]
+    box = getbbox(im)
+    if box is not None and box != (0, 0, w, h):
+        raise ReferencePasteMismatch("images do not match")
+    padded = np.full((dh, dw), 255 if variant == "demo" else 0, np.uint8)
+    padded[:h, :w] = im
+    return padded
+
+
 def area_downsample(img, ratio):
     """cv2.resize(img, (int(w/ratio), int(h/ratio)), interpolation=cv2.INTER_AREA) -- PARITY UNPINNED (cv2 absent).
 
@@ -244,7 +275,8 @@ def resize(img, opt, variant="demo"):
             img = area_downsample(img, ratio)
     lut = normalize_lut(opt["mean"], opt["std"])
     try:
-        out = minmax_size(img, opt["max_dimension"], opt["min_dimension"], variant=variant)
+        out = minmax_size(pad(img, variant=variant) if opt.get("pad", False) else img,
+                          opt["max_dimension"], opt["min_dimension"], variant=variant)
     except ValueError:
         # predict_utils.py:85-97 / helper.py:193-205: the image as it is at this point, normalised, then
         # F.pad(..., (0, max_w - w, 0, max_h - h), value=1) -- a negative amount crops.  The "api" copy asserts a 3-D
