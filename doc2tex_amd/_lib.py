@@ -28,7 +28,7 @@ class D2TConfig(C.Structure):
 
 class D2TPrepConfig(C.Structure):  # include/d2t_prep.h d2t_prep_config
     _fields_ = [(n, C.c_int32) for n in ("max_h", "max_w", "min_h", "min_w", "downsample", "variant")] + \
-               [("mean", C.c_float), ("std", C.c_float)]
+               [("mean", C.c_float), ("std", C.c_float), ("norm_mode", C.c_int32)]
 
 
 class D2TPrepPlan(C.Structure):  # include/d2t_prep.h d2t_prep_plan
@@ -37,6 +37,7 @@ class D2TPrepPlan(C.Structure):  # include/d2t_prep.h d2t_prep_plan
 
 
 PREP_DEMO, PREP_API = 0, 1
+NORM_ALB, NORM_RAW = 0, 1
 PREP_OK, PREP_UNBOUND_LOCAL, PREP_FALLBACK = 0, 1, 2
 PREP_FLAG_PASTE_MISMATCH = 1
 POST_NONE, POST_API, POST_DEMO = 0, 1, 2

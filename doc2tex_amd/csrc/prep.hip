@@ -185,6 +185,20 @@ int plan_image(const d2t_prep_config* c, int src_h, int src_w, d2t_prep_plan* p)
   return D2T_OK;
 }
 
+// albumentations Normalize(mean, std, max_pixel_value=255) in float32 (math_transform.py:43-52), or torchvision's
+// Normalize on the raw 0..255 values (predict_utils.py:110): tensor.sub_(mean).div_(std)
+float normalise_value(const d2t_prep_config& c, float v) {
+  if (c.norm_mode == D2T_NORM_RAW) {
+    volatile float t = v - c.mean;
+    return t / c.std;
+  }
+  const float m = c.mean * 255.0f;
+  volatile float sd = c.std * 255.0f;
+  const float dnm = 1.0f / sd;
+  volatile float t = v - m;
+  return t * dnm;
+}
+
 // ---- device side -------------------------------------------------------------------------------------------------
 struct PrepDesc {
   int64_t src_off, ds_off, hp_off;  // byte offsets: source pixels; work buffer (downsampled image, horizontal-pass image)
@@ -497,17 +511,9 @@ int d2t_prep_create(const d2t_prep_config* cfg, d2t_prep** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(p, D2T_EHIP, "no HIP device visible (the pre-processing has no CPU path)");
-  // albumentations Normalize(mean, std, max_pixel_value=255) in float32 (math_transform.py:43-52)
-  float host[258];
-  const float m = cfg->mean * 255.0f;
-  volatile float sd = cfg->std * 255.0f;
-  const float dnm = 1.0f / sd;
-  for (int v = 0; v < 256; ++v) {
-    volatile float t = (float)v - m;
-    host[v] = t * dnm;
-  }
-  host[256] = m;
-  host[257] = dnm;
+  if (cfg->norm_mode != D2T_NORM_ALB && cfg->norm_mode != D2T_NORM_RAW) return fail(p, D2T_EINVAL, "bad norm_mode");
+  float host[256];
+  for (int v = 0; v < 256; ++v) host[v] = normalise_value(*cfg, (float)v);
   PHIP(p, hipMalloc(&p->lut, sizeof host));
   PHIP(p, hipMemcpy(p->lut, host, sizeof host, hipMemcpyHostToDevice));
   for (auto& st : p->stage) PHIP(p, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
@@ -670,14 +676,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
 
   // ---- descriptors ----------------------------------------------------------------------------------------------------
   PrepDesc* descs = reinterpret_cast<PrepDesc*>(st.h);
-  float canvas;  // canvas colour 255 through the normalisation table
-  {
-    const float m = c.mean * 255.0f;
-    volatile float sd = c.std * 255.0f;
-    const float dnm = 1.0f / sd;
-    volatile float t = 255.0f - m;
-    canvas = t * dnm;
-  }
+  const float canvas = normalise_value(c, 255.0f);  // canvas colour 255 through the normalisation table
   size_t work = 0;
   int max_ds_w = 1, max_ds_h = 1, max_rows_h = 0, any_min = 0, any_ds = 0, any_h = 0;
   for (int i = 0; i < n; ++i) {

@@ -40,8 +40,10 @@ class Preprocessor:
         import torch
         assert isinstance(opt, dict)
         assert "imgH" in opt and "imgW" in opt  # predict_utils.py:18-19
-        if opt["imgH"] is not None:
-            raise NotImplementedError("doc2tex_amd.preprocess: only the `imgH: null` branch (the shipped configs) is built")
+        self.fixed_height = opt["imgH"] is not None
+        if self.fixed_height and variant == "demo":
+            # helper.py:142-207 has no `else:` for a set imgH: `new_img` is never assigned
+            raise UnboundLocalError("local variable 'new_img' referenced before assignment (demo/HybridViT/helper.py:206)")
         if opt.get("rgb", False):
             raise NotImplementedError("doc2tex_amd.preprocess: grayscale only (rgb: False in every shipped config)")
         self.pad = bool(opt.get("pad", False))
@@ -61,11 +63,18 @@ class Preprocessor:
             raise RuntimeError("doc2tex_amd.preprocess runs on the GPU only (no CPU path)")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.cfg = _lib.D2TPrepConfig(
-            max_h=opt["max_dimension"][0], max_w=opt["max_dimension"][1],
-            min_h=opt["min_dimension"][0], min_w=opt["min_dimension"][1],
-            downsample=int(ds) if ds else 0, variant=_lib.PREP_API if variant == "api" else _lib.PREP_DEMO,
-            mean=float(opt["mean"]), std=float(opt["std"]))
+        if self.fixed_height:
+            # predict_utils.py:98-114: no downsample, no resize, no padding -- the pixels as they are through torchvision's
+            # Normalize(mean, std) on the 0..255 values
+            self.pad = False
+            self.cfg = _lib.D2TPrepConfig(max_h=1 << 30, max_w=1 << 30, min_h=0, min_w=0, downsample=0, variant=_lib.PREP_API,
+                                          mean=float(opt["mean"]), std=float(opt["std"]), norm_mode=_lib.NORM_RAW)
+        else:
+            self.cfg = _lib.D2TPrepConfig(
+                max_h=opt["max_dimension"][0], max_w=opt["max_dimension"][1],
+                min_h=opt["min_dimension"][0], min_w=opt["min_dimension"][1],
+                downsample=int(ds) if ds else 0, variant=_lib.PREP_API if variant == "api" else _lib.PREP_DEMO,
+                mean=float(opt["mean"]), std=float(opt["std"]), norm_mode=_lib.NORM_ALB)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self.lib.d2t_prep_create(C.byref(self.cfg), C.byref(h))
@@ -272,7 +281,8 @@ def resize(resizer, img, opt, variant=None):
         raise NotImplementedError("doc2tex_amd.preprocess: the learned resizer loop is not on this path")
     if variant is None:
         variant = "api" if isinstance(img, (str, os.PathLike)) else "demo"
-    key = (variant, tuple(opt["max_dimension"]), tuple(opt["min_dimension"]), opt.get("downsample", None),
+    key = (variant, opt["imgH"] is not None, bool(opt.get("pad", False)), tuple(opt["max_dimension"]),
+           tuple(opt["min_dimension"]), opt.get("downsample", None),
            float(opt["mean"]), float(opt["std"]), str(opt.get("device", "cuda")))
     pre = _cache.get(key)
     if pre is None:

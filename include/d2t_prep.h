@@ -38,6 +38,7 @@ extern "C" {
 typedef struct d2t_prep d2t_prep;
 
 enum { D2T_PREP_DEMO = 0, D2T_PREP_API = 1 };
+enum { D2T_NORM_ALB = 0, D2T_NORM_RAW = 1 };
 
 /* d2t_prep_plan.status */
 enum {
@@ -61,6 +62,9 @@ typedef struct {
   int32_t downsample;   /* opt["downsample"] (variant API only), 0 = none */
   int32_t variant;      /* D2T_PREP_DEMO / D2T_PREP_API */
   float mean, std;      /* opt["mean"], opt["std"] (grayscale) */
+  int32_t norm_mode;    /* D2T_NORM_ALB: (v - mean*255) * float32(1/(std*255))  -- albumentations, the `imgH: null` branch;
+                           D2T_NORM_RAW: (v - mean) / std on the 0..255 values  -- torchvision Normalize, the `imgH` branch
+                           (predict_utils.py:98-114, which neither resizes nor divides by 255)                          */
 } d2t_prep_config;
 
 typedef struct {

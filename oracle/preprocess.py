@@ -268,6 +268,13 @@ def normalize_lut(mean, std):
 def resize(img, opt, variant="demo"):
     """predict_utils.py:14-115 (variant "api") == demo/HybridViT/helper.py:134-200 (variant "demo") for `imgH None`, `use_resizer False`, `pad False`, `rgb False`: uint8 [h, w]
     (what `Image.open(path).convert("L")` holds) -> float32 [1, 1, H, W]."""
+    if opt.get("imgH", None) is not None:
+        # predict_utils.py:98-114 (variant "api" only): torchvision Normalize(mean, std) on the raw 0..255 values, no resize.
+        # PARITY UNPINNED (torchvision absent): tensor.sub_(mean).div_(std) in float32
+        if variant == "demo":
+            raise UnboundLocalError("new_img")  # helper.py has no else-branch
+        x = img.astype(np.float32)
+        return ((x - np.float32(opt["mean"])) / np.float32(opt["std"]))[None, None]
     if opt.get("downsample", None) is not None:
         ratio = opt["downsample"]
         h, w = img.shape

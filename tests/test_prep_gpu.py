@@ -166,12 +166,23 @@ def test_pad_option(variant, capsys):
     assert "RuntimeError" in seen  # the blank pages
 
 
+def test_fixed_height_branch():
+    """`imgH` set (predict_utils.py:98-114): no resize at all, torchvision's Normalize on the raw 0..255 values."""
+    opt = _opt((128, 512), imgH=32, mean=0.5, std=0.5)
+    pre = _pre(opt, "api")
+    for h, w, seed in ((32, 100, 7400), (77, 301, 7401), (200, 900, 7402)):
+        img = synth.synth_formula_image(h, w, seed)
+        got = pre(img).cpu().numpy()
+        assert got.shape == (1, 1, h, w) and np.array_equal(got, P.resize(img, opt, variant="api"))
+    assert float(got.max()) > 400  # not divided by 255, as in the reference
+
+
 def test_unsupported_options_raise():
     from doc2tex_amd.preprocess import Preprocessor, resize
     with pytest.raises(NotImplementedError):
         Preprocessor(_opt((128, 512), pad=True, downsample=2), "api")
-    with pytest.raises(NotImplementedError):
-        Preprocessor(_opt((128, 512), imgH=32))
+    with pytest.raises(UnboundLocalError):  # the demo copy of resize() has no branch for a set imgH
+        Preprocessor(_opt((128, 512), imgH=32), "demo")
     with pytest.raises(NotImplementedError):
         resize(object(), np.zeros((4, 4), np.uint8), _opt((128, 512)))
 
