@@ -87,6 +87,19 @@ class LabelDecoder:
         """converter.decode(text_index, token_level): every token of every row, joined."""
         return self._decode(text_index, token_level, False, _lib.POST_NONE)
 
+    def detokenize(self, token_ids):
+        """converter.detokenize(token_ids): per row the token strings up to (not including) the first "[s]"."""
+        ids = token_ids.detach().cpu().numpy() if hasattr(token_ids, "detach") else np.asarray(token_ids)
+        out = []
+        for row in ids:
+            toks = []
+            for i in row:
+                if self.character[i] == "[s]":
+                    break
+                toks.append(self.character[i])
+            out.append(toks)
+        return out
+
     def to_latex(self, preds_index, token_level="word", postprocess=True):
         """decode -> cut at "[s]" -> whitespace clean-up, in one native call (inferencing.py:93,119-125).
         `postprocess`: True / "api" (remove_unused_whitespace), "demo" (recog_flow._postprocess), False."""

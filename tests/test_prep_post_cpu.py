@@ -170,8 +170,15 @@ def test_decode_cut_and_cleanup_match_reference_fixture():
         assert dec.to_latex(ids, c["token_level"], postprocess=True) == c["latex_api"]
         assert dec.to_latex(ids, c["token_level"], postprocess="demo") == c["latex_demo"]
         assert dec.to_latex(ids, c["token_level"], postprocess=False) == c["latex_none"]
+        assert dec.detokenize(ids) == c["detokenize"]
     with pytest.raises(IndexError):
         dec.decode(np.array([[10 ** 6]]))
+    adec = LabelDecoder(POST["vocab"], head="Attn")  # AttnLabelConverter: [GO] [s] [UNK] first (attn_converter.py:8)
+    for c in POST["attn"]:
+        ids = np.array(c["ids"], np.int64)
+        assert adec.decode(ids, "word") == c["decode"]
+        assert adec.detokenize(ids) == c["detokenize"]
+        assert adec.to_latex(ids, "word", postprocess=True) == c["latex_api"]
 
 
 def test_preprocessor_fails_loudly_without_a_device():

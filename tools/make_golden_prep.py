@@ -131,6 +131,7 @@ def post_main():
     sys.path.insert(0, "/root/reference")
     with contextlib.redirect_stdout(io.StringIO()):
         from doc2tex.modules.converter.tfm_converter import TFMLabelConverter
+        from doc2tex.modules.converter.attn_converter import AttnLabelConverter
     api, demo = reference_postprocessors()
     rnd = random.Random(77)
     strings = ["", " ", "x", "\\mathrm { d } x", "\\operatorname * { a r g m a x } _ { x }", "\\mathrm  { a }",
@@ -160,8 +161,19 @@ def post_main():
             cut = [p[: p.find("[s]")] for p in full]
             decode.append({"ids": ids.tolist(), "token_level": level, "decode": full,
                            "latex_api": [api(p) for p in cut], "latex_demo": [demo(p) for p in cut], "latex_none": cut})
+    aconv = AttnLabelConverter(vocab, "cpu")
+    attn = []
+    for r in range(10):
+        ids = rng.integers(2, len(aconv.character), (2, int(rng.integers(1, 24))))
+        if r % 2 == 0:
+            ids[0, int(rng.integers(0, ids.shape[1]))] = 1  # [s]
+        full = aconv.decode(ids, "word")
+        attn.append({"ids": ids.tolist(), "decode": full, "detokenize": aconv.detokenize(ids),
+                     "latex_api": [api(p[: p.find("[s]")]) for p in full]})
+    for c in decode:
+        c["detokenize"] = conv.detokenize(np.array(c["ids"]))
     with open(os.path.join(GOLD, "post_cases.json"), "w") as f:
-        json.dump({"python": sys.version.split()[0], "vocab": vocab, "strings": cases, "decode": decode}, f,
+        json.dump({"python": sys.version.split()[0], "vocab": vocab, "strings": cases, "decode": decode, "attn": attn}, f,
                   ensure_ascii=True, indent=0)
     print("post:", len(cases), "strings,", len(decode), "decode cases,",
           os.path.getsize(os.path.join(GOLD, "post_cases.json")), "bytes")
