@@ -163,6 +163,9 @@ int d2t_decode_attn_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int
  * loop is latency-bound and leaves most CUs idle).  tokens_dev / logits_dev / start_tokens_dev must stay
  * alive and untouched until d2t_decode_wait: it makes `stream` wait for every outstanding decode
  * (and, if host_sync != 0, blocks the host until they are complete). */
+/* Decode groups: B need not be one encoder batch.  A serving loop may collect the memories of several consecutive batches
+ * (same T) in one buffer and decode their rows with ONE call -- the step loop's duration hardly depends on the row count,
+ * and every row's result is bit-identical to its single-batch decode (doc2tex_amd.Model.decode_group does exactly this). */
 int d2t_decode_greedy_async(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T,
                             const int64_t* start_tokens_dev, int64_t* tokens_dev, float* logits_dev, d2t_stream stream);
 int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);

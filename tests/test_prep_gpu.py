@@ -177,6 +177,28 @@ def test_fixed_height_branch():
     assert float(got.max()) > 400  # not divided by 255, as in the reference
 
 
+def test_c_abi_misuse_is_reported_not_executed():
+    """A plan that is not what d2t_prep_plan_image produces for the handle's configuration, or an output size that does not
+    match, is refused with an error string; the handle keeps working."""
+    import ctypes as C
+    from doc2tex_amd import _lib
+    pre = _pre(_opt((128, 512)), "demo")
+    img = synth.synth_formula_image(300, 1400, 7500)
+    src, offs = pre._upload([img])
+    plan = pre.plan(300, 1400)
+    out = torch.empty((1, 1, plan.out_h, plan.out_w), device="cuda")
+    call = lambda pl, oh, ow: pre.lib.d2t_prep_run(pre.h, 1, (_lib.D2TPrepPlan * 1)(pl), _lib.ptr(src),
+                                                    offs.ctypes.data_as(C.POINTER(C.c_int64)), _lib.ptr(out), oh, ow, None,
+                                                    _lib.stream_of(out))
+    bad = pre.plan(300, 1400)
+    bad.rs_w += 32
+    assert call(bad, plan.out_h, plan.out_w) == 1 and b"does not match" in pre.lib.d2t_prep_last_error(pre.h)
+    assert call(plan, plan.out_h, plan.out_w + 32) == 1 and b"produces" in pre.lib.d2t_prep_last_error(pre.h)
+    assert call(plan, plan.out_h, plan.out_w) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), P.resize(img, _opt((128, 512)), variant="demo"))
+
+
 def test_unsupported_options_raise():
     from doc2tex_amd.preprocess import Preprocessor, resize
     with pytest.raises(NotImplementedError):
