@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -614,7 +615,9 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     if (new_words > p->arena_cap) {
       if (p->d_arena) PHIP(p, hipFree(p->d_arena));
       p->d_arena = nullptr, p->arena_cap = 0;
-      const size_t cap = std::max<size_t>(new_words * 2, (size_t)16 << 20);  // >= 64 MB of int32
+      // >= 64 MB of int32 (D2T_PREP_ARENA_WORDS: a small arena for the test of the start-over path)
+      static const size_t min_words = getenv("D2T_PREP_ARENA_WORDS") ? (size_t)atoll(getenv("D2T_PREP_ARENA_WORDS")) : (size_t)16 << 20;
+      const size_t cap = std::max<size_t>(new_words * 2, min_words);
       PHIP(p, hipMalloc((void**)&p->d_arena, cap * 4));
       p->arena_cap = cap;
     }

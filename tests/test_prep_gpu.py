@@ -177,6 +177,33 @@ def test_fixed_height_branch():
     assert float(got.max()) > 400  # not divided by 255, as in the reference
 
 
+def test_table_arena_start_over():
+    """A deliberately tiny table arena (D2T_PREP_ARENA_WORDS, read once per process: run in a child process) overflows after
+    a few sizes and starts over; results stay exact across the resets."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from doc2tex_amd import synth
+from doc2tex_amd.preprocess import Preprocessor
+from oracle import preprocess as P
+opt = {"imgH": None, "imgW": None, "max_dimension": [64, 256], "min_dimension": [32, 32], "mean": 0.5, "std": 0.5,
+       "rgb": False, "pad": False, "device": "cuda"}
+pre = Preprocessor(opt, "demo")
+rng = np.random.default_rng(3)
+for rnd in range(10):
+    imgs = [synth.synth_formula_image(int(rng.integers(70, 300)), int(rng.integers(260, 900)), 7600 + 10 * rnd + i) for i in range(6)]
+    ts, es = pre.batch(imgs)
+    for img, t in zip(imgs, ts):
+        assert np.array_equal(t.cpu().numpy(), P.resize(img, opt, variant="demo")), (rnd, img.shape)
+print("arena ok")
+""" % (ROOT, ROOT)
+    env = dict(os.environ, D2T_PREP_ARENA_WORDS="60000")  # ~4 pages' worth of tables
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "arena ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_c_abi_misuse_is_reported_not_executed():
     """A plan that is not what d2t_prep_plan_image produces for the handle's configuration, or an output size that does not
     match, is refused with an error string; the handle keeps working."""
