@@ -405,7 +405,12 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
     __syncthreads();                                   // ... and everyone else's; reads of `cur` are done
   }
-  conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+  if (wide_epilogue_ok(p)) {  // block-uniform
+    static_assert(BM * BN * 4 <= 2 * STAGE, "the fp32 tile must fit in the staging area");
+    conv_epilogue_wide<BM, BN, NW * 64, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+  } else {
+    conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+  }
   }  // tile loop
 }
 

@@ -94,4 +94,75 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][
   }
 }
 
+// Wide epilogue for block tiles whose LDS staging area is free after the K loop (the split-bf16 LDS-DMA kernel): the
+// accumulators go through LDS once so that a thread afterwards owns FOUR CONSECUTIVE CHANNELS of one output row, and the
+// residual is read and the result written with 8/16-byte accesses instead of one 2-byte (or 4-byte) access per element --
+// the element-wise epilogue above costs a residual layer ~10 % of its run time and dominates the short-K layers.
+// Same arithmetic per element, in the same order, as conv_epilogue: v = acc + bias; v += res | (res_hi + res_lo);
+// activation; split.  Requires: no row remap, no positional add, no head-split store, Cout % 32 == 0.
+// LDS tile: fp32 [BM][BN], the 32-float column block XOR-ed with bit 2 of the row so that the two half-waves of an MFMA
+// result (rows 4 apart, same columns) hit different banks.
+__device__ __forceinline__ bool wide_epilogue_ok(const ConvP& p) {
+  return p.store_mode == STORE_ROWS && p.rows_per_img == 0 && !p.row_add && (p.Cout & 31) == 0;
+}
+
+template <int BM, int BN, int NT, int MI, int NJ>
+__device__ __forceinline__ void conv_epilogue_wide(const ConvP& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int m0, int n0,
+                                                   int wrow, int wcol, int r, int h, int tid) {
+  float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wrow + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int col = (wcol + j * 32 + r) ^ (((row >> 2) & 1) << 5);
+        tile[row * BN + col] = acc[i][j][reg];
+      }
+  __syncthreads();
+  constexpr int QPR = BN / 4;  // 4-channel quads per tile row
+#pragma unroll 2  // more would cost the registers that let a decode wave share the SIMD with four convolution waves
+  for (int idx = tid; idx < BM * QPR; idx += NT) {
+    const int row = idx / QPR, q = idx % QPR;
+    const int m = m0 + row, n = n0 + q * 4;
+    if (m >= p.M || n >= p.Cout) continue;
+    const int col = (q * 4) ^ (((row >> 2) & 1) << 5);
+    const float4 a = *reinterpret_cast<const float4*>(tile + row * BN + col);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+    }
+    const size_t off = (size_t)m * p.Cout + n;
+    const size_t pi = plane_idx((size_t)m, n, p.Cout);
+    if (p.res) {
+      const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
+      v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+    }
+    if (p.res_hi) {
+      const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
+      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
+      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
+      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
+      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    if (p.out_hi) {
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint2 oh, ol;
+      oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+      *reinterpret_cast<uint2*>(p.out_hi + pi) = oh;
+      *reinterpret_cast<uint2*>(p.out_hi + pi + 32) = ol;
+    } else {
+      *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();  // the tile is staging memory again (next tile's LDS-DMA)
+}
+
 }  // namespace d2t
