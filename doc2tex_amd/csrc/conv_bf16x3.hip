@@ -55,6 +55,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
   constexpr int PLANE_A = BM * XROW, PLANE_B = BN * XROW;
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  static_assert(BM * BN * 4 <= 2 * STAGE, "the wide epilogue's fp32 tile must fit in the staging area");
 
   const int nt = (p.Cout + BN - 1) / BN;
   const int logical = xcd_logical_tile();
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
         compute(kt2, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
       }
     }
-    conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+    if (wide_epilogue_ok(p)) conv_epilogue_wide<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+    else conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
     return;
   }
   // steady state (K-steps kt+1 and kt+2 exist), unrolled by two so the register sets are static
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
   } else if (kt < KT) {     // one left
     compute(kt, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
   }
-  conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+  if (wide_epilogue_ok(p)) conv_epilogue_wide<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+  else conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
 
 // ---------------------------------------------------------------------------
