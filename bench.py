@@ -69,7 +69,12 @@ def pmc_traffic(precision):
         return None, None
     with open(files[-1]) as f:
         pm = json.load(f)
+    global _PMC
+    _PMC = pm
     return pm.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
+_PMC = {}
 
 
 def log(msg):
@@ -294,6 +299,9 @@ def main():
             "all_encoder_gemms": {"achieved": round(total_flop / (total_ms * 1e-3) / 1e12, 2),
                                   "ms_per_step": round(total_ms / args.steps, 3)},
         }
+        if _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
+            roofline["mfma_busy_frac_pmc"] = round(_PMC["mfma_busy_frac"], 4)
+            roofline["kernel_alone_ms_rocprof"] = round(_PMC.get("kernel_trace_avg_ms", 0.0), 4)
         if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
             roofline["mfma_issued_tflops"] = round(3 * achieved, 2)
             roofline["mfma_issued_frac"] = round(3 * achieved / peak, 4)
