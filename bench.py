@@ -185,6 +185,10 @@ def main():
                     help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--group", type=int, default=2,
                     help="pipelined mode: decode the rows of this many consecutive batches in one step loop")
+    ap.add_argument("--end-bias", type=float, default=0.0,
+                    help="secondary run (SURVEY 8d): raise the [s] logit bias of the synthetic weights by this much so that "
+                         "rows terminate, and decode with is_test=True (the reference's early exit: a batch stops at the "
+                         "first step at which every row has ended); synchronous, not pipelined")
     ap.add_argument("--train", action="store_true",
                     help="secondary mode (BASELINE configs[3]): time the training step of config C3 -- forward under "
                          "module.train(), CE, backward in the HIP engine, bucketed RCCL gradient all-reduce when more than "
@@ -218,10 +222,11 @@ def main():
     L = cfg["Prediction"]["params"]["max_seq_len"]
     model = Model(cfg)
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
-    model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
+    model.load_state_dict(synth.synth_state_dict(tmpl, end_bias=args.end_bias), strict=False)
     model.eval().to(dev)
     model.conv_precision = args.precision
-    model.pipelined = not args.no_pipeline
+    early = args.end_bias != 0.0
+    model.pipelined = not args.no_pipeline and not early
     model.decode_chains = args.chains
     model.decode_group = args.group
     model.reserved_blocks = args.reserve  # decode of batch i overlaps the encoder of batch i+1
@@ -230,7 +235,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            return model(img, text, is_train=False, is_test=False)
+            return model(img, text, is_train=False, is_test=early)
 
     if model.pipelined:
         # capture every decode graph the timed region can need before anything is timed: a group that synchronize() finds
@@ -266,7 +271,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert out[0].shape == (B, L + 1), out[0].shape
+    assert early or out[0].shape == (B, L + 1), out[0].shape
 
     if rank == 0:
         log(f"timed {args.steps} steps in {elapsed:.3f} s")
@@ -312,7 +317,8 @@ def main():
                                          ff=cfg["Prediction"]["params"]["dim_feedforward"],
                                          n=cfg["Prediction"]["params"]["num_decoder_layers"])
         result = {
-            "metric": "formulas/s (greedy decode, 128x512 crops)" if name == "C2" else f"formulas/s ({name})",
+            "metric": ("formulas/s (greedy decode, 128x512 crops)" if name == "C2" else f"formulas/s ({name})") +
+                      (" -- early exit (is_test), synchronous" if early else ""),
             "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
@@ -324,6 +330,7 @@ def main():
                        "pipelined": bool(model.pipelined), "reserved_blocks": model.reserved_blocks if model.pipelined else 0,
                        "decode_chains": model.decode_chains if model.pipelined else 1,
                        "decode_group": model.decode_group if model.pipelined else 1},
+            **({"early_exit": {"end_bias": args.end_bias, "decode_steps_run": int(out[0].shape[1])}} if early else {}),
             "algorithmic_gflop_per_formula": round(algo / 1e9, 2),
             "e2e_tflops": round(algo * formulas / elapsed / 1e12, 2),
             "roofline": roofline,
