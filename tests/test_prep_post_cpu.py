@@ -161,6 +161,21 @@ def test_whitespace_pass_matches_python_re_live():
         assert Postprocessing.remove_unused_whitespace(s) == fixed_point(s), repr(s)
 
 
+def test_whitespace_pass_is_idempotent_and_never_grows():
+    """Size-independent properties on long inputs (thousands of tokens): the clean-up is a fixed point of itself, never
+    lengthens the string, and only ever removes whitespace characters."""
+    import random
+    from doc2tex_amd.postprocess import Postprocessing
+    rnd = random.Random(21)
+    toks = [c["s"] for c in POST["strings"] if c["s"]]
+    for _ in range(30):
+        s = " ".join(rnd.choice(toks) for _ in range(200))
+        once = Postprocessing.remove_unused_whitespace(s)
+        assert Postprocessing.remove_unused_whitespace(once) == once
+        assert len(once) <= len(s)
+        assert [ch for ch in once if not ch.isspace()] == [ch for ch in s if not ch.isspace()]
+
+
 def test_decode_cut_and_cleanup_match_reference_fixture():
     from doc2tex_amd.postprocess import LabelDecoder
     dec = LabelDecoder(POST["vocab"], head="TFM")
