@@ -177,6 +177,30 @@ def test_fixed_height_branch():
     assert float(got.max()) > 400  # not divided by 255, as in the reference
 
 
+def test_full_size_batch_properties():
+    """The bench / serving shape (64 pages of ~360x1600 -> 128x512) through size-independent properties: constant pages stay
+    constant under the resampling (its integer coefficients sum to one), outputs lie in the normalised range, a page's
+    result does not depend on what else is in the batch, and three sampled pages match the oracle bit for bit."""
+    opt = _opt((128, 512))
+    pre = _pre(opt, "demo")
+    rng = np.random.default_rng(17)
+    pages = [synth.synth_formula_image(int(rng.integers(310, 395)), int(rng.integers(1580, 1620)), 7700 + i) for i in range(64)]
+    for k, v in ((5, 0), (9, 255), (13, 131)):
+        pages[k] = np.full_like(pages[k], v)
+    tensors, errors = pre.batch(pages)
+    assert all(e is None for e in errors) and all(t.shape == (1, 1, 128, 512) for t in tensors)
+    lut = P.normalize_lut(0.5, 0.5)
+    for k, v in ((5, 0), (9, 255), (13, 131)):
+        assert torch.all(tensors[k] == float(lut[v]))
+    allv = torch.cat(tensors)
+    assert float(allv.min()) >= -1.0 and float(allv.max()) <= 1.0
+    again, _ = pre.batch(pages[40:] + pages[:7])  # other batch composition, other order
+    for a, b in zip(again, tensors[40:] + tensors[:7]):
+        assert torch.equal(a, b)
+    for k in (0, 31, 63):
+        assert np.array_equal(tensors[k].cpu().numpy(), P.resize(pages[k], opt, variant="demo"))
+
+
 def test_table_arena_start_over():
     """A deliberately tiny table arena (D2T_PREP_ARENA_WORDS, read once per process: run in a child process) overflows after
     a few sizes and starts over; results stay exact across the resets."""
