@@ -79,6 +79,7 @@ class Preprocessor:
         with torch.cuda.device(self.device):
             rc = self.lib.d2t_prep_create(C.byref(self.cfg), C.byref(h))
         self.h = h
+        self._slot, self._stage = -1, [None] * 4  # rotating pinned staging blocks (_upload)
         self._check(rc, "d2t_prep_create")
 
     def _check(self, rc, what):
@@ -111,9 +112,8 @@ class Preprocessor:
             # next to the persistent convolution and the host then waits a whole encoder for its staging memory).
             # Pinned staging blocks rotate; a block is reused only after the copy out of it has finished, which with four
             # blocks is a copy queued three batches ago -- the host does not wait behind the encoder in flight.
-            self._slot = (getattr(self, "_slot", -1) + 1) % 4
-            stage = self._stage = getattr(self, "_stage", [None] * 4)
-            slot = self._slot
+            slot = self._slot = (self._slot + 1) % len(self._stage)
+            stage = self._stage
             if stage[slot] is None or stage[slot][0].numel() < total:
                 stage[slot] = (torch.empty(max(total, 1 << 20) * 5 // 4, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
             else:
