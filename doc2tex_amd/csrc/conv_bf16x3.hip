@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
         compute(kt2, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
       }
     }
-    if (wide_epilogue_ok(p)) conv_epilogue_wide<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+    if (wide_epilogue_full_ok(p)) conv_epilogue_wide_full<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
     else conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
     return;
   }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
   } else if (kt < KT) {     // one left
     compute(kt, F_{}, F_{}, ra[1], rbh[1], rbl[1], ra[0], rbh[0], rbl[0]);
   }
-  if (wide_epilogue_ok(p)) conv_epilogue_wide<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+  if (wide_epilogue_full_ok(p)) conv_epilogue_wide_full<BM, BN, NT, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
   else conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
 

@@ -165,4 +165,91 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvP& p, f32x16 (&acc)
   __syncthreads();  // the tile is staging memory again (next tile's LDS-DMA)
 }
 
+// The same with the row remap (rows_per_img), the positional-table add and the head-split K/V store, for the kernels whose
+// register budget does not matter (the on-the-fly split-bf16 kernel, the fp32 kernel).  Kept apart from the lean function
+// above on purpose: with the remap code compiled in, the split-bf16 LDS-DMA kernel needs 107-121 VGPRs instead of 101; above
+// 104 a decode wave no longer fits on a SIMD next to four convolution waves and the decode streams starve (measured: 1139
+// instead of 1210 formulas/s).  Requires Cout % 32 == 0 and, for the head-split store, head_dim % 4 == 0.
+__device__ __forceinline__ bool wide_epilogue_full_ok(const ConvP& p) {
+  return (p.Cout & 31) == 0 && (p.store_mode == STORE_ROWS || (p.kv_hd & 3) == 0);
+}
+
+template <int BM, int BN, int NT, int MI, int NJ>
+__device__ __forceinline__ void conv_epilogue_wide_full(const ConvP& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int m0, int n0,
+                                                   int wrow, int wcol, int r, int h, int tid) {
+  float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wrow + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int col = (wcol + j * 32 + r) ^ (((row >> 2) & 1) << 5);
+        tile[row * BN + col] = acc[i][j][reg];
+      }
+  __syncthreads();
+  constexpr int QPR = BN / 4;  // 4-channel quads per tile row
+#pragma unroll 2  // more would cost the registers that let a decode wave share the SIMD with four convolution waves
+  for (int idx = tid; idx < BM * QPR; idx += NT) {
+    const int row = idx / QPR, q = idx % QPR;
+    const int m = m0 + row, n = n0 + q * 4;
+    if (m >= p.M || n >= p.Cout) continue;
+    const int col = (q * 4) ^ (((row >> 2) & 1) << 5);
+    const float4 a = *reinterpret_cast<const float4*>(tile + row * BN + col);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+    }
+    if (p.store_mode == STORE_KV) {  // n -> (slab, head, e), m -> (b, j): four consecutive e of one head
+      const int d = p.kv_heads * p.kv_hd, slab = n / d, within = n - slab * d;
+      const int head = within / p.kv_hd, e = within - head * p.kv_hd;
+      const int bb = m / p.kv_T, jj = m - bb * p.kv_T;
+      *reinterpret_cast<float4*>(p.out + ((((size_t)slab * p.kv_B + bb) * p.kv_heads + head) * p.kv_T + jj) * p.kv_hd + e) =
+          make_float4(v[0], v[1], v[2], v[3]);
+      continue;
+    }
+    size_t orow = (size_t)m;
+    int in_img = 0;
+    if (p.rows_per_img > 0) {
+      const int img = m / p.rows_per_img;
+      in_img = m - img * p.rows_per_img;
+      orow = (size_t)img * p.img_stride + p.row_off + in_img;
+    }
+    const size_t off = orow * p.Cout + n;
+    const size_t pi = plane_idx(orow, n, p.Cout);
+    if (p.res) {
+      const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
+      v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+    }
+    if (p.res_hi) {
+      const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
+      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
+      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
+      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
+      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    if (p.row_add) {
+      const float4 ra = *reinterpret_cast<const float4*>(p.row_add + (size_t)(p.row_add_off + in_img) * p.Cout + n);
+      v[0] += ra.x, v[1] += ra.y, v[2] += ra.z, v[3] += ra.w;
+    }
+    if (p.out_hi) {
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint2 oh, ol;
+      oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+      *reinterpret_cast<uint2*>(p.out_hi + pi) = oh;
+      *reinterpret_cast<uint2*>(p.out_hi + pi + 32) = ol;
+    } else {
+      *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();  // the tile is staging memory again (next tile's LDS-DMA)
+}
+
 }  // namespace d2t

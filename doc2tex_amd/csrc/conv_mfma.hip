@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvP p) {
   }
 
   static_assert((size_t)BM * BN <= 2 * (BM + BN) * LDS_LD, "the wide epilogue's fp32 tile must fit in the staging area");
-  if (wide_epilogue_ok(p))
-    conv_epilogue_wide<BM, BN, 256, MI, NJ>(p, acc, reinterpret_cast<unsigned char*>(smem), m0, n0, wm * WTM, wn * WTN, r, h, tid);
+  if (wide_epilogue_full_ok(p))
+    conv_epilogue_wide_full<BM, BN, 256, MI, NJ>(p, acc, reinterpret_cast<unsigned char*>(smem), m0, n0, wm * WTM, wn * WTN, r, h, tid);
   else
     conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
 }
