@@ -185,7 +185,7 @@ def main():
                     help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--group", type=int, default=0,
                     help="pipelined mode: decode the rows of this many consecutive batches in one step loop "
-                         "(default: 2 for C2, whose step is encoder-bound from there on; 4 for the decode-bound C1)")
+                         "(default: 3 for C2, whose step is encoder-bound from there on; 4 for the decode-bound C1)")
     ap.add_argument("--end-bias", type=float, default=0.0,
                     help="secondary run (SURVEY 8d): raise the [s] logit bias of the synthetic weights by this much so that "
                          "rows terminate, and decode with is_test=True (the reference's early exit: a batch stops at the "
@@ -218,7 +218,7 @@ def main():
         return train_bench(args, rank, world, dev, dist)
     name = args.config
     if args.group <= 0:
-        args.group = 4 if name == "C1" else 2
+        args.group = 4 if name == "C1" else 3
     H, W = synth.crop_shape(name)
     B = args.batch or synth.batch_size(name)
     cfg = synth.make_config(name, device=str(dev))

@@ -112,9 +112,9 @@ def test_headline_shape_properties(cases):
 
 
 def test_headline_shape_in_the_benchmarked_serving_mode(cases):
-    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of two batches, no reserved
-    block slots (and the earlier serving configuration: ungrouped, 64 reserved slots): four batches in flight give exactly
-    the synchronous results, and the fixture rows stay exact."""
+    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of three batches, no reserved
+    block slots (and the earlier serving configurations: groups of two; ungrouped with 64 reserved slots): four batches in
+    flight give exactly the synchronous results, and the fixture rows stay exact."""
     c = _case(cases, "greedy", "c2_greedy")
     z = np.load(os.path.join(GOLD, "c2_greedy.npz"))
     cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
@@ -128,7 +128,7 @@ def test_headline_shape_in_the_benchmarked_serving_mode(cases):
     with torch.no_grad():
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
-        for group, reserve in ((2, 0), (1, 64)):
+        for group, reserve in ((3, 0), (2, 0), (1, 64)):
             m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, group, reserve
             got = [m(x, text, is_train=False)[:2] for x in imgs]  # rings of four result buffers
             m.synchronize()
