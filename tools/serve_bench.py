@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--group", type=int, default=2, help="decode groups (batches per decode step loop)")
+    ap.add_argument("--group", type=int, default=3, help="decode groups (batches per decode step loop)")
     ap.add_argument("--page-sets", type=int, default=4, help="distinct batches of pages cycled through")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -52,7 +52,7 @@ def main():
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
     side = torch.cuda.Stream(dev)
     L = cfg["Prediction"]["params"]["max_seq_len"] + 1
-    ring = [torch.empty((B, L), dtype=torch.int64).pin_memory() for _ in range(8)]
+    ring = [torch.empty((B, L), dtype=torch.int64).pin_memory() for _ in range(16)]
     pending, waiting, done, t_pre, t_post, sample = [], [], 0, 0.0, 0.0, None
 
     def consume(block):
