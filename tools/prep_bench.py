@@ -104,7 +104,7 @@ def main():
         "value_from_host_arrays_new_sizes": round(args.batch / e2e_cold, 1),
         "ms_per_batch_kernels": round(dev * 1e3, 3), "ms_per_batch_end_to_end": round(e2e * 1e3, 3), "batch": args.batch,
         "roofline": {"bound": "hbm", "achieved": round((src_bytes + out_bytes) / dev / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round((src_bytes + out_bytes) / dev / 8e12, 4),
+                     "frac": round((src_bytes + out_bytes) / dev / 8e12, 4), "traffic": None,
                      "algorithmic_bytes_per_image": (src_bytes + out_bytes) // args.batch,
                      "with_intermediate_bytes_per_image": (src_bytes + out_bytes + inter) // args.batch},
         "cpu_baseline": {"value": round(1 / cpu, 1), "unit": "images/s", "cores": 1, "kind": "reference",
