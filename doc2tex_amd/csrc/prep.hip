@@ -308,33 +308,56 @@ __global__ __launch_bounds__(256) void prep_hpass_kernel(const PrepDesc* __restr
 }
 
 // Vertical LANCZOS pass (when the height changes) + canvas / padding + normalisation table + paste check.  One block per
-// output row of the batch tensor, 256 columns per block: the row index is block-uniform, so the coefficients are scalar
-// loads, and every tap reads 256 consecutive bytes of one intermediate row.
+// FR consecutive output rows x 256 columns: the intermediate rows those FR outputs need (about taps + (FR-1) x scale of
+// them) are staged in LDS once -- one block per output row re-read every intermediate row ~taps times, 4.4x its size in L2
+// misses (rocprofv3 FETCH_SIZE) because neighbouring rows ran on different XCDs.  The row index is block-uniform within an
+// iteration, so the coefficients are scalar loads.  Strips whose rows do not fit the LDS window read global memory directly.
+constexpr int FR = 8, FIN_ROWS = 96;  // output rows per block; LDS window (rows x 256 bytes = 24 KB)
 __global__ __launch_bounds__(256) void prep_finish_kernel(const PrepDesc* __restrict__ descs, const uint8_t* __restrict__ src,
                                                           const uint8_t* __restrict__ work, const int32_t* __restrict__ tabs,
                                                           const float* __restrict__ lut, float* __restrict__ out, int out_h,
                                                           int out_w, int32_t* __restrict__ bits) {
+  __shared__ uint8_t win[FIN_ROWS][256];
   const PrepDesc d = descs[blockIdx.z];
-  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  const int y0 = blockIdx.y * FR, x = blockIdx.x * 256 + threadIdx.x;
   const uint8_t* in = d.do_h ? work + d.hp_off : (d.do_ds ? work + d.ds_off : src + d.src_off);
   const int iw = d.rs_w;  // width of `in` (the horizontal pass, when there is one, has already produced rs_w columns)
-  float o = d.fill;
-  int mybits = 0;
-  if (x < out_w && y < d.rs_h && x < d.rs_w) {
-    int v;
-    if (d.do_v) {
-      const int ymin = tabs[d.vb + 2 * y], cnt = tabs[d.vb + 2 * y + 1];
-      const int32_t* vk = tabs + d.vk + (size_t)y * d.vks;
-      int ss = 1 << (PRECISION_BITS - 1);
-      for (int k = 0; k < cnt; ++k) ss += (int)in[(size_t)(ymin + k) * iw + x] * vk[k];
-      v = clip8(ss);
-    } else {
-      v = in[(size_t)y * iw + x];
+  // input rows [lo, hi) needed by the resampled output rows of this strip (block-uniform)
+  int lo = 0, hi = 0;
+  bool windowed = false;
+  if (d.do_v && y0 < d.rs_h) {
+    const int yl = min(y0 + FR, d.rs_h) - 1;
+    lo = tabs[d.vb + 2 * y0];
+    hi = tabs[d.vb + 2 * yl] + tabs[d.vb + 2 * yl + 1];
+    windowed = hi - lo <= FIN_ROWS;
+    if (windowed) {
+      if (x < iw)
+        for (int rr = lo; rr < hi; ++rr) win[rr - lo][threadIdx.x] = in[(size_t)rr * iw + x];
     }
-    o = lut[v];  // the fallback normalises with the same transform (predict_utils.py:89)
-    if (d.min_branch && v) mybits = 1 | (y == 0 ? 2 : 0) | (y == d.rs_h - 1 ? 4 : 0) | (x == 0 ? 8 : 0) | (x == d.rs_w - 1 ? 16 : 0);
   }
-  if (x < out_w) out[((size_t)blockIdx.z * out_h + y) * out_w + x] = o;
+  // each thread reads back only the column it wrote: no barrier needed
+  int mybits = 0;
+  for (int y = y0; y < min(y0 + FR, out_h); ++y) {
+    float o = d.fill;
+    if (x < out_w && y < d.rs_h && x < d.rs_w) {
+      int v;
+      if (d.do_v) {
+        const int ymin = tabs[d.vb + 2 * y], cnt = tabs[d.vb + 2 * y + 1];
+        const int32_t* vk = tabs + d.vk + (size_t)y * d.vks;
+        int ss = 1 << (PRECISION_BITS - 1);
+        if (windowed)
+          for (int k = 0; k < cnt; ++k) ss += (int)win[ymin + k - lo][threadIdx.x] * vk[k];
+        else
+          for (int k = 0; k < cnt; ++k) ss += (int)in[(size_t)(ymin + k) * iw + x] * vk[k];
+        v = clip8(ss);
+      } else {
+        v = in[(size_t)y * iw + x];
+      }
+      o = lut[v];  // the fallback normalises with the same transform (predict_utils.py:89)
+      if (d.min_branch && v) mybits |= 1 | (y == 0 ? 2 : 0) | (y == d.rs_h - 1 ? 4 : 0) | (x == 0 ? 8 : 0) | (x == d.rs_w - 1 ? 16 : 0);
+    }
+    if (x < out_w) out[((size_t)blockIdx.z * out_h + y) * out_w + x] = o;
+  }
   if (d.min_branch) {
     for (int s = 32; s; s >>= 1) mybits |= __shfl_xor(mybits, s);
     if ((threadIdx.x & 63) == 0 && mybits) atomicOr(&bits[blockIdx.z], mybits);
@@ -764,7 +787,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
                          p->d_work, d_tabs, stride);
   }
   if (any_min) PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));
-  hipLaunchKernelGGL(prep_finish_kernel, dim3((out_w + 255) / 256, out_h, n), dim3(256), 0, stream, d_descs, src_dev,
+  hipLaunchKernelGGL(prep_finish_kernel, dim3((out_w + 255) / 256, (out_h + FR - 1) / FR, n), dim3(256), 0, stream, d_descs, src_dev,
                      (const uint8_t*)p->d_work, d_tabs, (const float*)p->lut, out_dev, out_h, out_w, p->d_bits);
   if (flags_dev) {
     if (!any_min) PHIP(p, hipMemsetAsync(p->d_bits, 0, (size_t)n * 4, stream));

@@ -20,6 +20,15 @@ from doc2tex_amd import synth
 from doc2tex_amd.preprocess import Preprocessor
 
 
+def pmc_traffic():
+    """HBM bytes per batch of 64 pages from the committed PMC passes (tools/probe/prep_pmc.sh), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_prep.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_batch_of_64")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
@@ -104,7 +113,8 @@ def main():
         "value_from_host_arrays_new_sizes": round(args.batch / e2e_cold, 1),
         "ms_per_batch_kernels": round(dev * 1e3, 3), "ms_per_batch_end_to_end": round(e2e * 1e3, 3), "batch": args.batch,
         "roofline": {"bound": "hbm", "achieved": round((src_bytes + out_bytes) / dev / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round((src_bytes + out_bytes) / dev / 8e12, 4), "traffic": None,
+                     "frac": round((src_bytes + out_bytes) / dev / 8e12, 4), "traffic": pmc_traffic(),
+                     "traffic_unit": "HBM bytes per batch of 64 (profiles/r01_pmc_prep.json)",
                      "algorithmic_bytes_per_image": (src_bytes + out_bytes) // args.batch,
                      "with_intermediate_bytes_per_image": (src_bytes + out_bytes + inter) // args.batch},
         "cpu_baseline": {"value": round(1 / cpu, 1), "unit": "images/s", "cores": 1, "kind": "reference",
