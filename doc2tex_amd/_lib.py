@@ -51,6 +51,7 @@ SIGNATURES = {
     "d2t_destroy": (None, [_P]),
     "d2t_last_error": (C.c_char_p, [_P]),
     "d2t_device_available": (_I, []),
+    "d2t_device_of": (_I, [_P]),
     "d2t_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _P]),
     "d2t_finalize_weights": (_I, [_P, _P]),
     "d2t_encoder_shape": (_I, [_P, _I, _I] + [C.POINTER(_I)] * 6),
@@ -59,6 +60,9 @@ SIGNATURES = {
     "d2t_decode_attn_greedy": (_I, [_P, _P, _I, _I, _I, _P, _P, C.POINTER(_I), _P]),
     "d2t_decode_greedy_async": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "d2t_decode_wait": (_I, [_P, _P, _I]),
+    "d2t_decode_last_ticket": (_L, [_P]),
+    "d2t_decode_query": (_I, [_P, _L]),
+    "d2t_decode_wait_ticket": (_I, [_P, _L, _P, _I]),
     "d2t_decode_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_decode_beam_batch": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_decode_attn_beam_batch": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
@@ -85,6 +89,11 @@ SIGNATURES = {
     "d2t_op_layernorm": (_I, [_P] * 4 + [_I, _I, C.c_float, _P]),
     "d2t_op_vit_attention": (_I, [_P, _P, _I, _I, _I, _P]),
     "d2t_op_decode_attention": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "d2t_op_train_conv": (_I, [_P] * 14 + [_I] * 13 + [_P]),
+    "d2t_op_train_linear": (_I, [_P] * 10 + [_I] * 5 + [_P]),
+    "d2t_op_train_layernorm": (_I, [_P] * 8 + [_I, _I, C.c_float, _P]),
+    "d2t_op_train_attention": (_I, [_P] * 7 + [_I] * 6 + [_P]),
+    "d2t_op_train_maxpool": (_I, [_P] * 4 + [_I] * 8 + [_P]),
 }
 # include/d2t_prep.h
 SIGNATURES_PREP = {

@@ -92,6 +92,29 @@ class PredictBuilder(nn.Module):
             self.Prediction = P.AttentionParams(**config["Prediction"]["params"])
 
 
+class DecodeHandle:
+    """Completion handle of a pipelined forward (addition_outputs["decode"]): the forward's tokens / logits are views the
+    engine's decode stream is still writing.  `wait()` orders the current stream (optionally the host) after exactly that
+    decode -- launching the group first if it is still collecting batches -- and `done()` polls without blocking."""
+
+    def __init__(self, model, eng, ticket=None):
+        self._model, self._eng, self.ticket = model, eng, ticket
+
+    def _launch(self):
+        if self.ticket is None:  # the group this forward belongs to has not been launched yet
+            self._model._flush_group(self._eng)
+        assert self.ticket is not None
+
+    def done(self):
+        if self.ticket is None:
+            return False
+        return self._eng.ticket_done(self.ticket)
+
+    def wait(self, host_sync=False):
+        self._launch()
+        self._eng.wait_ticket(self.ticket, host_sync=host_sync)
+
+
 class Model(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -140,26 +163,28 @@ class Model(nn.Module):
         return self.engine().decode_attn_beam_batch(memory.contiguous(), beam)
 
     def _group_decode(self, eng, memory, start):
-        """pipelined + decode_group > 1: collect the encoder memories of consecutive calls, launch one decode per group."""
+        """pipelined + decode_group > 1: collect the encoder memories of consecutive calls, launch one decode per group.
+        Every group writes into fresh tensors (no ring to overrun): the views handed out stay valid for as long as the
+        caller keeps them, and become readable once the group's ticket is complete."""
         import torch
         G = int(self.decode_group)
         B, T, d = memory.shape
         S, V = eng.cfg.max_seq_len + 1, eng.cfg.vocab
         key = (G, B, T, d, S, V, memory.device)
         g = self._grp
-        if g is None or g["key"] != key:
+        if g is not None and g["key"] != key:
             self._flush_group(eng)
-            eng.decode_wait(host_sync=True)
-            ring = [dict(mem=torch.empty((G * B, T, d), dtype=torch.float32, device=memory.device),
-                         start=torch.zeros((G * B,), dtype=torch.int64, device=memory.device),
-                         tokens=torch.zeros((G * B, S), dtype=torch.int64, device=memory.device),
-                         logits=torch.zeros((G * B, S, V), dtype=torch.float32, device=memory.device)) for _ in range(4)]
-            g = self._grp = {"key": key, "ring": ring, "pos": 0, "n": 0}
-        buf = g["ring"][g["pos"] % len(g["ring"])]
+            g = None
+        if g is None:
+            g = self._grp = {"key": key, "n": 0, "handle": DecodeHandle(self, eng),
+                             "mem": torch.empty((G * B, T, d), dtype=torch.float32, device=memory.device),
+                             "start": torch.empty((G * B,), dtype=torch.int64, device=memory.device),
+                             "tokens": torch.empty((G * B, S), dtype=torch.int64, device=memory.device),
+                             "logits": torch.empty((G * B, S, V), dtype=torch.float32, device=memory.device)}
         k = g["n"]
-        buf["mem"][k * B:(k + 1) * B].copy_(memory)
-        buf["start"][k * B:(k + 1) * B].copy_(start.to(device=memory.device, dtype=torch.int64))
-        out = buf["tokens"][k * B:(k + 1) * B], buf["logits"][k * B:(k + 1) * B]
+        g["mem"][k * B:(k + 1) * B].copy_(memory)
+        g["start"][k * B:(k + 1) * B].copy_(start.to(device=memory.device, dtype=torch.int64))
+        out = g["tokens"][k * B:(k + 1) * B], g["logits"][k * B:(k + 1) * B], g["handle"]
         g["n"] += 1
         if g["n"] == G:
             self._flush_group(eng)
@@ -169,12 +194,10 @@ class Model(nn.Module):
         g = self._grp
         if g is None or g["n"] == 0:
             return
-        buf = g["ring"][g["pos"] % len(g["ring"])]
-        B = g["key"][1]
-        rows = g["n"] * B
-        eng.decode_greedy_async_into(buf["mem"][:rows], buf["start"][:rows], buf["tokens"][:rows], buf["logits"][:rows])
-        g["pos"] += 1
-        g["n"] = 0
+        rows = g["n"] * g["key"][1]
+        g["handle"].ticket = eng.decode_greedy_async_into(g["mem"][:rows], g["start"][:rows], g["tokens"][:rows],
+                                                          g["logits"][:rows])
+        self._grp = None
 
     def synchronize(self, host_sync=True, flush=True):
         """Order the current stream (and optionally the host) after every outstanding pipelined decode.  `flush` also
@@ -188,8 +211,15 @@ class Model(nn.Module):
     # -- engine plumbing -----------------------------------------------------
     def engine(self, finalize=True):
         """The libd2t context of this model, with the current weights uploaded (and packed for inference)."""
+        # the context lives where the parameters live (model.to("cuda:1") moves the engine with them); before the first
+        # .to() the reference's own device string, opt["device"] (build_pred.py:17), decides
+        p0 = next(self.parameters())
+        dev = p0.device if p0.is_cuda else None
+        if self._engine is not None and dev is not None and self._engine.device != dev.index:
+            self.synchronize()
+            self._engine, self._grp = None, None  # parameters were moved to another GPU: a fresh context there
         if self._engine is None:
-            self._engine = Engine(self.opt)
+            self._engine = Engine(self.opt, device=dev)
         self._engine.sync_weights(self, finalize=finalize)
         want = self.reserved_blocks if self.pipelined else 0
         if getattr(self._engine, "_reserved", None) != want:
@@ -225,8 +255,10 @@ class Model(nn.Module):
             # build_pred.py:36-44 -> Attention.forward (seq2seq.py:333-347)
             if self.training or is_train:
                 raise NotImplementedError(
-                    "teacher-forced LSTM-attention decoding (is_train=True / model.train()) is not implemented in "
-                    "the HIP engine; call model.eval() and pass is_train=False (engine/inferencing.py:70-76)")
+                    "forward_decoder() is the inference entry point of the HIP engine (greedy / beam decoding of an encoder "
+                    "memory): call model.eval() and pass is_train=False (engine/inferencing.py:70-76).  The teacher-forced "
+                    "training pass of the LSTM-attention head runs through Model.forward() under model.train(), which keeps "
+                    "the whole step on one autograd node")
             if beam_size > 1:  # seq2seq.py:333-347 -> forward_beam (one sample, returns (seq, score, None))
                 prediction, logits = eng.decode_attn_beam(contextual_feature.contiguous(), beam_size)
                 return prediction, logits, None, {}
@@ -234,17 +266,21 @@ class Model(nn.Module):
             return prediction, logits, None, {}
         if self.training:
             raise NotImplementedError(
-                "teacher-forced training pass (tfm.py:103-118) is not implemented in the HIP engine yet; "
-                "call model.eval() for greedy / beam decoding")
+                "forward_decoder() is the inference entry point of the HIP engine (greedy / beam decoding of an encoder "
+                "memory): call model.eval() first.  The teacher-forced training pass (tfm.py:103-118) runs through "
+                "Model.forward() under model.train(), encoder and decoder on one autograd node, so that loss.backward() "
+                "reaches the backbone")
         if beam_size > 1:
             prediction, logits = eng.decode_beam(contextual_feature.contiguous(), beam_size)
         else:
             if text.dim() != 2 or text.shape[1] != 1:
                 raise ValueError("eval decoding expects text = [B,1] start tokens ([GO])")
             if self.pipelined and not is_test and int(self.decode_group) > 1:
-                prediction, logits = self._group_decode(eng, contextual_feature.contiguous(), text[:, 0])
+                prediction, logits, handle = self._group_decode(eng, contextual_feature.contiguous(), text[:, 0])
+                return prediction, logits, None, {"decode": handle}
             elif self.pipelined and not is_test:
-                prediction, logits = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0])
+                prediction, logits, ticket = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0])
+                return prediction, logits, None, {"decode": DecodeHandle(self, eng, ticket)}
             else:
                 prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
         return prediction, logits, None, {}

@@ -94,6 +94,7 @@ struct d2t_ctx {
   bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
+  int device = 0;            // HIP device the context was created on: every stream, event and buffer lives there
 
   // packed weights
   std::string bb;  // backbone key prefix ("...ConvNet.")
@@ -128,6 +129,11 @@ struct d2t_ctx {
   hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
   bool ev_done_valid[2] = {false, false};
   unsigned decode_seq = 0;
+  // serving tickets: every asynchronous decode gets the next ticket and records ticket_ev[ticket % N] on its decode stream
+  // when its outputs are complete (d2t_decode_last_ticket / d2t_decode_wait_ticket / d2t_decode_query)
+  static constexpr int TICKET_RING = 64;
+  int64_t last_ticket = 0;
+  hipEvent_t ticket_ev[TICKET_RING] = {};
   float* skv = nullptr; size_t skv_cap = 0;
   float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
@@ -188,6 +194,29 @@ int ensure(d2t_ctx* c, T** p, size_t* cap, size_t bytes) {
   int rc = dev_alloc(c, reinterpret_cast<void**>(p), bytes);
   if (rc) return rc;
   *cap = bytes;
+  return D2T_OK;
+}
+
+// Every entry point that takes a context runs on the context's device, whatever device is current for the calling
+// thread (two Models on two GPUs in one process; a Model on cuda:1 without torch.cuda.set_device): switch on entry,
+// restore on return.
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(const d2t_ctx* c) {
+    if (!c) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
+  }
+  ~DevGuard() { if (prev >= 0) hipSetDevice(prev); }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+// a caller buffer must live on the context's device (raw pointers carry no device tag of their own)
+int check_dev_ptr(d2t_ctx* c, const void* p, const char* what) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return D2T_OK; }  // unregistered host memory etc.
+  if (a.type == hipMemoryTypeDevice && a.device != c->device)
+    return fail(c, D2T_EINVAL, "%s is on HIP device %d but this context lives on device %d", what, a.device, c->device);
   return D2T_OK;
 }
 

@@ -294,6 +294,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
     return fail(c, D2T_EINVAL, "unknown decoder %d", cfg->decoder);
   }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
+  HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
@@ -310,6 +311,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
 }
 
 void d2t_destroy(d2t_ctx* c) {
+  DevGuard dg_(c);
   if (!c) return;
   hipDeviceSynchronize();
   d2t_train_release(c);
@@ -332,6 +334,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->zero_page) hipFree(c->zero_page);
   if (c->gc_ws) hipFree(c->gc_ws);
   if (c->ev_in) hipEventDestroy(c->ev_in);
+  for (hipEvent_t ev : c->ticket_ev) if (ev) hipEventDestroy(ev);
   if (c->dstream) hipStreamDestroy(c->dstream);
   if (c->parked.skv) hipFree(c->parked.skv);
   if (c->parked.dws) hipFree(c->parked.dws);
@@ -344,9 +347,13 @@ void d2t_destroy(d2t_ctx* c) {
 
 const char* d2t_last_error(const d2t_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
+int d2t_device_of(const d2t_ctx* c) { return c ? c->device : -1; }
+
 int d2t_load_weight(d2t_ctx* c, const char* name, const float* dev, const int64_t* shape, int32_t ndim,
                     d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !name || !dev || ndim < 0 || (ndim > 0 && !shape)) return fail(c, D2T_EINVAL, "bad argument");
+  if (int rc = check_dev_ptr(c, dev, name)) return rc;
   size_t n = 1;
   std::vector<int64_t> shp(shape, shape + ndim);
   for (auto v : shp) n *= (size_t)v;
@@ -365,6 +372,7 @@ int d2t_load_weight(d2t_ctx* c, const char* name, const float* dev, const int64_
 }
 
 int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c) return D2T_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipDeviceSynchronize();
@@ -668,8 +676,11 @@ int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_
 }
 
 int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, float* memory, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !image || !memory || B < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (int rc = check_dev_ptr(c, image, "image")) return rc;
+  if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const d2t_config& g = c->cfg;
   int T, dim, gh, gw, pw, ph;
@@ -928,7 +939,8 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   int64_t* const user_tokens = tokens;
   float* const user_logits = logits;
   const size_t tok_bytes = (size_t)B * S * sizeof(int64_t), log_bytes = (size_t)B * S * V * sizeof(float);
-  if (async && use_graph) {  // engine-owned staging: [logits | tokens]
+  if (use_graph) {  // engine-owned staging [logits | tokens] on both paths: the graph key holds engine addresses only, so a
+                    // caller that allocates fresh output tensors per call (Model.forward does) never forces a re-capture
     if ((rc = ensure(c, &c->dout, &c->dout_cap, log_bytes + tok_bytes))) return rc;
     logits = c->dout;
     tokens = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(c->dout) + log_bytes);
@@ -982,7 +994,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
       e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
       hipGraphDestroy(gr);
       if (e != hipSuccess) return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      if (c->graphs.size() >= 8) {  // evict the least recently used; it may still be queued on a decode stream
+      if (c->graphs.size() >= 16) {  // evict the least recently used; it may still be queued on a decode stream
         HIPCHK(c, hipStreamSynchronize(c->dstream));
         HIPCHK(c, hipStreamSynchronize(c->parked.stream));
         hipGraphExecDestroy(c->graphs.front().exec);
@@ -1007,6 +1019,12 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   }
   HIPCHK(c, hipEventRecord(c->ev_done[slot], s));
   c->ev_done_valid[slot] = true;
+  if (async) {  // serving ticket: this decode's outputs are complete once its event has fired
+    const int64_t t = ++c->last_ticket;
+    hipEvent_t& ev = c->ticket_ev[t % d2t_ctx::TICKET_RING];
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(ev, s));
+  }
   if (!async) HIPCHK(c, hipStreamSynchronize(s));
   if (steps_out) *steps_out = steps;
   return D2T_OK;
@@ -1015,16 +1033,20 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
 
 int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
                       int32_t is_test, int64_t* tokens, float* logits, int32_t* steps_out, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !memory || !start_tokens || !tokens || !logits || !steps_out || B < 1 || T < 1)
     return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
+  if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
+  if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
   return greedy_impl(c, memory, B, T, start_tokens, is_test, tokens, logits, steps_out, (hipStream_t)stream, false);
 }
 
 int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, int32_t is_test, int64_t* tokens,
                            float* probs, int32_t* steps_out, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !memory || !tokens || !probs || !steps_out || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   const d2t_config& g = c->cfg;
@@ -1071,6 +1093,7 @@ int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T
 
 int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
                          float* score_out, d2t_stream stream) {
+  DevGuard dg_(c);
   // Attention.forward_beam (prediction_head/seq2seq.py:83-222) / AttentionV2.forward_beam (seq2seq_v2.py:12-174) for
   // one sample: the attention cell + LSTMCell + generator of every live hypothesis run as ONE launch per step (the
   // greedy kernel in step mode, one block per hypothesis, keys shared), log_softmax + flat top-k on the device, the
@@ -1219,6 +1242,7 @@ int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t bea
 
 int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
                                int32_t* len_out, float* score_out, d2t_stream stream) {
+  DevGuard dg_(c);
   // Attention / AttentionV2.forward_beam for N samples in one step loop: rows = live hypotheses of all samples, each
   // attending over its own sample's keys (row map); log_softmax + top-k per sample segment; per-sample bookkeeping
   // exactly as in d2t_decode_attn_beam (whose results this reproduces sample by sample).
@@ -1390,14 +1414,18 @@ int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32
 
 int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
                             int64_t* tokens, float* logits, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
+  if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
+  if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
   return greedy_impl(c, memory, B, T, start_tokens, 0, tokens, logits, nullptr, (hipStream_t)stream, true);
 }
 
 int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
+  DevGuard dg_(c);
   if (!c) return D2T_EINVAL;
   for (int i = 0; i < 2; ++i)
     if (c->ev_done_valid[i]) HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_done[i], 0));
@@ -1408,8 +1436,34 @@ int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
   return D2T_OK;
 }
 
+int64_t d2t_decode_last_ticket(const d2t_ctx* c) { return c ? c->last_ticket : 0; }
+
+// 1: the decode with this ticket has completed; 0: still running; < 0: error.  Tickets older than the event ring are
+// complete by construction: a chain is an in-order stream and the ring holds TICKET_RING >> 2 chains' worth of decodes.
+int d2t_decode_query(d2t_ctx* c, int64_t ticket) {
+  DevGuard dg_(c);
+  if (!c || ticket < 1 || ticket > c->last_ticket) return -D2T_EINVAL;
+  if (ticket + d2t_ctx::TICKET_RING <= c->last_ticket) return 1;
+  const hipError_t e = hipEventQuery(c->ticket_ev[ticket % d2t_ctx::TICKET_RING]);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  fail(c, D2T_EHIP, "hipEventQuery: %s", hipGetErrorString(e));
+  return -D2T_EHIP;
+}
+
+int d2t_decode_wait_ticket(d2t_ctx* c, int64_t ticket, d2t_stream stream, int32_t host_sync) {
+  DevGuard dg_(c);
+  if (!c || ticket < 1 || ticket > c->last_ticket) return fail(c, D2T_EINVAL, "unknown decode ticket %lld", (long long)ticket);
+  if (ticket + d2t_ctx::TICKET_RING <= c->last_ticket) return D2T_OK;  // long since complete
+  hipEvent_t ev = c->ticket_ev[ticket % d2t_ctx::TICKET_RING];
+  HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+  if (host_sync) HIPCHK(c, hipEventSynchronize(ev));
+  return D2T_OK;
+}
+
 int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
                     float* score_out, d2t_stream stream) {
+  DevGuard dg_(c);
   // TransformerPrediction.forward_beam (tfm.py:145-186) with tools/beam.py:38-140 bookkeeping on the
   // host; a fresh beam per call (demo reset_beam semantics).  The model runs KV-cached on
   // the device for the live hypotheses only; log_softmax + flat top-k run on the device too, so each
@@ -1534,6 +1588,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
 
 int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T, int32_t beam_size, int64_t* seq_out,
                           int32_t* len_out, float* score_out, d2t_stream stream) {
+  DevGuard dg_(c);
   // forward_beam (tfm.py:145-186) + Beam (tools/beam.py) for N samples AT ONCE: the hypotheses of all samples are rows
   // of one step loop (each row attends over its own sample's cross K/V through a row map), log_softmax + top-k run per
   // sample segment, the bookkeeping of every sample is the single-sample one.  Results equal N calls of
@@ -1677,6 +1732,7 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
 }
 
 int d2t_set_reserved_blocks(d2t_ctx* c, int32_t blocks) {
+  DevGuard dg_(c);
   if (!c || blocks < 0) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->num_cus) {
     hipDeviceProp_t prop;
@@ -1692,24 +1748,28 @@ int d2t_set_reserved_blocks(d2t_ctx* c, int32_t blocks) {
 }
 
 int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
+  DevGuard dg_(c);
   if (!c || chains < 1 || chains > 2) return fail(c, D2T_EINVAL, "decode chains must be 1 or 2");
   c->n_chains = chains;
   return D2T_OK;
 }
 
 int d2t_set_conv_precision(d2t_ctx* c, int32_t mode) {
+  DevGuard dg_(c);
   if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3)) return fail(c, D2T_EINVAL, "unknown conv precision %d", mode);
   c->conv_bf16x3 = mode == D2T_CONV_BF16X3;
   return D2T_OK;
 }
 
 int d2t_profile_enable(d2t_ctx* c, int32_t on) {
+  DevGuard dg_(c);
   if (!c) return D2T_EINVAL;
   c->profiling = on != 0;
   return D2T_OK;
 }
 
 int d2t_profile_read(d2t_ctx* c, int32_t max_records, int32_t* n, int32_t* M, int32_t* N, int32_t* K, float* ms) {
+  DevGuard dg_(c);
   if (!c || !n) return D2T_EINVAL;
   HIPCHK(c, hipDeviceSynchronize());
   int out = 0;

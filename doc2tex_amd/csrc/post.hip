@@ -37,18 +37,21 @@ bool in_ranges(const CpRange* r, int n, uint32_t cp) {
 
 enum : uint8_t { C_LETTER = 1, C_NOLETTER = 2, C_SPACE = 4 };
 
-uint8_t classify(uint32_t cp) {
-  static uint8_t ascii[128];
-  static bool init = false;
-  if (!init) {
+struct AsciiClasses {  // built once, thread-safely (function-local static of a constructed object): d2t_post_* may be called
+  uint8_t v[128];      // from several serving threads at once
+  AsciiClasses() {
     for (uint32_t c = 0; c < 128; ++c) {
       const bool alpha = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'), digit = c >= '0' && c <= '9';
       const bool space = c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f);
-      ascii[c] = (alpha ? C_LETTER : 0) | ((!alpha && !digit && c != '_') || digit || c == '_' || c == '^' ? C_NOLETTER : 0) |
-                 (space ? C_SPACE : 0);
+      v[c] = (alpha ? C_LETTER : 0) | ((!alpha && !digit && c != '_') || digit || c == '_' || c == '^' ? C_NOLETTER : 0) |
+             (space ? C_SPACE : 0);
     }
-    init = true;
   }
+};
+
+uint8_t classify(uint32_t cp) {
+  static const AsciiClasses table;
+  const uint8_t* ascii = table.v;
   if (cp < 128) return ascii[cp];
   const bool word = in_ranges(kAlnumRanges, kAlnumRanges_n, cp);  // \w (the underscore is ASCII)
   const bool dec = in_ranges(kDecimalRanges, kDecimalRanges_n, cp);

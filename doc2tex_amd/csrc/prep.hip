@@ -597,6 +597,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     AxisTab t;
   };
   std::vector<Miss> miss;
+  std::vector<std::pair<TabKey, DevTab>> new_tabs;  // this call's new tables (committed to dev_tabs after their upload)
   auto need_tab = [&](int in, int out, int kind) {
     TabKey key{in, out, kind};
     if (p->dev_tabs.count(key)) return;
@@ -679,6 +680,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
   {
     int32_t* hw = reinterpret_cast<int32_t*>(st.h + desc_bytes);
     size_t at = 0;
+    new_tabs.reserve(miss.size());
     for (auto& m : miss) {
       const AxisTab& t = m.t;
       DevTab dt;
@@ -695,10 +697,18 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
         memcpy(hw + at, t.coef.data(), t.coef.size() * 4);
       }
       at += t.coef.size();
-      p->dev_tabs.emplace(m.key, dt);
+      new_tabs.emplace_back(m.key, dt);
     }
     if (at != new_words) return fail(p, D2T_EINVAL, "d2t_prep_run: internal table size mismatch");
   }
+  // tables of this call that are not resident yet: visible to the descriptor loop below, but entered into the
+  // resident map only once their upload has been enqueued (an error return in between must not leave map entries
+  // that point at arena words which were never written)
+  auto tab_at = [&](const TabKey& k) -> const DevTab& {
+    for (auto& kv : new_tabs)
+      if (kv.first == k) return kv.second;
+    return p->dev_tabs.at(k);
+  };
 
   // ---- descriptors ----------------------------------------------------------------------------------------------------
   PrepDesc* descs = reinterpret_cast<PrepDesc*>(st.h);
@@ -722,9 +732,9 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
         d.do_ds = 2, d.ds_fx = (int)sx, d.ds_fy = (int)sy;
       } else {
         d.do_ds = 3;
-        const DevTab& ax = p->dev_tabs.at(TabKey{pl.src_w, pl.ds_w, K_AREA});
+        const DevTab& ax = tab_at(TabKey{pl.src_w, pl.ds_w, K_AREA});
         d.axb = ax.b, d.axk = ax.k, d.axs = ax.ks;
-        const DevTab& ay = p->dev_tabs.at(TabKey{pl.src_h, pl.ds_h, K_AREA});
+        const DevTab& ay = tab_at(TabKey{pl.src_h, pl.ds_h, K_AREA});
         d.ayb = ay.b, d.ayk = ay.k, d.ays = ay.ks;
       }
       d.ds_off = (int64_t)work;
@@ -734,7 +744,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     }
     if (!d.fallback && pl.rs_w != pl.ds_w) {  // ImagingResample: horizontal pass only when the width changes
       d.do_h = 1;
-      const DevTab& t = p->dev_tabs.at(TabKey{pl.ds_w, pl.rs_w, K_HORZ});
+      const DevTab& t = tab_at(TabKey{pl.ds_w, pl.rs_w, K_HORZ});
       d.hb = t.b, d.hk = t.k, d.hks = t.ks;
       d.hp_off = (int64_t)work;
       work += ((size_t)pl.ds_h * pl.rs_w + 15) & ~(size_t)15;
@@ -743,7 +753,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
     }
     if (!d.fallback && pl.rs_h != pl.ds_h) {
       d.do_v = 1;
-      const DevTab& t = p->dev_tabs.at(TabKey{pl.ds_h, pl.rs_h, K_VERT});
+      const DevTab& t = tab_at(TabKey{pl.ds_h, pl.rs_h, K_VERT});
       d.vb = t.b, d.vk = t.k, d.vks = t.ks;
     }
     if (d.fallback) d.rs_h = std::min(pl.ds_h, out_h), d.rs_w = pl.ds_w;  // F.pad with a negative amount crops
@@ -765,6 +775,7 @@ int d2t_prep_run(d2t_prep* p, int n, const d2t_prep_plan* plans, const uint8_t* 
   if (new_words)
     PHIP(p, hipMemcpyAsync(p->d_arena + p->arena_used, st.h + desc_bytes, new_words * 4, hipMemcpyHostToDevice, stream));
   p->arena_used += new_words;
+  for (auto& kv : new_tabs) p->dev_tabs.emplace(kv.first, kv.second);
   PHIP(p, hipEventRecord(st.done, stream));
   st.pending = true;
   const PrepDesc* d_descs = reinterpret_cast<const PrepDesc*>(st.d);

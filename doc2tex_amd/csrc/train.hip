@@ -953,7 +953,10 @@ extern "C" {
 
 int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, const int64_t* tgt, int32_t L,
                       float* logits, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !image || !tgt || !logits || B < 1 || H < 1 || W < 1 || L < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (int rc = check_dev_ptr(c, image, "image")) return rc;
+  if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
   const d2t_config& g = c->cfg;
   const bool lstm = g.decoder == D2T_DEC_ATTN;
   if (g.encoder != D2T_ENC_HYBRID_VIT && g.encoder != D2T_ENC_RESNET)
@@ -993,6 +996,7 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
 }
 
 int d2t_train_backward(d2t_ctx* c, const float* dlogits, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !dlogits) return fail(c, D2T_EINVAL, "bad argument");
   d2t_train_state* st = c->train;
   if (!st || !st->have_forward) return fail(c, D2T_ESTATE, "d2t_train_backward without a preceding d2t_train_forward");
@@ -1004,6 +1008,7 @@ int d2t_train_backward(d2t_ctx* c, const float* dlogits, d2t_stream stream) {
 }
 
 int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !name || !dst) return fail(c, D2T_EINVAL, "bad argument");
   d2t_train_state* st = c->train;
   if (!st) return fail(c, D2T_ESTATE, "no training step has run");
@@ -1018,6 +1023,7 @@ int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_
 }
 
 int d2t_read_weight(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !name || !dst) return fail(c, D2T_EINVAL, "bad argument");
   const RawW* r = find(c, name);
   if (!r) return fail(c, D2T_ESTATE, "unknown tensor '%s'", name);
@@ -1027,6 +1033,7 @@ int d2t_read_weight(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t
 }
 
 int d2t_train_set_dropout(d2t_ctx* c, float p, uint64_t seed) {
+  DevGuard dg_(c);
   if (!c || !(p >= 0.f) || p >= 1.f) return fail(c, D2T_EINVAL, "dropout probability must be in [0, 1)");
   if (!c->train) c->train = new d2t_train_state();
   if (c->train->drop_seed != seed) c->train->drop_calls = 0;
@@ -1036,6 +1043,7 @@ int d2t_train_set_dropout(d2t_ctx* c, float p, uint64_t seed) {
 }
 
 int d2t_train_set_teacher_flags(d2t_ctx* c, const uint8_t* flags, int32_t n) {
+  DevGuard dg_(c);
   if (!c || n < 0 || (n > 0 && !flags)) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->train) c->train = new d2t_train_state();
   c->train->teacher_flags.assign(flags, flags + n);
@@ -1043,6 +1051,7 @@ int d2t_train_set_teacher_flags(d2t_ctx* c, const uint8_t* flags, int32_t n) {
 }
 
 int d2t_train_read_mask(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t numel, d2t_stream stream) {
+  DevGuard dg_(c);
   if (!c || !dst) return fail(c, D2T_EINVAL, "bad argument");
   d2t_train_state* st = c->train;
   if (!st || index < 0 || (size_t)index >= st->masks.size()) return fail(c, D2T_EINVAL, "no dropout mask %d", index);
@@ -1054,11 +1063,196 @@ int d2t_train_read_mask(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t numel, 
 int d2t_train_mask_count(d2t_ctx* c) { return c && c->train ? (int)c->train->masks.size() : 0; }
 
 void d2t_train_release(d2t_ctx* c) {
+  DevGuard dg_(c);
   if (c && c->train) {
     hipDeviceSynchronize();
     delete c->train;
     c->train = nullptr;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Op-level test entry points: ONE node of the training tape, forward + backward, on caller tensors (row-major
+// [rows][cols], NHWC maps).  They drive exactly the builders / backward functions the full step uses (a throw-away
+// context holds the operands under fake keys), so tests/test_ops_gpu.py can hold every backward kernel -- data gradients,
+// weight gradients in both arithmetic modes, BatchNorm / LayerNorm / attention / max-pool backward -- against float64
+// torch autograd one op at a time.  Synchronous; not on any hot path.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct OpCtx {
+  d2t_ctx c;
+  d2t_train_state st;
+  Tr tr;
+  OpCtx(int bf16x3, hipStream_t s) : tr{&c, &st, s} {
+    c.conv_bf16x3 = bf16x3 != 0;
+    hipGetDevice(&c.device);
+  }
+  void put(const char* key, const float* p, std::vector<int64_t> shape) {
+    RawW r;
+    r.p = const_cast<float*>(p);
+    r.shape = shape;
+    r.numel = 1;
+    for (auto v : shape) r.numel *= (size_t)v;
+    c.raw[key] = r;
+  }
+  int out(float* dst, const float* src, size_t n) {
+    if (!dst) return D2T_OK;
+    if (!src) return hipMemsetAsync(dst, 0, n * 4, tr.s) == hipSuccess ? D2T_OK : D2T_EHIP;
+    return hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, tr.s) == hipSuccess ? D2T_OK : D2T_EHIP;
+  }
+  int grad(float* dst, const char* key, size_t n) {
+    auto it = st.grads.find(key);
+    return out(dst, it == st.grads.end() ? nullptr : it->second, n);
+  }
+  int finish(int rc) {
+    hipStreamSynchronize(tr.s);
+    c.raw.clear();  // caller memory: nothing to free
+    return rc;
+  }
+};
+}  // namespace
+
+int d2t_op_train_conv(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                      const float* residual, const float* dy, float* y, float* dx, float* dw, float* dbias,
+                      float* dgamma, float* dbeta, float* dres, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                      int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t relu,
+                      int32_t bf16x3, d2t_stream stream) {
+  if (!x || !w || !dy || (gamma && !beta) || (!gamma && !bias && Cin != 1) || SH < 1 || SW < 1) return D2T_EINVAL;
+  if (Cin != 1 && Cin % 32) return D2T_EINVAL;
+  OpCtx o(bf16x3, (hipStream_t)stream);
+  Tr& tr = o.tr;
+  o.put("w.weight", w, {Cout, Cin, KH, KW});
+  if (bias) o.put("w.bias", bias, {Cout});
+  float *rm = nullptr, *rv = nullptr;
+  if (gamma) {
+    o.put("bn.weight", gamma, {Cout});
+    o.put("bn.bias", beta, {Cout});
+    RC(tr.zeros(&rm, Cout));
+    RC(tr.zeros(&rv, Cout));
+    o.put("bn.running_mean", rm, {Cout});
+    o.put("bn.running_var", rv, {Cout});
+  }
+  int xin = -1, res = -1, out = -1;
+  auto run = [&]() -> int {
+    if (Cin == 1) {  // the stem: 3x3, stride 1, pad 1, BatchNorm + ReLU (resnet.py:205-207)
+      if (KH != 3 || KW != 3 || SH != 1 || SW != 1 || PH != 1 || PW != 1 || !gamma || residual || !relu || Cout != 32)
+        return fail(&o.c, D2T_EINVAL, "stem geometry");
+      o.st.image = x; o.st.B = B; o.st.H = H; o.st.W = W;
+      RC(tr.stem(x, B, H, W, "w", "bn", &out));
+    } else {
+      RC(tr.new_tensor((long long)B * H * W, Cin, &xin, B, H, W, const_cast<float*>(x)));
+      const int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+      if (residual) RC(tr.new_tensor((long long)B * OH * OW, Cout, &res, B, OH, OW, const_cast<float*>(residual)));
+      RC(tr.conv_bn(xin, "w", gamma ? "bn" : "", Cout, KH, KW, SH, SW, PH, PW, relu != 0, res, &out));
+    }
+    const TT yo = o.st.t[out];
+    RC(o.out(y, yo.p, (size_t)yo.rows * yo.cols));
+    o.st.t[out].grad = const_cast<float*>(dy);
+    RC(tr.backward());
+    if (xin >= 0) RC(o.out(dx, o.st.t[xin].grad, (size_t)B * H * W * Cin));
+    if (res >= 0) RC(o.out(dres, o.st.t[res].grad, (size_t)yo.rows * yo.cols));
+    RC(o.grad(dw, "w.weight", (size_t)Cout * Cin * KH * KW));
+    if (bias && !gamma) RC(o.grad(dbias, "w.bias", Cout));
+    if (gamma) { RC(o.grad(dgamma, "bn.weight", Cout)); RC(o.grad(dbeta, "bn.bias", Cout)); }
+    return D2T_OK;
+  };
+  return o.finish(run());
+}
+
+int d2t_op_train_linear(const float* x, const float* w, const float* bias, const float* residual, const float* dy, float* y,
+                        float* dx, float* dw, float* dbias, float* dres, int32_t M, int32_t K, int32_t N, int32_t relu,
+                        int32_t bf16x3, d2t_stream stream) {
+  if (!x || !w || !bias || !dy || K % 32) return D2T_EINVAL;
+  OpCtx o(bf16x3, (hipStream_t)stream);
+  Tr& tr = o.tr;
+  o.put("l.weight", w, {N, K});
+  o.put("l.bias", bias, {N});
+  auto run = [&]() -> int {
+    int xin, res = -1, out;
+    RC(tr.new_tensor(M, K, &xin, 0, 0, 0, const_cast<float*>(x)));
+    if (residual) RC(tr.new_tensor(M, N, &res, 0, 0, 0, const_cast<float*>(residual)));
+    RC(tr.linear(xin, "l", N, K, 0, relu ? ACT_RELU : ACT_NONE, res, &out));
+    RC(o.out(y, o.st.t[out].p, (size_t)M * N));
+    o.st.t[out].grad = const_cast<float*>(dy);
+    RC(tr.backward());
+    RC(o.out(dx, o.st.t[xin].grad, (size_t)M * K));
+    if (res >= 0) RC(o.out(dres, o.st.t[res].grad, (size_t)M * N));
+    RC(o.grad(dw, "l.weight", (size_t)N * K));
+    RC(o.grad(dbias, "l.bias", N));
+    return D2T_OK;
+  };
+  return o.finish(run());
+}
+
+int d2t_op_train_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, float* dx,
+                           float* dgamma, float* dbeta, int32_t rows, int32_t D, float eps, d2t_stream stream) {
+  if (!x || !gamma || !beta || !dy) return D2T_EINVAL;
+  OpCtx o(0, (hipStream_t)stream);
+  Tr& tr = o.tr;
+  o.put("n.weight", gamma, {D});
+  o.put("n.bias", beta, {D});
+  auto run = [&]() -> int {
+    int xin, out;
+    RC(tr.new_tensor(rows, D, &xin, 0, 0, 0, const_cast<float*>(x)));
+    RC(tr.layernorm(xin, "n", eps, &out));
+    RC(o.out(y, o.st.t[out].p, (size_t)rows * D));
+    o.st.t[out].grad = const_cast<float*>(dy);
+    RC(tr.backward());
+    RC(o.out(dx, o.st.t[xin].grad, (size_t)rows * D));
+    RC(o.grad(dgamma, "n.weight", D));
+    RC(o.grad(dbeta, "n.bias", D));
+    return D2T_OK;
+  };
+  return o.finish(run());
+}
+
+// q [nb*Lq][heads*hd], kv [nb*Lk][2*heads*hd] (keys in the first half of a row, values in the second); keytok: optional
+// [nb][Lk] token ids whose PAD (0) entries are masked out (tgt_key_padding_mask, tfm.py:107-110); causal: additive -inf mask
+int d2t_op_train_attention(const float* q, const float* kv, const int64_t* keytok, const float* dy, float* y, float* dq,
+                           float* dkv, int32_t nb, int32_t Lq, int32_t Lk, int32_t heads, int32_t hd, int32_t causal,
+                           d2t_stream stream) {
+  if (!q || !kv || !dy) return D2T_EINVAL;
+  OpCtx o(0, (hipStream_t)stream);
+  Tr& tr = o.tr;
+  auto run = [&]() -> int {
+    const int D = heads * hd;
+    int qt, kt, out;
+    RC(tr.new_tensor((long long)nb * Lq, D, &qt, 0, 0, 0, const_cast<float*>(q)));
+    RC(tr.new_tensor((long long)nb * Lk, 2 * D, &kt, 0, 0, 0, const_cast<float*>(kv)));
+    RC(tr.attention(qt, 0, kt, 0, D, nb, Lq, Lk, heads, hd, causal, keytok, &out));
+    RC(o.out(y, o.st.t[out].p, (size_t)nb * Lq * D));
+    float* g;  // the backward overwrites the incoming gradient's buffer in places: give it a private copy
+    RC(tr.alloc(&g, (size_t)nb * Lq * D));
+    RC(o.out(g, dy, (size_t)nb * Lq * D));
+    o.st.t[out].grad = g;
+    RC(tr.zeros(&o.st.t[qt].grad, (size_t)nb * Lq * D));
+    RC(tr.zeros(&o.st.t[kt].grad, (size_t)nb * Lk * 2 * D));
+    RC(tr.backward());
+    RC(o.out(dq, o.st.t[qt].grad, (size_t)nb * Lq * D));
+    RC(o.out(dkv, o.st.t[kt].grad, (size_t)nb * Lk * 2 * D));
+    return D2T_OK;
+  };
+  return o.finish(run());
+}
+
+int d2t_op_train_maxpool(const float* x, const float* dy, float* y, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t SH, int32_t SW, int32_t PH, int32_t PW, d2t_stream stream) {
+  if (!x || !dy) return D2T_EINVAL;
+  OpCtx o(0, (hipStream_t)stream);
+  Tr& tr = o.tr;
+  auto run = [&]() -> int {
+    int xin, out;
+    RC(tr.new_tensor((long long)B * H * W, C, &xin, B, H, W, const_cast<float*>(x)));
+    RC(tr.pool(xin, SH, SW, PH, PW, &out));
+    const TT yo = o.st.t[out];
+    RC(o.out(y, yo.p, (size_t)yo.rows * C));
+    o.st.t[out].grad = const_cast<float*>(dy);
+    RC(tr.backward());
+    RC(o.out(dx, o.st.t[xin].grad, (size_t)B * H * W * C));
+    return D2T_OK;
+  };
+  return o.finish(run());
 }
 
 }  // extern "C"

@@ -82,19 +82,43 @@ def config_from_opt(opt):
     return cfg
 
 
+def device_index(device):
+    """opt["device"] as the reference passes it around ('cuda', 'cuda:1', a torch.device, None) -> HIP device index."""
+    if device is None or (isinstance(device, str) and device in ("", "cpu")):
+        return torch.cuda.current_device()  # the engine has no CPU path; 'cpu' configs get the current GPU
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"doc2tex_amd: device '{device}' is not a ROCm (cuda) device; the engine has no CPU path")
+    return torch.cuda.current_device() if d.index is None else int(d.index)
+
+
 class Engine:
-    def __init__(self, opt):
+    def __init__(self, opt, device=None):
         self.lib = _lib.require_device()
         self.cfg = config_from_opt(opt)
         self.ctx = C.c_void_p()
-        rc = self.lib.d2t_create(C.byref(self.cfg), C.byref(self.ctx))
+        # the context lives on ONE device: opt["device"] (build_pred.py:17) unless the module has been moved since
+        self.device = device_index(opt.get("device") if device is None else device)
+        if not 0 <= self.device < torch.cuda.device_count():
+            raise RuntimeError(f"doc2tex_amd: no HIP device {self.device} (visible: {torch.cuda.device_count()})")
+        with torch.cuda.device(self.device):
+            rc = self.lib.d2t_create(C.byref(self.cfg), C.byref(self.ctx))
         if rc != _lib.D2T_OK:
             msg = self.lib.d2t_last_error(self.ctx).decode() if self.ctx else ""
             if self.ctx:
                 self.lib.d2t_destroy(self.ctx)
             self.ctx = None
             raise RuntimeError(f"d2t_create failed (code {rc}): {msg}")
+        assert self.lib.d2t_device_of(self.ctx) == self.device
         self._sig = None
+
+    def _on_device(self, t, what):
+        """Tensors handed to the context must live on its device (the C side checks the raw pointers too)."""
+        if not t.is_cuda:
+            raise RuntimeError(f"doc2tex_amd: {what} must be a ROCm (cuda) tensor; the engine has no CPU path")
+        if t.device.index != self.device:
+            raise RuntimeError(f"doc2tex_amd: {what} is on {t.device} but this model's engine lives on cuda:{self.device}; "
+                               "move the input, or the Model with .to(device), so that they agree")
 
     def __del__(self):
         ctx, self.ctx = getattr(self, "ctx", None), None
@@ -126,6 +150,7 @@ class Engine:
         for name, t in items:
             if not t.is_cuda:
                 raise RuntimeError(f"doc2tex_amd: parameter '{name}' is on {t.device}; move the Model to the GPU")
+            self._on_device(t, f"parameter '{name}'")
             td = t.detach()
             if td.dtype != torch.float32 or not td.is_contiguous():
                 td = td.float().contiguous()
@@ -143,10 +168,9 @@ class Engine:
     def train_forward(self, image, tgt):
         """Model.forward under module.train(): logits [B,L,V] of the teacher-forced pass (BatchNorm on batch
         statistics; the engine's running statistics are updated, see read_weight)."""
-        if not image.is_cuda:
-            raise RuntimeError("doc2tex_amd: input must be a ROCm (cuda) tensor; the engine has no CPU path")
+        self._on_device(image, "input")
         image = image.float().contiguous()
-        tgt = tgt.to(torch.int64).contiguous()
+        tgt = tgt.to(device=image.device, dtype=torch.int64).contiguous()
         B, _, H, W = image.shape
         L = tgt.shape[1]
         logits = torch.empty((B, L, self.cfg.vocab), dtype=torch.float32, device=image.device)
@@ -169,7 +193,7 @@ class Engine:
         return int(self.lib.d2t_train_mask_count(self.ctx))
 
     def read_mask(self, index, numel):
-        m = torch.empty(int(numel), dtype=torch.uint8, device="cuda")
+        m = torch.empty(int(numel), dtype=torch.uint8, device=f"cuda:{self.device}")
         self._check(self.lib.d2t_train_read_mask(self.ctx, int(index), _lib.ptr(m), int(numel), _lib.stream_of(m)), "train_read_mask")
         return m
 
@@ -203,8 +227,7 @@ class Engine:
         return T, d, gh, gw, pw, ph
 
     def encode(self, image):
-        if not image.is_cuda:
-            raise RuntimeError("doc2tex_amd: input must be a ROCm (cuda) tensor; the engine has no CPU path")
+        self._on_device(image, "input")
         if image.dim() != 4 or image.shape[1] != 1:
             raise ValueError(f"expected image [B,1,H,W], got {tuple(image.shape)}")
         image = image.float().contiguous()
@@ -240,6 +263,7 @@ class Engine:
 
     # ---- decoder -----------------------------------------------------------
     def decode_greedy(self, memory, start_tokens, is_test):
+        self._on_device(memory, "memory")
         memory = memory.float().contiguous()
         B, T, _ = memory.shape
         S, V = self.cfg.max_seq_len + 1, self.cfg.vocab
@@ -266,36 +290,49 @@ class Engine:
                                                     _lib.stream_of(memory)), "decode_attn_greedy")
         return tokens, probs
 
-    def decode_greedy_async(self, memory, start_tokens, ring=4):
-        """Pipelined greedy decode (always max_seq_len+1 steps): returns views of engine-held
-        ring buffers that become valid after decode_wait(); at most `ring` - 1 later calls may be
-        issued before the result is consumed."""
+    def decode_greedy_async(self, memory, start_tokens):
+        """Pipelined greedy decode (always max_seq_len+1 steps): returns (tokens, logits, ticket).  The tensors are fresh
+        allocations written by the engine's decode stream; they are valid once `ticket` is complete (wait_ticket /
+        decode_wait) and are never recycled behind the caller's back -- the engine keeps them alive until then."""
+        self._on_device(memory, "memory")
         memory = memory.float().contiguous()
         B, T, _ = memory.shape
         S, V = self.cfg.max_seq_len + 1, self.cfg.vocab
-        key = (B, S, V, memory.device)
-        if getattr(self, "_ring_key", None) != key:
-            self.decode_wait(host_sync=True)
-            self._ring = [(torch.zeros((B,), dtype=torch.int64, device=memory.device),
-                           torch.zeros((B, S), dtype=torch.int64, device=memory.device),
-                           torch.zeros((B, S, V), dtype=torch.float32, device=memory.device)) for _ in range(ring)]
-            self._ring_key, self._ring_pos = key, 0
-        start, tokens, logits = self._ring[self._ring_pos % len(self._ring)]
-        self._ring_pos += 1
-        start.copy_(start_tokens.to(device=memory.device, dtype=torch.int64))
-        self._check(self.lib.d2t_decode_greedy_async(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start),
-                                                     _lib.ptr(tokens), _lib.ptr(logits), _lib.stream_of(memory)),
-                    "decode_greedy_async")
-        self._wait_dev = memory.device
-        return tokens, logits
+        start = start_tokens.to(device=memory.device, dtype=torch.int64).contiguous()
+        tokens = torch.empty((B, S), dtype=torch.int64, device=memory.device)
+        logits = torch.empty((B, S, V), dtype=torch.float32, device=memory.device)
+        ticket = self.decode_greedy_async_into(memory, start, tokens, logits)
+        return tokens, logits, ticket
 
     def decode_greedy_async_into(self, memory, start, tokens, logits):
-        """d2t_decode_greedy_async on caller-held buffers (which must stay untouched until decode_wait)."""
+        """d2t_decode_greedy_async on caller-held buffers; returns the decode's ticket.  The buffers are referenced here
+        until the ticket completes, so dropping them early cannot hand their memory to another allocation mid-write."""
         B, T, _ = memory.shape
         self._check(self.lib.d2t_decode_greedy_async(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start),
                                                      _lib.ptr(tokens), _lib.ptr(logits), _lib.stream_of(memory)),
                     "decode_greedy_async")
         self._wait_dev = memory.device
+        ticket = int(self.lib.d2t_decode_last_ticket(self.ctx))
+        held = getattr(self, "_held", None)
+        if held is None:
+            held = self._held = []
+        held.append((ticket, (memory, start, tokens, logits)))
+        while held and self.ticket_done(held[0][0]):  # tickets complete in order per chain; at most a few stay pending
+            held.pop(0)
+        if len(held) > 48:  # the C side keeps 64 ticket events: never let a live ticket fall out of its ring
+            self.wait_ticket(held[0][0], host_sync=True)
+        return ticket
+
+    def ticket_done(self, ticket):
+        r = int(self.lib.d2t_decode_query(self.ctx, int(ticket)))
+        if r < 0:
+            self._check(-r, "decode_query")
+        return r == 1
+
+    def wait_ticket(self, ticket, host_sync=False):
+        """Order the current stream (and the host, if asked) after the decode with this ticket -- and only that one."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._check(self.lib.d2t_decode_wait_ticket(self.ctx, int(ticket), stream, int(bool(host_sync))), "decode_wait_ticket")
 
     def decode_wait(self, host_sync=False):
         dev = getattr(self, "_wait_dev", None)
@@ -303,6 +340,8 @@ class Engine:
             return
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self._check(self.lib.d2t_decode_wait(self.ctx, stream, int(bool(host_sync))), "decode_wait")
+        if host_sync:
+            self._held = []
 
     def decode_attn_beam(self, memory, beam_size):
         """Attention.forward_beam / AttentionV2.forward_beam for one sample: (LongTensor [1, n] on the CPU, score)."""

@@ -106,10 +106,17 @@ typedef struct d2t_config {
   int32_t gcb;              /* 1: GlobalContext blocks close the four ResNet stages (gcb: True) */
 } d2t_config;
 
-/* ---- lifecycle ---------------------------------------------------------- */
+/* ---- lifecycle ----------------------------------------------------------
+ * d2t_create binds the context to the HIP device that is current for the calling thread (the reference picks its
+ * device from the string opt["device"], build_pred.py:17 -- the Python layer above translates "cuda:N" into
+ * hipSetDevice(N) around this call).  Every stream, event and buffer of the context lives on that device and every
+ * later call switches to it on entry and restores the caller's device on return, so two contexts on two GPUs can be
+ * driven from one thread.  Caller buffers on another device are rejected with D2T_EINVAL. */
 int d2t_create(const d2t_config* cfg, d2t_ctx** out);
 void d2t_destroy(d2t_ctx* ctx);
 const char* d2t_last_error(const d2t_ctx* ctx);
+/* HIP device index the context was created on (-1 for a null ctx). */
+int d2t_device_of(const d2t_ctx* ctx);
 /* 1 if a HIP device is usable from this process, else 0 (no ctx needed). */
 int d2t_device_available(void);
 
@@ -169,6 +176,14 @@ int d2t_decode_attn_greedy(d2t_ctx* ctx, const float* memory_dev, int32_t B, int
 int d2t_decode_greedy_async(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T,
                             const int64_t* start_tokens_dev, int64_t* tokens_dev, float* logits_dev, d2t_stream stream);
 int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
+/* Serving tickets.  Every d2t_decode_greedy_async call is numbered 1, 2, 3, ... (d2t_decode_last_ticket returns the
+ * number of the most recent one, 0 before the first).  d2t_decode_wait_ticket orders `stream` (and the host, if
+ * host_sync != 0) after THAT decode only -- a consumer of batch i need not wait for batches i+1, i+2 that are already
+ * in flight; d2t_decode_query polls: 1 complete, 0 still running, < 0 error (-D2T_E*).  The output buffers of a decode
+ * belong to the engine until its ticket is complete: a caller that recycles buffers checks the ticket first. */
+int64_t d2t_decode_last_ticket(const d2t_ctx* ctx);
+int d2t_decode_query(d2t_ctx* ctx, int64_t ticket);
+int d2t_decode_wait_ticket(d2t_ctx* ctx, int64_t ticket, d2t_stream stream, int32_t host_sync);
 
 /* ---- beam decode (one sample, fresh beam state per call) ------------------
  * memory [1,T,d].  seq_out: HOST buffer of max_seq_len+1 int64; *len_out its
@@ -290,6 +305,33 @@ int d2t_op_vit_attention(const float* qkv, float* y, int32_t B, int32_t N, int32
  * attends over the first L keys; y [B,heads*hd].  hd = 32 or 64. */
 int d2t_op_decode_attention(const float* q, const float* k, const float* v, float* y, int32_t B, int32_t heads,
                             int32_t hd, int32_t L, int32_t Lmax, d2t_stream stream);
+
+/* ---- op-level TRAINING test entry points ---------------------------------------------------------------------
+ * One node of the training tape, forward + backward, on caller tensors (fp32, device, row-major [rows][cols]; maps
+ * NHWC; convolution weights OIHW as in the state_dict).  They run the very builders / backward functions of
+ * d2t_train_forward / d2t_train_backward, so the backward kernels can be checked one op at a time.  Output pointers may
+ * be NULL.  bf16x3 != 0: split-bf16 arithmetic for the convolution / data-gradient / weight-gradient GEMMs.
+ * Synchronous (the call returns after the stream has drained). */
+/* y = [relu]( BN_batchstats( conv(x, w) ) [+ residual] )  (gamma != NULL)   or   conv(x, w) + bias  (gamma == NULL).
+ * Cin == 1 selects the stem (3x3, pad 1, BN + ReLU, 32 output channels: resnet.py:205-207). */
+int d2t_op_train_conv(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                      const float* residual, const float* dy, float* y, float* dx, float* dw, float* dbias,
+                      float* dgamma, float* dbeta, float* dres, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                      int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t relu,
+                      int32_t bf16x3, d2t_stream stream);
+/* y = [relu](x @ w^T + bias) [+ residual];  x [M][K], w [N][K] */
+int d2t_op_train_linear(const float* x, const float* w, const float* bias, const float* residual, const float* dy, float* y,
+                        float* dx, float* dw, float* dbias, float* dres, int32_t M, int32_t K, int32_t N, int32_t relu,
+                        int32_t bf16x3, d2t_stream stream);
+int d2t_op_train_layernorm(const float* x, const float* gamma, const float* beta, const float* dy, float* y, float* dx,
+                           float* dgamma, float* dbeta, int32_t rows, int32_t D, float eps, d2t_stream stream);
+/* nn.MultiheadAttention core: q [nb*Lq][heads*hd], kv [nb*Lk][2*heads*hd] (keys | values); keytok (optional) [nb][Lk]
+ * token ids whose PAD (0) entries are masked (tgt_key_padding_mask); causal != 0 adds the causal mask. */
+int d2t_op_train_attention(const float* q, const float* kv, const int64_t* keytok, const float* dy, float* y, float* dq,
+                           float* dkv, int32_t nb, int32_t Lq, int32_t Lk, int32_t heads, int32_t hd, int32_t causal,
+                           d2t_stream stream);
+int d2t_op_train_maxpool(const float* x, const float* dy, float* y, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t SH, int32_t SW, int32_t PH, int32_t PW, d2t_stream stream);
 
 #ifdef __cplusplus
 }

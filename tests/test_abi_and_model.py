@@ -136,3 +136,64 @@ def test_lds_dma_convolution_leaves_registers_for_a_decode_wave(tmp_path):
         m = re.search(r"\.name:\s+_ZN3d2t\d+%s.*?\.vgpr_count:\s+(\d+)" % kernel, text, re.S)
         assert m, kernel
         assert int(m.group(1)) <= 104, (kernel, int(m.group(1)))
+
+
+# ---- device binding (the reference hands device strings such as "cuda:1" around: build_pred.py:17, api/infer.py:106) -------
+def test_device_strings_resolve_like_torch():
+    from doc2tex_amd.engine import device_index
+    with pytest.raises(RuntimeError, match="not a ROCm"):
+        device_index("xpu:0")
+    if torch.cuda.is_available():
+        assert device_index("cuda") == torch.cuda.current_device()
+        assert device_index("cuda:0") == 0 and device_index(torch.device("cuda", 0)) == 0
+        assert device_index(None) == torch.cuda.current_device()
+
+
+@pytest.mark.gpu
+def test_engine_lives_on_the_device_the_model_names():
+    """opt["device"] = "cuda:0": the context reports device 0, tensors from another device or from the host are refused
+    with a clear message, and a device index the machine does not have is an error at construction, not a crash."""
+    cfg = synth.make_config("T2", device="cuda:0", max_seq_len=6)
+    m = Model(cfg)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict()))
+    m = m.eval().to("cuda:0")
+    img = synth.synth_images(1, 48, 64).to("cuda:0")
+    text = torch.ones(1, 1, dtype=torch.long, device="cuda:0")
+    with torch.no_grad():
+        preds, _, _ = m(img, text, is_train=False)
+    eng = m.engine()
+    assert eng.device == 0 and eng.lib.d2t_device_of(eng.ctx) == 0 and preds.device.index == 0
+    with pytest.raises(RuntimeError, match="no CPU path|ROCm"):
+        m(img.cpu(), text.cpu(), is_train=False)
+    from doc2tex_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Engine(synth.make_config("T2"), device=f"cuda:{torch.cuda.device_count()}")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_two_models_on_two_gpus_in_one_process():
+    """A Model on cuda:1 without torch.cuda.set_device(1), next to one on cuda:0: each context lives with its parameters,
+    results agree bit for bit, an input on the wrong GPU is refused, and .to() moves the engine."""
+    outs = []
+    models = []
+    for dev in ("cuda:0", "cuda:1"):
+        cfg = synth.make_config("T2", device=dev, max_seq_len=6)
+        m = Model(cfg)
+        m.load_state_dict(synth.synth_state_dict(m.state_dict()))
+        m = m.eval().to(dev)
+        img = synth.synth_images(2, 48, 64).to(dev)
+        with torch.no_grad():
+            p, l, _ = m(img, torch.ones(2, 1, dtype=torch.long, device=dev), is_train=False)
+        assert m.engine().device == int(dev[-1]) and p.device.index == int(dev[-1])
+        outs.append((p.cpu(), l.cpu()))
+        models.append(m)
+    assert torch.cuda.current_device() == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with pytest.raises(RuntimeError, match="lives on cuda:1"):
+        models[1](synth.synth_images(1, 48, 64).to("cuda:0"), torch.ones(1, 1, dtype=torch.long, device="cuda:0"), is_train=False)
+    moved = models[1].to("cuda:0")
+    with torch.no_grad():
+        p, l, _ = moved(synth.synth_images(2, 48, 64).to("cuda:0"), torch.ones(2, 1, dtype=torch.long, device="cuda:0"),
+                        is_train=False)
+    assert moved.engine().device == 0 and torch.equal(p.cpu(), outs[0][0])

@@ -3,7 +3,6 @@ token gather, doc2tex_amd/dist.py).  The per-rank decoder here is the CPU oracle
 (the engine needs a GPU); the host logic under test is identical on RCCL."""
 import json
 import os
-import socket
 import sys
 
 import pytest
@@ -29,8 +28,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import restatement as R
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with open(os.path.join(GOLD, "manifests.json")) as f:
         man = json.load(f)
@@ -49,34 +47,30 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _run_world(worker, world=2, attempts=3):
-    """Spawn `world` ranks of `worker(rank, world, port, queue)`; returns what rank 0 put on the queue.  The
-    rendezvous port is picked by binding port 0 and releasing it, so a collision with another process is possible:
-    retry on a fresh port if a rank dies before producing a result."""
-    last = None
-    for _ in range(attempts):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
+def _run_world(worker, world=2):
+    """Spawn `world` ranks of `worker(rank, world, rendezvous, queue)`; returns what rank 0 put on the queue.  The
+    ranks meet through a file store in a fresh temporary directory (no TCP port to collide on), so there is nothing to
+    retry: a rank that dies, for whatever reason, fails the test the first time."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        store = os.path.join(tmp, "rendezvous")
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        procs = [ctx.Process(target=worker, args=(r, world, store, q)) for r in range(world)]
         for p in procs:
             p.start()
+        err = None
         try:
             out = q.get(timeout=300)
-        except Exception as e:  # noqa: BLE001 - queue.Empty or a broken pipe: clean up and retry
-            last = e
-            out = None
+        except Exception as e:  # noqa: BLE001 - queue.Empty: a rank died or hung before rank 0 produced its result
+            out, err = None, e
         for p in procs:
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()
-        if out is not None and all(p.exitcode == 0 for p in procs):
-            return out
-        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
-    raise last
+        codes = [p.exitcode for p in procs]
+        assert out is not None and all(c == 0 for c in codes), f"rank exit codes {codes}: {err!r}"
+        return out
 
 
 def _until_end(row):
@@ -96,8 +90,7 @@ def _grad_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import restatement as R
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with open(os.path.join(GOLD, "manifests.json")) as f:
         man = json.load(f)

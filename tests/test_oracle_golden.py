@@ -12,7 +12,10 @@ from oracle import restatement as R
 
 # the two full-size greedy cases take ~15 s each on 8 cores; everything else is seconds
 GREEDY = ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_small_crop", "c2_greedy", "c1_greedy",
-          "c0_greedy", "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy"]
+          "c0_greedy", "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy",
+          # round 2: config C4's geometry (max_dimension [160, 640]); c4_greedy_160 / c1_greedy_full (151 steps, ~15 s each) are
+          # re-checked by tools/make_golden.py at generation time and on the GPU box, not here
+          "c4_greedy_128", "c4_greedy_96"]
 
 
 def _case(cases, kind, name):
@@ -23,6 +26,7 @@ def _case(cases, kind, name):
 def test_greedy_matches_reference_fixture(cases, manifests, name):
     c = _case(cases, "greedy", name)
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    cfg["beam_size"] = c.get("beam_size", cfg["beam_size"])
     z = np.load(os.path.join(GOLD, name + ".npz"))
     img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
     text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
@@ -56,7 +60,7 @@ def test_faithful_mode_equals_cached_mode(cases, manifests):
     assert float((lf - la).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish"])
+@pytest.mark.parametrize("name", ["t2_beam5", "c2_beam5", "t2_beam3_nofinish", "c4_beam5_160", "c4_beam5_96"])
 def test_beam_matches_reference_fixture(cases, manifests, name):
     c = _case(cases, "beam", name)
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
@@ -128,7 +132,7 @@ def train_step_labels(c):
     return text
 
 
-@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step"])
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step", "c3_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
     reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""
@@ -140,7 +144,7 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
     assert np.array_equal(text.numpy(), z["text"])
     loss, logits, grads, bn = R.train_step_grads(cfg, sd, img, text)
     assert abs(float(loss) - c["loss"]) <= 1e-5 * max(1.0, abs(c["loss"]))
-    assert np.abs(logits.numpy() - z["logits"]).max() <= 2e-4
+    assert np.abs(logits[:, ::c.get("logit_stride", 1)].numpy() - z["logits"]).max() <= 2e-4
     assert sorted(grads) == sorted(c["grad_norms"])
     assert not any(k in grads for k in c["frozen"])
     for k, g in grads.items():

@@ -279,3 +279,71 @@ def test_resize_feeds_the_recognizer():
         op, ol, _ = R.forward(ocfg, sd, want_x, text)
     assert torch.equal(preds.cpu(), op)
     assert float((logits.cpu() - ol).abs().max()) <= 1e-3
+
+
+# ---- the rows either side of the recognizer, end to end (SURVEY 8f.1 + 8f.2) --------------------------------------------
+def _reference_cleanup(s):
+    """Postprocessing.remove_unused_whitespace (utils/data_utils.py:433-455) through Python's re: the checker of the
+    native scanner (pinned on the reference's own function by tests/golden/post_cases.json)."""
+    import re
+    noletter, letter = r"[\W_^\d]", "[a-zA-Z]"
+    news = s
+    while True:
+        s = news
+        news = re.sub(r"(?!\\ )(%s)\s+?(%s)" % (noletter, noletter), r"\1\2", s)
+        news = re.sub(r"(?!\\ )(%s)\s+?(%s)" % (noletter, letter), r"\1\2", news)
+        news = re.sub(r"(%s)\s+?(%s)" % (letter, noletter), r"\1\2", news)
+        if news == s:
+            return s
+
+
+def test_pages_to_latex_end_to_end():
+    """Page images -> resize() (d2t_prep_run) -> Model.forward (HIP engine) -> LabelDecoder.to_latex (d2t_post_decode)
+    against oracle pre-processing -> oracle forward -> the reference's decode / "[s]" cut / regex clean-up in Python:
+    identical LaTeX strings for a batch of pages of one size bucket, rows ending at different steps."""
+    from doc2tex_amd.postprocess import LabelDecoder
+    from doc2tex_amd.preprocess import resize
+    from oracle import restatement as R
+    man = json.load(open(os.path.join(GOLD, "manifests.json")))
+    post = json.load(open(os.path.join(GOLD, "post_cases.json")))
+    L = 40
+    cfg, m = engine_model("T2", L, end_bias=2.1)  # at this [s] bias the plain pages end at once, the altered ones never do
+    ocfg, sd = oracle_state_dict("T2", man["T2"], L, end_bias=2.1)
+    opt = _opt(cfg["max_dimension"])
+    # a 496-symbol vocabulary made of the fixture's LaTeX tokens (repeats get a numeric suffix, so "\\frac3" etc. also
+    # exercise the letter / non-letter boundaries of the clean-up)
+    base = post["vocab"]
+    vocab = [base[i % len(base)] + (str(i // len(base)) if i >= len(base) else "") for i in range(synth.VOCAB - 4)]
+    dec = LabelDecoder(vocab, head="TFM")
+    chars = ["[PAD]", "[GO]", "[s]", "[UNK]"] + vocab
+    H0, W0 = cfg["max_dimension"]
+    pages = [synth.synth_formula_image(2 * H0 + 3 + i, 3 * W0 + 7 * i, 7100 + i) for i in range(5)]
+    pages[1] = 255 - pages[1]                                # white strokes on a dark page
+    pages[3] = (pages[3] // 4 + 190).astype(np.uint8)        # a faint, low-contrast scan
+    xs = [resize(None, pg, opt) for pg in pages]
+    assert len({tuple(x.shape) for x in xs}) == 1  # one (H, W) bucket -> one batch (data/collate_fn.py:15-47)
+    x = torch.cat(xs)
+    want_x = torch.cat([torch.from_numpy(P.resize(pg, opt, variant="demo")) for pg in pages])
+    assert torch.equal(x.cpu(), want_x)
+    text = torch.full((len(pages), 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        preds, logits, _ = m(x, text.cuda(), is_train=False, is_test=True)
+        op, ol, _ = R.forward(ocfg, sd, want_x, text, is_test=True)
+    assert torch.equal(preds.cpu(), op)
+    got = dec.to_latex(preds, "word", postprocess=True)
+    want = []
+    for row in op.tolist():
+        s = " ".join(chars[i] for i in row)  # TFMLabelConverter.decode, token_level "word" (tfm_converter.py:59-70)
+        cut = s.find("[s]")                    # engine/inferencing.py:119-121
+        want.append(_reference_cleanup(s[:cut] if cut >= 0 else s))
+    assert got == want
+    assert "" in want and any(len(w) > 40 for w in want)  # both kinds of row: "[s]" first -> empty string; never ended
+
+
+def test_post_processing_fixtures_in_the_gpu_suite():
+    """The reference-generated post-processing fixtures (419 strings, 80 id matrices; tests/test_prep_post_cpu.py) once
+    more in the suite the driver runs on the GPU box, so that row 8f.2 is covered there as well."""
+    import test_prep_post_cpu as T
+    T.test_whitespace_pass_matches_reference_fixture()
+    T.test_decode_cut_and_cleanup_match_reference_fixture()
+    T.test_whitespace_pass_matches_python_re_live()

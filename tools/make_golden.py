@@ -57,12 +57,26 @@ GREEDY_CASES = [
     # GlobalContext blocks on (gcb: True, addon_module/visual_attention.py:105-165)
     ("t2g_greedy", "T2G", 2, 48, 64, 12, 1234, 1014, 0.0, False),
     ("t1g_greedy", "T1G", 2, 32, 64, 12, 1234, 1015, 0.0, False),
+    # round 2 -- BASELINE configs[4] geometry: the C2 model built for max_dimension [160, 640] (9x161 backbone grid, 406 memory
+    # tokens), at its largest bucket and at the two smaller buckets of SURVEY 8d (flat-prefix slice of the 160x640 table)
+    ("c4_greedy_160", "C4", 2, 160, 640, 150, 1234, 1070, 0.0, False),
+    ("c4_greedy_128", "C4", 1, 128, 512, 20, 1234, 1071, 0.0, False),
+    ("c4_greedy_96", "C4", 2, 96, 384, 20, 1234, 1072, 0.0, False),
+    # BASELINE configs[1] at its full decode length (the GPU test decodes B=32 and checks these first rows)
+    ("c1_greedy_full", "C1", 2, 64, 256, 150, 1234, 1073, 0.0, False),
 ]
+ROUND2_GREEDY = ("c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full")
 BEAM_CASES = [
     ("t2_beam5", "T2", 48, 64, 16, 1234, 1010, 1.8, 5),
     ("c2_beam5", "C2", 96, 384, 12, 1234, 1011, 1.8, 5),
     ("t2_beam3_nofinish", "T2", 48, 64, 6, 1234, 1012, 0.0, 3),
+    # round 2 -- config C4 itself (beam_size 5 under max_dimension [160, 640]), every bucket; the last runs all 151 steps
+    ("c4_beam5_160", "C4", 160, 640, 24, 1234, 1074, 1.8, 5),
+    ("c4_beam5_128", "C4", 128, 512, 24, 1234, 1075, 1.8, 5),
+    ("c4_beam5_96", "C4", 96, 384, 24, 1234, 1076, 1.8, 5),
+    ("c4_beam5_160_full", "C4", 160, 640, 150, 1234, 1077, 0.0, 5),
 ]
+ROUND2_BEAM = ("c4_beam5_160", "c4_beam5_128", "c4_beam5_96", "c4_beam5_160_full")
 # LSTM-attention beam search (seq2seq.py:83-222 / seq2seq_v2.py:12-174): name, config, H, W, batch_max_length, wseed, iseed, end_bias, beam
 ATTN_BEAM_CASES = [
     ("ts0_beam5", "TS0", 48, 64, 14, 1234, 1050, 0.3, 5),
@@ -76,7 +90,11 @@ TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
 # full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
 TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031),
                     # HybridViT + Attnv2 (the shipped config/train.yaml stack), teacher_forcing 1.0, droprate 0
-                    ("ts0_train_step", "TS0", 3, 48, 64, 24, 1234, 1032)]
+                    ("ts0_train_step", "TS0", 3, 48, 64, 24, 1234, 1032),
+                    # round 2 -- BASELINE configs[3] at its own crop size and label length (four rows of the per-GPU shard:
+                    # 8256 pixels per BatchNorm channel in the deepest stage instead of ~100 in the toys above)
+                    ("c3_train_step", "C3", 4, 128, 512, 150, 1234, 1033)]
+LOGIT_STRIDE = {"c3_train_step": 8}  # store every 8th position of the [B, 151, V] logits (fixture size)
 GRAD_SAMPLES = 48
 # dropout placement (p = 0.1 in the decoder layers): name, config, B, H, W, L, wseed, iseed, mask seed
 TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77),
@@ -140,10 +158,10 @@ def check_tables(cfg, sd, report):
 def run_greedy(case):
     name, cname, B, H, W, L, wseed, iseed, end_bias, is_test = case
     t0 = time.time()
-    cfg, m, sd = build_ref(cname, L, wseed=wseed, end_bias=end_bias)
+    cfg, m, sd = build_ref(cname, L, beam_size=1, wseed=wseed, end_bias=end_bias)  # greedy: beam_size 1 (C4 defaults to 5)
     img = synth.synth_images(B, H, W, seed=iseed)
     text = torch.full((B, 1), R.GO, dtype=torch.long)
-    rep = {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed,
+    rep = {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "beam_size": 1,
            "iseed": iseed, "end_bias": end_bias, "is_test": is_test, "torch": torch.__version__}
     check_tables(cfg, sd, rep)
     with torch.no_grad():
@@ -315,7 +333,7 @@ def run_train_step(case):
     assert worst <= 5e-4, worst
     for k, v in after.items():
         assert maxdiff(obn[k], v) <= 1e-5, k
-    arrays = {"logits": preds.detach().numpy(), "text": text.numpy()}
+    arrays = {"logits": preds.detach()[:, ::LOGIT_STRIDE.get(name, 1)].numpy(), "text": text.numpy()}
     norms = {}
     for k, g in ref_grads.items():
         idx = grad_sample_index(k, g.numel())
@@ -326,6 +344,7 @@ def run_train_step(case):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
     return {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
             "loss": float(loss), "oracle_worst_rel_grad_diff": worst, "n_grads": len(ref_grads), "frozen": ref_frozen,
+            "logit_stride": LOGIT_STRIDE.get(name, 1),
             "grad_norms": norms, "seconds": round(time.time() - t0, 1), "torch": torch.__version__}
 
 
@@ -417,6 +436,37 @@ def main():
             print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
         for cn in ("T2D", "TS0D"):
             manifests[cn] = manifest(build_ref(cn, 24)[2])
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+            json.dump(manifests, f)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "round2":  # add / refresh only the round-2 cases (C4 geometry, C1 full length, C3 size)
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        with open(os.path.join(GOLD, "manifests.json")) as f:
+            manifests = json.load(f)
+        for case in GREEDY_CASES:
+            if case[0] not in ROUND2_GREEDY:
+                continue
+            rep, man, cname = run_greedy(case)
+            manifests[cname] = man
+            summary["greedy"] = [r for r in summary["greedy"] if r["case"] != rep["case"]] + [rep]
+            print("greedy", rep["case"], "steps", rep["steps"], "dmem", rep["diff_mem_folded"], "dlogit", rep["diff_logits_cached"],
+                  "gap", rep["min_top2_gap"], f'{rep["seconds"]}s', flush=True)
+        for case in BEAM_CASES:
+            if case[0] not in ROUND2_BEAM:
+                continue
+            rep = run_beam(case)
+            summary["beam"] = [r for r in summary["beam"] if r["case"] != rep["case"]] + [rep]
+            print("beam", rep["case"], rep["seq"], rep["score"], "completed", rep["completed"], flush=True)
+        for case in TRAIN_STEP_CASES:
+            if case[0] != "c3_train_step":
+                continue
+            rep = run_train_step(case)
+            manifests["C3"] = manifests["C2"]
+            summary["train_step"] = [r for r in summary["train_step"] if r["case"] != rep["case"]] + [rep]
+            print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
         with open(os.path.join(GOLD, "cases.json"), "w") as f:
             json.dump(summary, f, indent=1)
         with open(os.path.join(GOLD, "manifests.json"), "w") as f:
