@@ -77,6 +77,8 @@ SIGNATURES = {
     "d2t_train_set_dropout": (_I, [_P, C.c_float, C.c_uint64]),
     "d2t_train_set_teacher_flags": (_I, [_P, C.c_char_p, _I]),
     "d2t_train_mask_count": (_I, [_P]),
+    "d2t_train_decision_count": (_I, [_P]),
+    "d2t_train_read_decision": (_I, [_P, _I, _P, C.c_int64, C.POINTER(_I), C.POINTER(C.c_int64), _P]),
     "d2t_train_read_mask": (_I, [_P, _I, _P, C.c_int64, _P]),
     "d2t_train_release": (None, [_P]),
     "d2t_profile_enable": (_I, [_P, _I]),

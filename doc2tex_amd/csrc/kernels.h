@@ -308,6 +308,9 @@ hipError_t launch_dropout_mask(uint8_t* mask, size_t n, float p, unsigned long l
                                hipStream_t s);
 // out = a * mask * scale
 hipError_t launch_apply_mask(const float* a, const uint8_t* mask, float scale, float* out, size_t n, hipStream_t s);
+hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s);
+hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
+                              hipStream_t s);
 hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s);
 hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
                          int offw, hipStream_t s);

@@ -1062,6 +1062,47 @@ int d2t_train_read_mask(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t numel, 
 
 int d2t_train_mask_count(d2t_ctx* c) { return c && c->train ? (int)c->train->masks.size() : 0; }
 
+// The discrete decisions of the last training forward, in network order: one entry per ReLU (convolution + BatchNorm
+// [+ residual] + ReLU nodes, decoder linear1) and per max-pool.  A test replays them in the oracle (ReLU -> multiply by the
+// keep mask, max-pool -> gather of the recorded window element), which makes oracle and engine evaluate the SAME smooth
+// function: gradients then agree to rounding everywhere, with no "a tie may have flipped" allowance.
+static bool is_decision(const Node& n) { return n.kind == N_POOL || ((n.kind == N_CONV || n.kind == N_LINEAR) && n.relu); }
+
+int d2t_train_decision_count(d2t_ctx* c) {
+  if (!c || !c->train) return 0;
+  int k = 0;
+  for (const Node& n : c->train->nodes) k += is_decision(n);
+  return k;
+}
+
+// index-th decision: is_pool_out = 1 for a max-pool (bytes = window element kh*2+kw per output element, NHWC), 0 for a
+// ReLU keep mask (bytes = y > 0 per element, rows x cols); numel_out = its element count.  dst may be NULL (query only).
+int d2t_train_read_decision(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t numel, int32_t* is_pool_out, int64_t* numel_out,
+                            d2t_stream stream) {
+  DevGuard dg_(c);
+  if (!c || !c->train) return fail(c, D2T_ESTATE, "no training forward has run");
+  d2t_train_state* st = c->train;
+  int k = 0;
+  for (const Node& n : st->nodes) {
+    if (!is_decision(n)) continue;
+    if (k++ != index) continue;
+    const TT& y = st->t[n.out];
+    const int64_t ne = (int64_t)y.rows * y.cols;
+    if (is_pool_out) *is_pool_out = n.kind == N_POOL;
+    if (numel_out) *numel_out = ne;
+    if (!dst) return D2T_OK;
+    if (numel != ne) return fail(c, D2T_EINVAL, "decision %d has %lld elements", index, (long long)ne);
+    if (n.kind == N_POOL) {
+      const TT& x = st->t[n.in];
+      HIPCHK(c, launch_pool_argmax(x.p, dst, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, (hipStream_t)stream));
+    } else {
+      HIPCHK(c, launch_relu_mask(y.p, dst, (size_t)ne, (hipStream_t)stream));
+    }
+    return D2T_OK;
+  }
+  return fail(c, D2T_EINVAL, "no decision %d", index);
+}
+
 void d2t_train_release(d2t_ctx* c) {
   DevGuard dg_(c);
   if (c && c->train) {

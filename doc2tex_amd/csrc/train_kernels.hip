@@ -567,6 +567,45 @@ hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B,
 }
 
 // ---------------------------------------------------------------------------
+// The discrete decisions of a training forward, for tests that replay them in the oracle (d2t_train_read_decision):
+// ReLU keep masks (y > 0) and, per max-pool output element, which window element (kh*2 + kw) the backward routes the
+// gradient to -- the same first-maximum scan as maxpool_bwd_kernel.
+// ---------------------------------------------------------------------------
+__global__ void relu_mask_kernel(const float* __restrict__ y, uint8_t* __restrict__ m, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m[i] = y[i] > 0.f;
+}
+hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, s, y, m, n);
+  return hipGetLastError();
+}
+__global__ void pool_argmax_kernel(const float* __restrict__ x, uint8_t* __restrict__ k, int B, int H, int W, int C, int OH,
+                                   int OW, int SH, int SW, int PH, int PW) {
+  const size_t total = (size_t)B * OH * OW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int ow = (int)((i / C) % OW), oh = (int)((i / ((size_t)C * OW)) % OH), b = (int)(i / ((size_t)C * OW * OH));
+    float best = -INFINITY;
+    int bk = -1;
+    for (int kh = 0; kh < 2; ++kh)
+      for (int kw = 0; kw < 2; ++kw) {
+        const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
+        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+        const float v = x[(((size_t)b * H + ih) * W + iw) * C + c];
+        if (v > best || bk < 0) { best = v; bk = kh * 2 + kw; }
+      }
+    k[i] = (uint8_t)bk;
+  }
+}
+hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
+                              hipStream_t s) {
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+  const size_t total = (size_t)B * OH * OW * C;
+  hipLaunchKernelGGL(pool_argmax_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, x, k,
+                     B, H, W, C, OH, OW, SH, SW, PH, PW);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // LayerNorm with saved statistics / backward.  One wave per row, D = 256 or 512.
 // ---------------------------------------------------------------------------
 template <int D>

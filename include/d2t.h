@@ -259,6 +259,13 @@ int d2t_train_set_dropout(d2t_ctx* ctx, float p, uint64_t seed);
  * arg-max of step t-1's output (0).  n = 0 restores "always the label".  The flags apply to the following forwards. */
 int d2t_train_set_teacher_flags(d2t_ctx* ctx, const uint8_t* flags, int32_t n);
 int d2t_train_mask_count(d2t_ctx* ctx);
+/* The discrete decisions of the last d2t_train_forward, in network order: one entry per ReLU (keep mask, y > 0, one byte per
+ * element of the [rows][cols] output) and per max-pool (the window element kh*2+kw that holds the first maximum, one byte
+ * per NHWC output element).  Test instrument: replayed in the CPU oracle they pin both sides to the same smooth function.
+ * dst may be NULL to query *is_pool_out / *numel_out only. */
+int d2t_train_decision_count(d2t_ctx* ctx);
+int d2t_train_read_decision(d2t_ctx* ctx, int32_t index, uint8_t* dst, int64_t numel, int32_t* is_pool_out,
+                            int64_t* numel_out, d2t_stream stream);
 int d2t_train_read_mask(d2t_ctx* ctx, int32_t index, uint8_t* dst, int64_t numel, d2t_stream stream);
 /* free the training tape, gradient buffers and workspace */
 void d2t_train_release(d2t_ctx* ctx);

@@ -299,58 +299,61 @@ def test_lstm_head_training_with_output_dropout_and_scheduled_sampling(cases, ma
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3] at its own size: HybridViT + TFM-6, 128x512 crops, 150-token labels (SURVEY 8d "C3").
 # ---------------------------------------------------------------------------------------------------------------
-_C3_ORACLE = {}
-
-
-def _c3_oracle(cases, manifests):
-    """The oracle's step on the c3_train_step instance (B=4 rows of the per-GPU shard; ~15 s of host time), once."""
-    if not _C3_ORACLE:
-        c = _case(cases, "train_step", "c3_train_step")
-        cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
-        img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
-        text = train_step_labels(c)
-        _C3_ORACLE.update(c=c, img=img, text=text, out=R.train_step_grads(cfg, sd, img, text))
-    return _C3_ORACLE
+def _c3_instance(cases):
+    c = _case(cases, "train_step", "c3_train_step")
+    return c, synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]), train_step_labels(c)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_config_c3_crop_size_matches_reference_fixture(cases, manifests, precision):
     """The training step at C3's crop size and label length (128x512, L=150; B=4 so that the reference and the oracle
-    could run it): 8256 pixels per BatchNorm channel in the deepest stage instead of ~100 in the toy fixtures, so the
-    instance is well conditioned and BOTH arithmetic modes are held to the same tight bars -- loss / logits / running
-    statistics against the reference's fixture, every gradient tensor against the oracle's autograd (relative L2) and
-    against the reference's stored samples and norms."""
-    o = _c3_oracle(cases, manifests)
-    c, img, text = o["c"], o["img"], o["text"]
-    oloss, ologits, ograds, obn = o["out"]
+    could run it): 8256 pixels per BatchNorm channel in the deepest stage instead of ~100 in the toy fixtures.
+    Against the REFERENCE's fixture: loss, logits, BatchNorm running statistics, gradient norms and samples.
+    Against the float64 oracle replaying the engine's own ReLU / max-pool decisions (so that no tie can fall
+    differently): the relative L2 error of EVERY gradient tensor, in both arithmetic modes."""
+    c, img, text = _c3_instance(cases)
     z = np.load(os.path.join(GOLD, "c3_train_step.npz"))
     assert np.array_equal(text.numpy(), z["text"])
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"], precision=precision)
     loss, preds = _step(m, img, text)
     assert abs(float(loss) - c["loss"]) <= 1e-4 * max(1.0, abs(c["loss"]))
     assert np.abs(preds[:, ::c["logit_stride"]].cpu().numpy() - z["logits"]).max() <= 1e-3
     bufs = dict(m.named_buffers())
-    for k in obn:
-        ref = z["bn:" + k]
-        assert np.abs(bufs[k].cpu().numpy() - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    for k in bufs:
+        if k.endswith(("running_mean", "running_var")):
+            ref = z["bn:" + k]
+            assert np.abs(bufs[k].cpu().numpy() - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    with _ReplayDecisions(m._engine) as rep:
+        oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd64, img.double(), text)
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    assert float((preds.cpu().double() - ologits).abs().max()) <= 1e-3
     l2 = _l2_errors(m, ograds)
-    worst = sorted(l2.items(), key=lambda kv: -kv[1])[:5]
-    print(f"[c3 {precision}] worst relative L2 gradient errors: {worst}; median {np.median(list(l2.values())):.2e}")
-    upper = max(v for k, v in l2.items() if "ConvNet" not in k)
-    # decoder + ViT + patch embedding (above the backbone's ReLU / max-pool decisions): fp32-class in both modes
-    assert upper <= 1e-3, (upper, worst)
-    # backbone: a handful of ReLU / max-pool ties flip between two correct implementations; on this instance they move a
-    # tensor by well under a per cent (the toy instances: several per cent)
-    assert max(l2.values()) <= 1e-2, worst
+    order = sorted(l2.items(), key=lambda kv: -kv[1])
+    # BatchNorm weight / bias gradients of the high-resolution layers are sums over up to 4.2 million pixels that cancel to
+    # ~1/2000 of their terms' magnitude (the next BatchNorm removes most of what a shift or scale of this one changes): every
+    # arithmetic's rounding is amplified by that factor -- torch's own float32 autograd is 0.8-0.9 % off float64 there
+    # (measured, tools/make_golden.py's instance) -- so they get their own bar; everything else is held tight.
+    bn_vec = {k: v for k, v in l2.items() if "ConvNet" in k and (".bn" in k or "downsample.1" in k)}
+    rest = {k: v for k, v in l2.items() if k not in bn_vec}
+    whole = (sum((dict(m.named_parameters())[k].grad.double().cpu() - g.double()).norm() ** 2 for k, g in ograds.items()) /
+             sum(g.double().norm() ** 2 for g in ograds.values())) ** 0.5
+    print(f"[c3 {precision}, decisions replayed] whole-gradient rel. L2 {float(whole):.2e}; worst tensors {order[:4]}; "
+          f"worst non-BN {max(rest.items(), key=lambda kv: kv[1])}; median {np.median(list(l2.values())):.2e}")
+    tight, bn_tol = (2e-4, 3e-2) if precision == "fp32" else (2e-3, 3e-2)
+    assert max(rest.values()) <= tight, max(rest.items(), key=lambda kv: kv[1])
+    assert max(bn_vec.values()) <= bn_tol, max(bn_vec.items(), key=lambda kv: kv[1])
+    assert float(whole) <= tight
     params = dict(m.named_parameters())
     from test_oracle_golden import _grad_sample_index
-    for k, (norm, _) in c["grad_norms"].items():
+    for k, (norm, _) in c["grad_norms"].items():  # the reference's own (float32) numbers: 3 % covers its ill-conditioned sums
         g = params[k].grad
-        assert abs(float(g.double().norm()) - norm) <= 1e-2 * max(norm, 1e-6), k
+        assert abs(float(g.double().norm()) - norm) <= 3e-2 * max(norm, 1e-6), k
         idx = _grad_sample_index(k, g.numel())
         ref = z["g:" + k]
         rms = norm / g.numel() ** 0.5
-        assert np.abs(g.reshape(-1)[idx.cuda()].cpu().numpy() - ref).max() <= 2e-2 * max(float(np.abs(ref).max()), rms, 1e-7), k
+        assert np.abs(g.reshape(-1)[idx.cuda()].cpu().numpy() - ref).max() <= 3e-2 * max(float(np.abs(ref).max()), rms, 1e-7), k
 
 
 def test_config_c3_per_gpu_shard_properties(cases):
@@ -377,3 +380,94 @@ def test_config_c3_per_gpu_shard_properties(cases):
         for k, p in m.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, ref[k]), (k, sync is not None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Discriminating end-to-end check: replay the engine's own discrete decisions in the oracle.
+# ---------------------------------------------------------------------------------------------------------------
+class _ReplayDecisions:
+    """Patches torch.nn.functional.relu / max_pool2d for ONE oracle run so that every ReLU multiplies by the keep mask and
+    every max-pool gathers the window element the ENGINE chose in its forward (d2t_train_read_decision, network order).
+    Oracle and engine then evaluate the same smooth function: whatever difference remains in a gradient is arithmetic,
+    not a tie that fell the other way."""
+
+    def __init__(self, eng):
+        import ctypes as C
+        self.eng, self.C, self.i = eng, C, 0
+        self.n = int(eng.lib.d2t_train_decision_count(eng.ctx))
+
+    def _next(self, want_pool, numel):
+        from doc2tex_amd import _lib
+        C, eng = self.C, self.eng
+        is_pool, ne = C.c_int32(-1), C.c_int64(0)
+        assert self.i < self.n, "the oracle asks for more decisions than the engine took"
+        eng._check(eng.lib.d2t_train_read_decision(eng.ctx, self.i, None, 0, C.byref(is_pool), C.byref(ne), None), "read_decision")
+        assert bool(is_pool.value) == want_pool and ne.value == numel, (self.i, is_pool.value, ne.value, numel)
+        buf = torch.empty(numel, dtype=torch.uint8, device=f"cuda:{eng.device}")
+        eng._check(eng.lib.d2t_train_read_decision(eng.ctx, self.i, _lib.ptr(buf), numel, None, None, _lib.stream_of(buf)),
+                   "read_decision")
+        self.i += 1
+        return buf.cpu()
+
+    def relu(self, x, inplace=False):
+        m = self._next(False, x.numel())
+        if x.dim() == 4:  # the engine's maps are NHWC
+            B, Cc, H, W = x.shape
+            m = m.view(B, H, W, Cc).permute(0, 3, 1, 2)
+        else:
+            m = m.view(x.shape)
+        return x * m.to(x.dtype)
+
+    def max_pool2d(self, x, kernel_size, stride=None, padding=0, *a, **k):
+        assert kernel_size in (2, (2, 2))
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        ph, pw = (padding, padding) if isinstance(padding, int) else padding
+        B, Cc, H, W = x.shape
+        OH, OW = (H + 2 * ph - 2) // sh + 1, (W + 2 * pw - 2) // sw + 1
+        idx = self._next(True, B * OH * OW * Cc).view(B, OH, OW, Cc).permute(0, 3, 1, 2).long()
+        xp = torch.nn.functional.pad(x, (pw, pw, ph, ph), value=0.0)  # a padded element is never the recorded choice
+        win = xp.unfold(2, 2, sh).unfold(3, 2, sw)[:, :, :OH, :OW]     # [B, C, OH, OW, kh, kw]
+        return win.reshape(B, Cc, OH, OW, 4).gather(4, idx.unsqueeze(-1)).squeeze(-1)
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._saved = (F.relu, F.max_pool2d)
+        F.relu, F.max_pool2d = self.relu, self.max_pool2d
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.relu, F.max_pool2d = self._saved
+        if exc[0] is None:
+            assert self.i == self.n, f"the oracle replayed {self.i} of the engine's {self.n} decisions"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step"])
+def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, name, precision):
+    """ADVICE r1 / VERDICT r1 item 1d.  The loose end-to-end gradient bounds exist because a ReLU / max-pool decision whose
+    operands differ by rounding may fall differently in two correct implementations.  Here the oracle (float64) replays the
+    ENGINE's decisions, so that excuse is gone: every gradient tensor of the full step -- backbone included, in BOTH
+    arithmetic modes -- must match to arithmetic accuracy: 2e-4 relative L2 in fp32, 2e-3 in split-bf16 (2^-16 per
+    product through 32 convolution layers forward and backward, amplified by the BatchNorm reductions of ~100-pixel maps)."""
+    c = _case(cases, "train_step", name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"], precision=precision)
+    worst = {}
+    for iseed in (c["iseed"], 1130, 1230):
+        img = synth.synth_images(c["B"], c["H"], c["W"], seed=iseed)
+        text = train_step_labels({**c, "iseed": iseed})
+        m.load_state_dict({k: v for k, v in synth.synth_state_dict(m.state_dict(), seed=c["wseed"]).items()})
+        loss, preds = _step(m, img, text)
+        with _ReplayDecisions(m._engine) as rep:
+            oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd64, img.double(), text)
+        assert rep.n >= 30
+        assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+        assert float((preds.cpu().double() - ologits).abs().max()) <= 1e-3
+        l2 = _l2_errors(m, ograds)
+        k, v = max(l2.items(), key=lambda kv: kv[1])
+        worst[iseed] = (k, v, float(np.median(list(l2.values()))))
+    print(f"[replayed decisions, {name}, {precision}] worst tensor per instance: {worst}")
+    tol = 2e-4 if precision == "fp32" else 2e-3
+    assert all(v <= tol for _, v, _ in worst.values()), worst

@@ -147,9 +147,10 @@ def test_stem_conv_backward():
     dy = dy.masked_fill(z.detach().abs() < 1e-3, 0.0)
     grads = torch.autograd.grad(F.relu(z), [wd, gd, bd], dy.double())
     xg, wg, dyg = _nhwc(x), w.to(DEV), _nhwc(dy)
+    gg, bg = gamma.to(DEV), beta.to(DEV)  # named: a temporary would be freed (and its block reused) before the call runs
     y = torch.empty((B, H, W, Cout), device=DEV)
     dw, dgam, dbet = torch.empty_like(wg), torch.empty(Cout, device=DEV), torch.empty(Cout, device=DEV)
-    rc = lib.d2t_op_train_conv(_lib.ptr(xg), _lib.ptr(wg), None, _lib.ptr(gamma.to(DEV)), _lib.ptr(beta.to(DEV)), None,
+    rc = lib.d2t_op_train_conv(_lib.ptr(xg), _lib.ptr(wg), None, _lib.ptr(gg), _lib.ptr(bg), None,
                                _lib.ptr(dyg), _lib.ptr(y), None, _lib.ptr(dw), None, _lib.ptr(dgam), _lib.ptr(dbet), None,
                                B, H, W, 1, Cout, 3, 3, 1, 1, 1, 1, 1, 0, _lib.stream_of(xg))
     assert rc == 0
