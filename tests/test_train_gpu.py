@@ -1,15 +1,15 @@
 """GPU: the training step (module.train() forward + loss.backward()) of the HIP engine against the oracle's
 autograd on the same seeded weights / crops / labels, and against the reference's own numbers in the fixtures.
 
-Tolerances.  A ReLU / max-pool decision whose operands differ by less than fp32 rounding flips between two correct
-fp32 implementations and changes the gradients upstream of it by up to a few per cent of their largest entry (the
-oracle's own float32 and float64 gradients differ by 3e-3 on the backbone of these tiny batches).  Measured on
-MI355X: every tensor backward-downstream of the first such flip matches the oracle to 1e-5 ... 4e-5 (relative L2),
-everything upstream of it to 0.5 ... 1.5 %.  So each instance must satisfy
-  * tensors downstream of EVERY decision (vocabulary projection; last decoder layer after its ReLU): fp32-exact;
-  * every tensor: relative L2 error <= 3 % (a missing term / wrong scale, sign or index is off by >= 10x that);
-and over three instances at least two must have the whole decoder and ViT (everything above the backbone's
-discontinuities) at <= 1e-3.
+Two kinds of comparison.
+  * Decisions replayed (test_gradients_with_the_engines_own_decisions_replayed, the C3-size test): the float64 oracle
+    takes every ReLU / max-pool decision the ENGINE took (d2t_train_read_decision), so both sides differentiate the same
+    smooth function.  Measured on MI355X: every gradient tensor of the whole network within 4e-5 (fp32 arithmetic; one
+    decoder tensor of the d_model-512 stack 1.4e-4) and 7e-4 (split-bf16) relative L2 -- asserted at 2e-4 / 1e-3, for
+    EVERY tensor, in BOTH modes, at toy size and at config C3's own crop size.
+  * Against the reference's float32 fixtures (no replay possible): a ReLU / max-pool decision whose operands differ by
+    less than rounding falls differently in two correct implementations and moves the gradients upstream of it; so
+    those tests demand fp32-exactness downstream of every decision and 3 % relative L2 everywhere, in fp32 arithmetic.
 """
 import os
 
@@ -124,42 +124,6 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
         mem, _, _ = m.forward_encoder(img.cuda())
     assert out[0].shape[0] == c["B"]
     assert float((mem.cpu() - omem).abs().max()) / max(1.0, float(omem.abs().max())) <= 1e-4
-
-
-def test_train_step_gradients_match_oracle_autograd(cases, manifests):
-    c = _case(cases, "train_step", "t2_train_step")
-    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
-    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"])
-    state0 = {k: v.clone() for k, v in m.state_dict().items()}
-    tight = 0
-    for iseed in (1130, 1230, 1330):
-        m.load_state_dict(state0)  # every instance starts from the same weights / running statistics
-        img = synth.synth_images(c["B"], c["H"], c["W"], seed=iseed)
-        text = train_step_labels({**c, "iseed": iseed})
-        oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text)
-        loss, preds = _step(m, img, text)
-        assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
-        assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
-        tight += _check_instance(m, ograds) <= 1e-3
-    assert tight >= 2, tight
-
-
-def test_train_step_in_split_bf16(cases, manifests):
-    """The Model default (conv_precision = 'bf16x3'): forward and data-gradient convolutions of the training step on
-    the split-bf16 kernel.  Loss / logits as tight as fp32; decoder + ViT gradients within 3 %; backbone gradients
-    within the instance's conditioning (see _train_model)."""
-    c = _case(cases, "train_step", "t2_train_step")
-    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
-    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"], precision="bf16x3")
-    img = synth.synth_images(c["B"], c["H"], c["W"], seed=1130)
-    text = train_step_labels({**c, "iseed": 1130})
-    oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd, img, text)
-    loss, preds = _step(m, img, text)
-    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
-    assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
-    l2 = _l2_errors(m, ograds)
-    assert max(v for k, v in l2.items() if "ConvNet" not in k) <= 3e-2
-    assert max(l2.values()) <= 0.15 and float(np.median(list(l2.values()))) <= 0.08
 
 
 def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
@@ -331,23 +295,20 @@ def test_config_c3_crop_size_matches_reference_fixture(cases, manifests, precisi
     assert float((preds.cpu().double() - ologits).abs().max()) <= 1e-3
     l2 = _l2_errors(m, ograds)
     order = sorted(l2.items(), key=lambda kv: -kv[1])
-    # BatchNorm weight / bias gradients of the high-resolution layers are sums over up to 4.2 million pixels that cancel to
-    # ~1/2000 of their terms' magnitude (the next BatchNorm removes most of what a shift or scale of this one changes): every
-    # arithmetic's rounding is amplified by that factor -- torch's own float32 autograd is 0.8-0.9 % off float64 there
-    # (measured, tools/make_golden.py's instance) -- so they get their own bar; everything else is held tight.
-    bn_vec = {k: v for k, v in l2.items() if "ConvNet" in k and (".bn" in k or "downsample.1" in k)}
-    rest = {k: v for k, v in l2.items() if k not in bn_vec}
     whole = (sum((dict(m.named_parameters())[k].grad.double().cpu() - g.double()).norm() ** 2 for k, g in ograds.items()) /
              sum(g.double().norm() ** 2 for g in ograds.values())) ** 0.5
     print(f"[c3 {precision}, decisions replayed] whole-gradient rel. L2 {float(whole):.2e}; worst tensors {order[:4]}; "
-          f"worst non-BN {max(rest.items(), key=lambda kv: kv[1])}; median {np.median(list(l2.values())):.2e}")
-    tight, bn_tol = (2e-4, 3e-2) if precision == "fp32" else (2e-3, 3e-2)
-    assert max(rest.values()) <= tight, max(rest.items(), key=lambda kv: kv[1])
-    assert max(bn_vec.values()) <= bn_tol, max(bn_vec.items(), key=lambda kv: kv[1])
-    assert float(whole) <= tight
+          f"median {np.median(list(l2.values())):.2e}")
+    tol = 2e-4 if precision == "fp32" else 1e-3  # measured: 3.5e-5 / 5.8e-4 (worst tensor), 2.1e-5 / 3.4e-4 (whole gradient)
+    assert order[0][1] <= tol, order[:4]
+    assert float(whole) <= tol
+    if precision != "fp32":
+        return
+    # the reference's own float32 numbers (no replay possible: decisions within rounding of a tie may differ, measured
+    # <= 1.4 % on the BatchNorm vectors of the high-resolution layers, whose sums over 4.2 M pixels cancel to 1/2000)
     params = dict(m.named_parameters())
     from test_oracle_golden import _grad_sample_index
-    for k, (norm, _) in c["grad_norms"].items():  # the reference's own (float32) numbers: 3 % covers its ill-conditioned sums
+    for k, (norm, _) in c["grad_norms"].items():
         g = params[k].grad
         assert abs(float(g.double().norm()) - norm) <= 3e-2 * max(norm, 1e-6), k
         idx = _grad_sample_index(k, g.numel())
@@ -443,13 +404,13 @@ class _ReplayDecisions:
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step"])
+@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step"])
 def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, name, precision):
     """ADVICE r1 / VERDICT r1 item 1d.  The loose end-to-end gradient bounds exist because a ReLU / max-pool decision whose
     operands differ by rounding may fall differently in two correct implementations.  Here the oracle (float64) replays the
     ENGINE's decisions, so that excuse is gone: every gradient tensor of the full step -- backbone included, in BOTH
-    arithmetic modes -- must match to arithmetic accuracy: 2e-4 relative L2 in fp32, 2e-3 in split-bf16 (2^-16 per
-    product through 32 convolution layers forward and backward, amplified by the BatchNorm reductions of ~100-pixel maps)."""
+    arithmetic modes -- must match to arithmetic accuracy: 2e-4 relative L2 in fp32, 1e-3 in split-bf16 (2^-16 per
+    product through 32 convolution layers forward and backward; measured 4e-5 / 7e-4)."""
     c = _case(cases, "train_step", name)
     cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"])
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -469,5 +430,5 @@ def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, nam
         k, v = max(l2.items(), key=lambda kv: kv[1])
         worst[iseed] = (k, v, float(np.median(list(l2.values()))))
     print(f"[replayed decisions, {name}, {precision}] worst tensor per instance: {worst}")
-    tol = 2e-4 if precision == "fp32" else 2e-3
+    tol = 2e-4 if precision == "fp32" else 1e-3
     assert all(v <= tol for _, v, _ in worst.values()), worst
