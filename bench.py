@@ -206,11 +206,16 @@ def main():
                     help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
+    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic"],
+                    help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
     ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
                     help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--group", type=int, default=0,
                     help="pipelined mode: decode the rows of this many consecutive batches in one step loop "
-                         "(default: 3 for C2, whose step is encoder-bound from there on; 4 for the decode-bound C1)")
+                         "(default: 6 for C2 -- the loop's duration hardly depends on the row count and it runs in the "
+                         "gaps the convolutions leave, so larger groups mean fewer loops beside the encoders; 4 for C1)")
     ap.add_argument("--end-bias", type=float, default=0.0,
                     help="secondary run (SURVEY 8d): raise the [s] logit bias of the synthetic weights by this much so that "
                          "rows terminate, and decode with is_test=True (the reference's early exit: a batch stops at the "
@@ -261,7 +266,7 @@ def main():
         return train_bench(args, rank, world, dev, dist)
     name = args.config
     if args.group <= 0:
-        args.group = 4 if name == "C1" else 3
+        args.group = 4 if name == "C1" else 6
     H, W = synth.crop_shape(name)
     B = args.batch or synth.batch_size(name)
     cfg = synth.make_config(name, device=str(dev))
@@ -276,6 +281,9 @@ def main():
     model.decode_chains = args.chains
     model.decode_group = args.group
     model.reserved_blocks = args.reserve  # decode of batch i overlaps the encoder of batch i+1
+    model.reserved_cus = args.reserve_cus
+    if args.conv_kernel:
+        model.conv_kernel = args.conv_kernel
     host_img = synth.synth_images(B, H, W, seed=1000 + rank).pin_memory()  # each rank its own shard
     img = host_img.to(dev)
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
@@ -308,6 +316,8 @@ def main():
         torch.cuda.synchronize(dev)
         eng.profile(not with_transfers)
         bufs, toks = None, []
+        marks = [] if with_transfers else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                           for _ in range(steps)]
         if with_transfers:
             bufs = [torch.empty_like(img), torch.empty_like(img)]
             copy_stream = torch.cuda.Stream(device=dev)
@@ -331,7 +341,11 @@ def main():
                 free_ev[k].record()
                 toks.append(out[0])
             else:
+                if i < len(marks):
+                    marks[i][0].record()
                 out = step()
+                if i < len(marks):
+                    marks[i][1].record()
         model.synchronize()  # every batch fully decoded
         if with_transfers:
             host_tok = torch.stack(toks).to("cpu", non_blocking=True)  # D2H of the token ids of every timed batch
@@ -348,6 +362,11 @@ def main():
         assert early or out[0].shape == (B, L + 1), out[0].shape
         if with_transfers:
             assert host_tok.shape[0] == steps
+        if marks and rank == 0:  # time the caller's stream spends on one forward (encoder + cross K/V + waits for a K/V slot)
+            per = [a.elapsed_time(b) for a, b in marks]
+            gaps = [marks[i][1].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)]
+            log(f"caller stream: forward {sum(per) / len(per):.2f} ms avg (max {max(per):.2f}), gap between forwards "
+                f"{sum(gaps) / max(1, len(gaps)):.2f} ms avg")
         return elapsed, recs, out
 
     def roofline_of(recs, precision, steps):
@@ -355,7 +374,7 @@ def main():
         launch on the launch stream (d2t_profile_*)."""
         by_shape = {}
         for M_, N_, K_, ms in recs:
-            if ms > 0:
+            if ms > 0 and M_ > 0:
                 by_shape.setdefault((M_, N_, K_), []).append(ms)
         total_ms = sum(sum(v) for v in by_shape.values())
         total_flop = sum(2.0 * m * n * k * len(v) for (m, n, k), v in by_shape.items())
@@ -386,6 +405,15 @@ def main():
         if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
             roofline["mfma_issued_tflops"] = round(3 * achieved, 2)
             roofline["mfma_issued_frac"] = round(3 * achieved / peak, 4)
+        if os.environ.get("D2T_BENCH_SHAPES"):  # per-shape table of the timed region (in situ: beside the decode streams)
+            for shp, v in sorted(by_shape.items(), key=lambda kv: -sum(kv[1])):
+                log(f"  GEMM {shp}: {len(v) // max(1, steps)} launches/step, avg {sum(v) / len(v) * 1e3:.0f} us, "
+                    f"{sum(v) / steps:.2f} ms/step, {2.0 * shp[0] * shp[1] * shp[2] / (sum(v) / len(v) * 1e-3) / 1e12:.0f} TFLOP/s")
+        loops = [(N_, K_, ms) for M_, N_, K_, ms in recs if M_ == -1 and ms > 0]
+        if loops:  # the decode step loops that ran beside the encoders (HIP events on the decode streams)
+            roofline["decode_loops"] = {"count": len(loops), "rows": loops[0][0], "steps": loops[0][1],
+                                        "avg_ms": round(sum(l[2] for l in loops) / len(loops), 2),
+                                        "max_ms": round(max(l[2] for l in loops), 2)}
         return roofline
 
     elapsed, recs, out = timed(args.steps, args.warmup)
@@ -436,6 +464,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
                        "parallelism": f"dp{world} (batch-sharded, no collective)",
                        "pipelined": bool(model.pipelined), "reserved_blocks": model.reserved_blocks if model.pipelined else 0,
+                       "conv_kernel": model.conv_kernel, "reserved_cus": model.reserved_cus if model.pipelined else 0,
                        "decode_chains": model.decode_chains if model.pipelined else 1,
                        "decode_group": model.decode_group if model.pipelined else 1},
             **({"early_exit": {"end_bias": args.end_bias, "decode_steps_run": int(out[0].shape[1])}} if early else {}),

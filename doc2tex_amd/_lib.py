@@ -70,6 +70,8 @@ SIGNATURES = {
     "d2t_set_conv_precision": (_I, [_P, _I]),
     "d2t_set_reserved_blocks": (_I, [_P, _I]),
     "d2t_set_decode_chains": (_I, [_P, _I]),
+    "d2t_set_conv_kernel": (_I, [_P, _I]),
+    "d2t_set_reserved_cus": (_I, [_P, _I]),
     "d2t_train_forward": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "d2t_train_backward": (_I, [_P, _P, _P]),
     "d2t_train_grad": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),
     "d2t_op_conv2d_bf16x3": (_I, [_P] * 5 + [_I] * 12 + [_P]),
     "d2t_op_conv2d_bf16x3_split": (_I, [_P] * 5 + [_I] * 12 + [_P]),
+    "d2t_op_set_conv_kernel": (_I, [_I, _I]),
     "d2t_op_linear": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "d2t_op_maxpool2x2": (_I, [_P, _P] + [_I] * 8 + [_P]),
     "d2t_op_layernorm": (_I, [_P] * 4 + [_I, _I, C.c_float, _P]),

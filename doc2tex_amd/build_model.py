@@ -137,6 +137,10 @@ class Model(nn.Module):
         self.pipelined = False
         # pipelined mode: block slots the persistent convolution leaves free for the decode stream
         self.reserved_blocks = 64
+        # split-bf16 convolution kernel: 'pipelined' (256x128 tile, one block per CU, three LDS stages; default) or 'classic'
+        # (128x128, two blocks per CU); pipelined serving: compute units the pipelined kernel's grid leaves to the decode streams
+        self.conv_kernel = os.environ.get("D2T_CONV_KERNEL_NAME", "pipelined")
+        self.reserved_cus = 0
         # pipelined mode: decode loops in flight side by side (1 or 2)
         self.decode_chains = 1
         # pipelined mode: decode the rows of this many consecutive forward() calls in ONE step loop.  The decode step is a
@@ -225,6 +229,13 @@ class Model(nn.Module):
         if getattr(self._engine, "_reserved", None) != want:
             self._engine.set_reserved_blocks(want)
             self._engine._reserved = want
+        want_cus = self.reserved_cus if self.pipelined else 0
+        if getattr(self._engine, "_reserved_cus", None) != want_cus:
+            self._engine.set_reserved_cus(want_cus)
+            self._engine._reserved_cus = want_cus
+        if getattr(self._engine, "_conv_kernel", None) != self.conv_kernel:
+            self._engine.set_conv_kernel(self.conv_kernel)
+            self._engine._conv_kernel = self.conv_kernel
         if getattr(self._engine, "_chains", None) != self.decode_chains:
             self._engine.set_decode_chains(self.decode_chains)
             self._engine._chains = self.decode_chains

@@ -443,6 +443,9 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes
     if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;
+    // layers with >= 128 output channels: the pipelined 256x128 kernel (one block per CU, three LDS stages); dispatch by
+    // layer shape only (never by the row count), so a sample's results do not depend on its batch
+    if (p.pipelined && p.Cout >= 128) return launch_conv_bf16x3p(p, s);
     int tiles = mt * ((p.Cout + (p.Cout <= 64 ? 63 : 127)) / (p.Cout <= 64 ? 64 : 128));
     const int grid = (p.max_blocks > 0 && tiles > p.max_blocks) ? p.max_blocks : tiles;
     if (p.Cout <= 64) {

@@ -1,0 +1,400 @@
+// Split-bf16 implicit-GEMM convolution, pipelined form (the roofline kernel of the recognizer's backbone).
+//
+// Same arithmetic, operand layouts and K order as conv_bf16x3g_body (conv_bf16x3.hip): split-bf16 activation records
+// in, three v_mfma_f32_32x32x16_bf16 per product (lo*hi, hi*lo, hi*hi, fp32 accumulate) -- an output element goes through
+// the SAME sequence of MFMA accumulations, so results are bit-identical to that kernel (tests assert it).  What differs is
+// how a CU is kept busy:
+//
+//   * block tile 256 x 128 x 32, 8 waves as 4 (M) x 2 (N), wave tile 64 x 64: 16 ds_read_b128 per 24 MFMAs
+//     (0.67 per MFMA instead of 1.0) and 48 KB of L2 -> LDS traffic per 1536 MFMA cycles of a SIMD instead of 64 KB;
+//   * ONE block per CU holding THREE LDS stages (144 KB): the LDS-DMA of K-step t+2 is issued while K-step t is computed,
+//     the issuer waits only for its OWN pieces of step t with a counted `s_waitcnt vmcnt(N)` (the pieces of step t+1 stay
+//     in flight), and a K-step costs one raw s_barrier -- no `vmcnt(0)` drain, no second barrier
+//     (cdna_hip_programming.md "Pipelining across barriers": the 3-buffer span);
+//   * LOADER WAVES: the block is 8 compute waves + 4 loader waves (one per SIMD).  A K-step's 48 KB go through the CU's
+//     vector-memory path at 64 B/clk = 768 cycles -- half of the 1536 MFMA cycles a SIMD needs for the step.  When the
+//     compute waves issue the LDS-DMA themselves they all sit in that queue at the same time (one block per CU: nobody
+//     else has MFMAs to issue) and the two phases add up: measured 3090 cycles per K-step.  Loader waves own the whole
+//     vector-memory side (addresses, LDS-DMA, counted waits); compute waves only ds_read and MFMA;
+//   * persistent over tiles with a grid of (CUs - reserved): whole rounds of tiles for the dominant layer
+//     (2064 tiles = 9 x 229.3) and the remaining CUs are free for the latency-bound decode kernels of the previous batch.
+//
+// Hazards (checked against the rules of the guide):
+//   RAW  a stage is read only after every wave has passed the barrier that follows its own counted vmcnt wait for that
+//        stage's pieces ("read a staged buffer after the wait that retires it and a barrier the reader has passed");
+//   WAR  stage (t+2)%3 == (t-1)%3 is overwritten by DMAs issued after barrier t; every wave has finished the ds_reads of
+//        step t-1 before it arrives there (they feed MFMAs that precede the barrier in program order, and the compiler's
+//        lgkmcnt waits sit in front of those MFMAs).
+#include <cstdlib>
+
+#include "conv_common.h"
+
+namespace d2t {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+namespace {
+constexpr int PBK = 32;   // K-step
+constexpr int PROW = 64;  // bytes per LDS row of one plane (32 bf16)
+__device__ __forceinline__ int pswz(int row, int c) { return c ^ ((row >> 2) & 3); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field on gfx9");
+  // s_waitcnt simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; leave expcnt / lgkmcnt untouched (max)
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+}  // namespace
+
+// Second phase of the wide epilogue (conv_common.h conv_epilogue_wide), run by EVERY thread of the block, loader waves
+// included: the fp32 [BM][BN] tile is in LDS (32-float column blocks XOR-ed with bit 2 of the row); a thread owns four
+// consecutive channels of one output row.  Same arithmetic per element in the same order as conv_epilogue:
+// v = acc + bias; v += res | (res_hi + res_lo); activation; split.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned char* smem, int m0, int n0, int tid) {
+  const float* tile = reinterpret_cast<const float*>(smem);
+  constexpr int QPR = BN / 4;  // 4-channel quads per tile row
+#pragma unroll 2
+  for (int idx = tid; idx < BM * QPR; idx += NT) {
+    const int row = idx / QPR, q = idx % QPR;
+    const int m = m0 + row, n = n0 + q * 4;
+    if (m >= p.M || n >= p.Cout) continue;
+    const int col = (q * 4) ^ (((row >> 2) & 1) << 5);
+    const float4 a = *reinterpret_cast<const float4*>(tile + row * BN + col);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+    }
+    const size_t off = (size_t)m * p.Cout + n;
+    const size_t pi = plane_idx((size_t)m, n, p.Cout);
+    if (p.res) {
+      const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
+      v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+    }
+    if (p.res_hi) {
+      const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
+      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
+      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
+      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
+      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    if (p.out_hi) {
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint2 oh, ol;
+      oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+      *reinterpret_cast<uint2*>(p.out_hi + pi) = oh;
+      *reinterpret_cast<uint2*>(p.out_hi + pi + 32) = ol;
+    } else {
+      *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// The vector-memory side of a tile for ONE issuing wave: which 16-row pieces of the A / B planes it copies, their per-lane
+// source addresses (XOR-swizzled k-chunk applied on the SOURCE: the LDS destination of a wave's LDS-DMA is linear) and the
+// per-row validity mask over the filter taps (out-of-image taps and rows beyond M / Cout read a zero page).
+template <int BM, int BN, int LW, int ABL>
+struct DmaIssuer {
+  static constexpr int AJ = BM / (16 * LW), BJ = BN / (16 * LW);
+  static constexpr int PLANE_A = BM * PROW, PLANE_B = BN * PROW, STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  static constexpr int PER_STEP = 2 * AJ + 2 * BJ;  // LDS-DMA instructions per K-step
+  static_assert(AJ >= 1 && BJ >= 1, "tile too small for the issuing waves");
+  static_assert(PER_STEP <= 31, "two K-steps of pieces must fit the 6-bit vmcnt");
+  int a_off[AJ];
+  unsigned a_mask[AJ];
+  const uint16_t* b_hi[BJ];
+  const uint16_t* b_lo[BJ];
+  int kh, kw, c0, lw;
+
+  __device__ __forceinline__ void setup(const ConvP& p, int m0, int n0, int lw_, int lane) {
+    lw = lw_;
+    kh = kw = c0 = 0;
+    const int lr = lane >> 2, pos = lane & 3;
+    const int ohow = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int row = (lw * AJ + j) * 16 + lr;
+      const int c = pswz(row, pos);  // the chunk that belongs at LDS position `pos` of this row
+      const int m = m0 + row;
+      a_off[j] = 0;
+      a_mask[j] = 0;
+      if (m < p.M) {
+        const int b = m / ohow, rem = m - b * ohow;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+        a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cin * 2 + c * 8;
+        for (int y = 0; y < p.KH; ++y)
+          for (int x = 0; x < p.KW; ++x)
+            if ((unsigned)(ih0 + y) < (unsigned)p.H && (unsigned)(iw0 + x) < (unsigned)p.W) a_mask[j] |= 1u << (y * p.KW + x);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = (lw * BJ + j) * 16 + lr;
+      const int c = pswz(row, pos);
+      const int n = n0 + row;
+      const bool ok = n < p.Cout;
+      b_hi[j] = ok ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
+      b_lo[j] = ok ? p.w_lo + (size_t)n * p.K + c * 8 : nullptr;
+    }
+  }
+  // K-steps must be issued in order (the tap / channel-chunk cursor advances)
+  __device__ __forceinline__ void issue(const ConvP& p, unsigned char* smem, int kt, int buf) {
+    unsigned char* ah = smem + buf * STAGE;
+    unsigned char* al = ah + PLANE_A;
+    unsigned char* bh = al + PLANE_A;
+    unsigned char* bl = bh + PLANE_B;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+    const int tap = kh * p.KW + kw;
+    const int tapoff = ((kh * p.W + kw) * p.Cin + c0) * 2;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const bool ok = (a_mask[j] >> tap) & 1u;
+      const uint16_t* src = ok ? p.in_hi + (a_off[j] + tapoff) : zero;
+      const int piece = (lw * AJ + j) * 1024;
+      if (ABL == 1) continue;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ah + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ok ? src + 32 : zero, (lds_ptr_t)(al + piece), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int piece = (lw * BJ + j) * 1024;
+      if (ABL == 1) continue;
+      __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bh + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bl + piece), 16, 0, 0);
+    }
+    if (++kw == p.KW) {
+      kw = 0;
+      if (++kh == p.KH) { kh = 0; c0 += 32; }
+    }
+  }
+};
+
+// block tile BM x BN, compute-wave grid WM x WN, NL dedicated loader waves (0: the compute waves issue the LDS-DMA themselves,
+// each its share, right after the K-step's barrier); ABL: ablation probes (1 no DMA, 2 no MFMA, 3 no ds_read / MFMA)
+template <int BM, int BN, int WM, int WN, int NL, int ABL = 0>
+__device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char* smem) {
+  constexpr int NW = WM * WN, NT = (NW + NL) * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 32, NJ = WTN / 32;
+  static_assert(MI >= 1 && NJ >= 1, "tile too small for the wave grid");
+  using Issuer = DmaIssuer<BM, BN, (NL > 0 ? NL : NW), ABL>;
+  constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, PER_STEP = Issuer::PER_STEP;
+  static_assert(BM * BN * 4 <= 3 * STAGE, "the fp32 epilogue tile must fit in the staging area");
+
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool loader = NL > 0 && wave >= NW;  // wave-uniform
+  if (p.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
+  const int KT = p.K / PBK;
+
+  // Tile order: in every round the blocks that share an XCD (equal blockIdx % 8) take consecutive tiles = the column
+  // tiles of the same pixels and the neighbouring rows, so they share that XCD's L2 (bijective for any grid size).
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * BM;
+    const int n0 = (tile % nt) * BN;
+
+    // Every wave executes exactly the same sequence of barriers per tile: one per K-step (barrier kt: "stage kt is complete,
+    // stage kt-1 is free"), one before the epilogue, and the epilogue's own two.
+    if (loader) {
+      Issuer dma;
+      dma.setup(p, m0, n0, wave - NW, lane);
+      dma.issue(p, smem, 0, 0);
+      if (KT > 1) dma.issue(p, smem, 1, 1);
+      int nxt2 = 2;  // stage of K-step kt+2
+      for (int kt = 0; kt < KT; ++kt) {
+        // this wave's pieces of K-step kt have landed (those of kt+1 may still be in flight) ...
+        if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();  // ... and so have the other loaders'; the compute waves are done reading K-step kt-1
+        if (kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+      }
+      __builtin_amdgcn_s_barrier();  // (compute waves: done with the last stage)
+      __builtin_amdgcn_s_barrier();  // (compute waves: accumulators are in the LDS tile)
+      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      __builtin_amdgcn_s_barrier();  // the tile is staging memory again
+      continue;
+    }
+
+    Issuer dma;  // NL == 0 only: this compute wave's share of the LDS-DMA
+    if (NL == 0) {
+      dma.setup(p, m0, n0, wave, lane);
+      dma.issue(p, smem, 0, 0);
+      if (KT > 1) dma.issue(p, smem, 1, 1);
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ds_read byte offsets of this lane's fragments inside a plane, for the two 16-deep halves of a K-step
+    int offa[2][MI], offb[2][NJ];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = 2 * kk + h;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WTM + i * 32 + r;
+        offa[kk][i] = row * PROW + pswz(row, c) * 16;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn * WTN + j * 32 + r;
+        offb[kk][j] = row * PROW + pswz(row, c) * 16;
+      }
+    }
+    int cur = 0, nxt2 = 2;  // stage of K-step kt / kt+2
+    for (int kt = 0; kt < KT; ++kt) {
+      if (NL == 0) {  // this wave's own pieces of K-step kt have landed (those of kt+1 may still be in flight)
+        if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
+      if (NL == 0 && kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
+      __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the ds_reads / MFMAs
+      const unsigned char* ah = smem + cur * STAGE;
+      const unsigned char* al = ah + PLANE_A;
+      const unsigned char* bh = al + PLANE_A;
+      const unsigned char* bl = bh + PLANE_B;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (ABL == 3) continue;
+        bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[kk][i]);
+          fal[i] = *reinterpret_cast<const bf16x8*>(al + offa[kk][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[kk][j]);
+          fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[kk][j]);
+        }
+        if (ABL == 2) {  // keep the reads alive, drop the matrix work
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fbh[j]), "v"(fbl[j]));
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the last stages: the staging area becomes the epilogue's fp32 tile
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = wm * WTM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int col = (wn * WTN + j * 32 + r) ^ (((row >> 2) & 1) << 5);
+            tile_f[row * BN + col] = acc[i][j][reg];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+    } else {
+      __builtin_amdgcn_s_barrier();
+      conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+// non-template entry points (the host-side stub of a __global__ template using the LDS-DMA builtin is not emitted)
+__global__ __launch_bounds__(768, 3) __attribute__((amdgpu_num_vgpr(112))) void conv_bf16x3p_256x128(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4>(p, smem);
+}
+// the dominant GEMM shape (512 -> 512 channels, 3x3: K = 4608) under its own symbol, so that rocprofv3's per-kernel rows
+// separate it from the other layers
+__global__ __launch_bounds__(768, 3) __attribute__((amdgpu_num_vgpr(112))) void conv_bf16x3p_256x128_k4608(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4>(p, smem);
+}
+
+// the same without dedicated loader waves: 8 waves (2 per SIMD), the compute waves issue the LDS-DMA themselves
+__global__ __launch_bounds__(512, 2) void conv_bf16x3p_256x128_w8(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 0>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv_bf16x3p_256x128_w8_k4608(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 0>(p, smem);
+}
+
+// ablation probes of the dominant shape (tools/conv_bench.py, D2T_CONV_ABL=1|2|3): results are garbage by construction
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p_probe_no_dma(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4, 1>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p_probe_no_mfma(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4, 2>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p_probe_dma_only(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4, 3>(p, smem);
+}
+
+// grid of the pipelined kernel: one block per CU on (CUs - reserved) CUs, never more blocks than tiles
+hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      return hipErrorInvalidDevice;
+    cus = n;
+  }
+  static const int prio = getenv("D2T_CONV_PRIO") ? atoi(getenv("D2T_CONV_PRIO")) : 0;
+  ConvP q = p;
+  q.wave_prio = prio;
+  const ConvP& p2 = q;
+  const int tiles = ((p.M + 255) / 256) * ((p.Cout + 127) / 128);
+  int grid = cus - (p.reserved_cus > 0 ? p.reserved_cus : 0);
+  if (grid < 8) grid = 8;
+  if (grid > tiles) grid = tiles;
+  static const int abl = getenv("D2T_CONV_ABL") ? atoi(getenv("D2T_CONV_ABL")) : 0;
+  static const int loaders = getenv("D2T_CONV_LOADERS") ? atoi(getenv("D2T_CONV_LOADERS")) : 4;
+  if (abl == 1) hipLaunchKernelGGL(conv_bf16x3p_probe_no_dma, dim3(grid), dim3(768), 0, s, p2);
+  else if (abl == 2) hipLaunchKernelGGL(conv_bf16x3p_probe_no_mfma, dim3(grid), dim3(768), 0, s, p2);
+  else if (abl == 3) hipLaunchKernelGGL(conv_bf16x3p_probe_dma_only, dim3(grid), dim3(768), 0, s, p2);
+  else if (loaders == 0 && p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_w8_k4608, dim3(grid), dim3(512), 0, s, p2);
+  else if (loaders == 0) hipLaunchKernelGGL(conv_bf16x3p_256x128_w8, dim3(grid), dim3(512), 0, s, p2);
+  else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_k4608, dim3(grid), dim3(768), 0, s, p2);
+  else hipLaunchKernelGGL(conv_bf16x3p_256x128, dim3(grid), dim3(768), 0, s, p2);
+  return hipGetLastError();
+}
+
+}  // namespace d2t

@@ -94,6 +94,8 @@ struct d2t_ctx {
   bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
+  int conv_pipelined = 1;    // d2t_set_conv_kernel: 1 = pipelined 256x128 split-bf16 kernel (one block per CU), 0 = 128x128 (two per CU)
+  int reserved_cus = 0;      // d2t_set_reserved_cus: CUs the pipelined kernel's grid leaves to other streams (decode)
   int device = 0;            // HIP device the context was created on: every stream, event and buffer lives there
 
   // packed weights
@@ -162,6 +164,10 @@ struct d2t_ctx {
   bool profiling = false;
   struct ProfRec { int M, N, K; hipEvent_t a, b; };
   std::vector<ProfRec> prof;
+  // debug timeline of the decode kernels (env D2T_DECODE_TRACE): [slot][2] ticks, one slot per kernel node of a captured loop
+  unsigned long long* dtrace = nullptr;
+  int dtrace_next = 0;
+  static constexpr int DTRACE_SLOTS = 8192;
   d2t_train_state* train = nullptr;  // lazily created by d2t_train_* (train.hip)
 };
 

@@ -3,11 +3,37 @@
 // nn.TransformerDecoder recomputes over the whole prefix at every step in the
 // reference (prediction_head/tfm.py:125-140).  All position-dependent values are
 // read from a device-side step counter so one captured hipGraph replays for every step.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace d2t {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifndef D2T_DECODE_PRIO
+#define D2T_DECODE_PRIO 3
+#endif
+
+// The decode step is a dependent chain of small latency-bound kernels that runs BESIDE the next batches' convolutions
+// (pipelined serving).  Instruction issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md "Two waves per
+// SIMD" item 2): a decode wave is always younger than the persistent convolution waves it shares the SIMD with and would
+// get only the issue slots they leave.  Its few instructions cost the matrix-bound convolution next to nothing, so the
+// decode kernels simply outrank it.
+__device__ __forceinline__ void decode_wave_priority() { __builtin_amdgcn_s_setprio(D2T_DECODE_PRIO); }
+
+// debug timeline (D2T_DECODE_TRACE): every block folds its own start / end time into the launch's record
+struct TraceScope {
+  unsigned long long* t;
+  __device__ __forceinline__ explicit TraceScope(unsigned long long* tr) : t(tr) {
+    if (t && threadIdx.x == 0) atomicMin(t, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+  __device__ __forceinline__ ~TraceScope() {
+    if (t) {
+      __syncthreads();
+      if (threadIdx.x == 0) atomicMax(t + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+  }
+};
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -27,6 +53,8 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // ---------------------------------------------------------------------------
 template <int NW, int NCH, int MT>  // K == NW * NCH * 16; block tile (16*MT) rows x 16 columns
 __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p) {
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
   constexpr int KS = NCH * 16;
   constexpr int ROWS = 16 * MT;
   __shared__ float part[NW][ROWS][17];
@@ -52,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p)
     }
   }
   {
-    const float* src = p.w + (size_t)(nok ? n : 0) * p.K + k0;
+    const float* src = p.w + (size_t)(nok ? n : 0) * (p.wld ? p.wld : p.K) + k0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       b[c] = *reinterpret_cast<const float4*>(src + c * 16);
@@ -190,6 +218,13 @@ __global__ __launch_bounds__(256) void skinny_generic_kernel(const SkinnyP p) {
   }
 }
 
+// small = 1: the 256-thread forms of the decode kernels (one wave per SIMD, <= 128 VGPRs), which fit on a CU beside the
+// pipelined convolution kernel's three 128-register waves per SIMD; identical arithmetic per row, so identical results
+static int decode_small() {
+  static const int v = getenv("D2T_DECODE_SMALL") ? atoi(getenv("D2T_DECODE_SMALL")) : 0;
+  return v;
+}
+
 hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % 16 != 0 || p.ldx % 4 != 0) return hipErrorInvalidValue;
@@ -203,6 +238,16 @@ hipError_t launch_skinny(const SkinnyP& p, hipStream_t s) {
   } while (0)
   if (p.K == 256) D2T_SK(4, 4);
   else if (p.K == 512) D2T_SK(8, 4);
+  else if (p.K == 1024 && decode_small() && !p.ln_g && !p.step_ptr) {
+    // two 256-thread passes over the halves of K (second pass accumulates onto the first through the residual input)
+    SkinnyP a = p, b = p;
+    a.K = 512; a.ldx = p.ldx; a.w = p.w; a.wld = p.K;
+    b.K = 512; b.x = p.x + 512; b.w = p.w + 512; b.wld = p.K; b.bias = nullptr; b.res = p.y; b.ldres = p.ldy;
+    a.act = ACT_NONE;
+    if (p.act != ACT_NONE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((skinny_splitk_kernel<4, 8, 1>), dim3((p.N + 15) / 16, (p.M + 15) / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((skinny_splitk_kernel<4, 8, 1>), dim3((p.N + 15) / 16, (p.M + 15) / 16), dim3(256), 0, s, b);
+  }
   else if (p.K == 1024) D2T_SK(8, 8);
   else {
     if (p.ln_g) return hipErrorInvalidValue;
@@ -341,6 +386,8 @@ hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start,
 // end-of-sequence bookkeeping stays on the device.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void argmax_embed_kernel(const ArgmaxP p) {
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
   const int b = blockIdx.x, lane = threadIdx.x;
   const int t = *p.step_ptr;
   const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
@@ -446,9 +493,9 @@ __device__ __forceinline__ void row_attention(const float* q, const float* Kc, c
 }
 
 // out_part[g][n] = sum_{k in group g} in[k] * Wt[k][n]; caller reduces over g after a barrier
-template <int D>
+template <int D, int NTH>
 __device__ __forceinline__ void row_gemv(const float* in_s, const float* __restrict__ Wt, float* part_s, int tid) {
-  constexpr int LPR = D / 4, G = 512 / LPR, KG = D / G;
+  constexpr int LPR = D / 4, G = NTH / LPR, KG = D / G;
   const int lr = tid % LPR, g = tid / LPR;
   const float* w = Wt + (size_t)(g * KG) * D + lr * 4;
   const float* in = in_s + g * KG;
@@ -463,28 +510,34 @@ __device__ __forceinline__ void row_gemv(const float* in_s, const float* __restr
   *reinterpret_cast<float4*>(part_s + g * D + lr * 4) = acc;
 }
 
-template <int D, int HD>
-__global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
-  constexpr int G = 512 / (D / 4);
+template <int D, int HD, int NTH>  // NTH = 512: one wave per head; 256: four waves, two heads each (<= 128 VGPRs, so that a
+                                    // block fits on a CU next to the pipelined convolution's three waves per SIMD)
+__global__ __launch_bounds__(NTH, NTH == 256 ? 4 : 2) void decoder_row_kernel(const DecRowP p) {
+  constexpr int G = NTH / (D / 4);
+  constexpr int HPW = 8 * 64 / NTH;  // heads per wave
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
   __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D], part_s[G * D];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int b = blockIdx.x;
   const int t = *p.step_ptr;
   const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
-  // ---- self-attention, wave = head ----
-  {
-    float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)wave * p.s_Lmax * HD;
-    float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)wave * p.s_Lmax * HD;
-    const float* curk = qkv + D + wave * HD;
-    const float* curv = qkv + 2 * D + wave * HD;
+  // ---- self-attention, one head per wave (and pass) ----
+#pragma unroll
+  for (int hp = 0; hp < HPW; ++hp) {
+    const int head = wave + hp * (NTH / 64);
+    float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+    float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+    const float* curk = qkv + D + head * HD;
+    const float* curv = qkv + 2 * D + head * HD;
     if (lane < HD) {
       Kc[(size_t)t * HD + lane] = curk[lane];
       Vc[(size_t)t * HD + lane] = curv[lane];
     }
-    row_attention<HD, 4>(qkv + wave * HD, Kc, Vc, curk, curv, t, t + 1, a_s + wave * HD, lane);
+    row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s + head * HD, lane);
   }
   __syncthreads();
-  row_gemv<D>(a_s, p.wo_t, part_s, tid);
+  row_gemv<D, NTH>(a_s, p.wo_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bo[tid] + p.xres[(size_t)b * D + tid];
@@ -514,7 +567,7 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
     }
   }
   __syncthreads();
-  row_gemv<D>(x1_s, p.wq_t, part_s, tid);
+  row_gemv<D, NTH>(x1_s, p.wq_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bq[tid];
@@ -523,15 +576,17 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
     q2_s[tid] = v;
   }
   __syncthreads();
-  // ---- cross-attention over the memory K/V, wave = head ----
-  {
+  // ---- cross-attention over the memory K/V, one head per wave (and pass) ----
+#pragma unroll
+  for (int hp = 0; hp < HPW; ++hp) {
+    const int head = wave + hp * (NTH / 64);
     const int cb = p.c_row_map ? p.c_row_map[b] : b;
-    const float* Kc = p.ck + (size_t)cb * p.c_batch_stride + (size_t)wave * p.T * HD;
-    const float* Vc = p.cv + (size_t)cb * p.c_batch_stride + (size_t)wave * p.T * HD;
-    row_attention<HD, 8>(q2_s + wave * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + wave * HD, lane);
+    const float* Kc = p.ck + (size_t)cb * p.c_batch_stride + (size_t)head * p.T * HD;
+    const float* Vc = p.cv + (size_t)cb * p.c_batch_stride + (size_t)head * p.T * HD;
+    row_attention<HD, 8>(q2_s + head * HD, Kc, Vc, nullptr, nullptr, -1, p.T, a_s + head * HD, lane);
   }
   __syncthreads();
-  row_gemv<D>(a_s, p.wco_t, part_s, tid);
+  row_gemv<D, NTH>(a_s, p.wco_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bco[tid] + x1_s[tid];
@@ -543,8 +598,10 @@ __global__ __launch_bounds__(512) void decoder_row_kernel(const DecRowP p) {
 
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
   if (p.heads != 8) return hipErrorInvalidValue;
-  if (p.D == 256) hipLaunchKernelGGL((decoder_row_kernel<256, 32>), dim3(p.M), dim3(512), 0, s, p);
-  else if (p.D == 512) hipLaunchKernelGGL((decoder_row_kernel<512, 64>), dim3(p.M), dim3(512), 0, s, p);
+  const bool small = decode_small() != 0;
+  if (p.D == 256 && small) hipLaunchKernelGGL((decoder_row_kernel<256, 32, 256>), dim3(p.M), dim3(256), 0, s, p);
+  else if (p.D == 256) hipLaunchKernelGGL((decoder_row_kernel<256, 32, 512>), dim3(p.M), dim3(512), 0, s, p);
+  else if (p.D == 512) hipLaunchKernelGGL((decoder_row_kernel<512, 64, 512>), dim3(p.M), dim3(512), 0, s, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

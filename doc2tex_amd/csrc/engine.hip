@@ -112,6 +112,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
+  p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus;
   if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
   if (res) {
     if (res->split) { p.res_hi = res->planes(); } else { p.res = res->p; }
@@ -295,6 +296,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
+  if (const char* e = getenv("D2T_CONV_KERNEL")) c->conv_pipelined = atoi(e) != 0;
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
@@ -778,6 +780,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
+    p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus;
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -846,9 +849,15 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
 
 struct Lin { const float* x; int ldx; const LinW* w; const float* res; float* y; int ldy; int act; };
 
+unsigned long long* trace_slot(d2t_ctx* c) {
+  if (!c->dtrace || c->dtrace_next >= d2t_ctx::DTRACE_SLOTS) return nullptr;
+  return c->dtrace + 2 * (size_t)(c->dtrace_next++);
+}
+
 hipError_t skinny(hipStream_t s, const Lin& l, int M, const LNW* ln = nullptr, float* ln_out = nullptr,
-                  const int* step_ptr = nullptr, long long step_stride = 0) {
+                  const int* step_ptr = nullptr, long long step_stride = 0, unsigned long long* trace = nullptr) {
   SkinnyP p{};
+  p.trace = trace;
   p.x = l.x; p.w = l.w->w; p.bias = l.w->b; p.res = l.res; p.y = l.y;
   p.M = M; p.K = l.w->K; p.N = l.w->N; p.ldx = l.ldx; p.ldy = l.ldy; p.ldres = l.w->N; p.act = l.act;
   p.step_ptr = step_ptr; p.out_step_stride = step_stride;
@@ -892,9 +901,9 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
   for (int l = 0; l < g.dec_layers; ++l) {
     const DecLayer& L = c->dec[l];
     if (l == 0) {
-      TRY(skinny(s, Lin{bf.x, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M));
+      TRY(skinny(s, Lin{bf.x, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c)));
     } else {
-      TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x));
+      TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x, nullptr, 0, trace_slot(c)));
     }
     DecRowP r{};
     r.qkv = bf.qkv; r.qkv_stride = 3 * d; r.xres = bf.x;
@@ -907,12 +916,13 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.wo_t = L.sa_out_t; r.bo = L.sa_out.b; r.ln1_g = L.n1.g; r.ln1_b = L.n1.b; r.eps = 1e-5f;
     r.wq_t = L.ca_q_t; r.bq = L.ca_q.b; r.wco_t = L.ca_out_t; r.bco = L.ca_out.b;
     r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
+    r.trace = trace_slot(c);
     TRY(launch_decoder_row(r, s));
-    TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2));
-    TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M));
+    TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c)));
+    TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c)));
   }
   TRY(skinny(s, Lin{bf.y3, d, &c->out_proj, nullptr, logits, (int)logit_row_stride, ACT_NONE}, M,
-             &c->dec[g.dec_layers - 1].n3, nullptr, step, logit_step_stride));
+             &c->dec[g.dec_layers - 1].n3, nullptr, step, logit_step_stride, trace_slot(c)));
 #undef TRY
   return hipSuccess;
 }
@@ -965,6 +975,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   auto one_step = [&](hipStream_t st) -> hipError_t {
     hipError_t e = decode_step(c, st, bf, B, T, B, false, logits, (long long)S * V, V);
     if (e != hipSuccess) return e;
+    am.trace = trace_slot(c);
     return launch_argmax_embed(am, st);
   };
 
@@ -982,6 +993,10 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
         break;
       }
     if (!exec) {
+      if (getenv("D2T_DECODE_TRACE")) {  // debug timeline: the kernel nodes of THIS captured loop get slots 0 .. n-1
+        if (!c->dtrace) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dtrace), (size_t)d2t_ctx::DTRACE_SLOTS * 16));
+        c->dtrace_next = 0;
+      }
       hipGraph_t gr = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       hipError_t e = hipSuccess;
@@ -1004,6 +1019,8 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
     }
   }
   int steps = S;
+  d2t_ctx::ProfRec drec{-1, B, S, nullptr, nullptr};  // profiling: the decode loop as ONE record (M = -1, N = rows, K = steps)
+  if (c->profiling && hipEventCreate(&drec.a) == hipSuccess && hipEventCreate(&drec.b) == hipSuccess) HIPCHK(c, hipEventRecord(drec.a, s));
   for (int t = 0; t < S; t += (use_graph ? steps_per_graph : 1)) {
     if (use_graph) HIPCHK(c, hipGraphLaunch(exec, s));
     else HIPCHK(c, one_step(s));
@@ -1012,6 +1029,10 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
       HIPCHK(c, hipStreamSynchronize(s));
       if (c->h_pinned[0] > 0) { steps = c->h_pinned[0]; break; }
     }
+  }
+  if (drec.b) {
+    HIPCHK(c, hipEventRecord(drec.b, s));
+    c->prof.push_back(drec);
   }
   if (tokens != user_tokens) {
     HIPCHK(c, hipMemcpyAsync(user_logits, logits, log_bytes, hipMemcpyDeviceToDevice, s));
@@ -1438,6 +1459,21 @@ int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
 
 int64_t d2t_decode_last_ticket(const d2t_ctx* c) { return c ? c->last_ticket : 0; }
 
+// debug (undocumented, env D2T_DECODE_TRACE): reset / read the per-kernel-node timeline of the most recently captured loop
+int d2t_debug_trace(d2t_ctx* c, unsigned long long* out, int32_t max_slots, int32_t reset) {
+  DevGuard dg_(c);
+  if (!c || !c->dtrace) return 0;
+  hipDeviceSynchronize();
+  const int n = std::min<int>(max_slots, c->dtrace_next);
+  if (out && n > 0) hipMemcpy(out, c->dtrace, (size_t)n * 16, hipMemcpyDeviceToHost);
+  if (reset) {
+    std::vector<unsigned long long> init((size_t)d2t_ctx::DTRACE_SLOTS * 2);
+    for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; }
+    hipMemcpy(c->dtrace, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+  }
+  return n;
+}
+
 // 1: the decode with this ticket has completed; 0: still running; < 0: error.  Tickets older than the event ring are
 // complete by construction: a chain is an in-order stream and the ring holds TICKET_RING >> 2 chains' worth of decodes.
 int d2t_decode_query(d2t_ctx* c, int64_t ticket) {
@@ -1747,6 +1783,20 @@ int d2t_set_reserved_blocks(d2t_ctx* c, int32_t blocks) {
   return D2T_OK;
 }
 
+int d2t_set_reserved_cus(d2t_ctx* c, int32_t cus) {
+  DevGuard dg_(c);
+  if (!c || cus < 0 || cus > 128) return fail(c, D2T_EINVAL, "reserved CUs must be in [0, 128]");
+  c->reserved_cus = cus;
+  return D2T_OK;
+}
+
+int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
+  DevGuard dg_(c);
+  if (!c || (kind != 0 && kind != 1)) return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU) or 1 (pipelined 256x128)");
+  c->conv_pipelined = kind;
+  return D2T_OK;
+}
+
 int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
   DevGuard dg_(c);
   if (!c || chains < 1 || chains > 2) return fail(c, D2T_EINVAL, "decode chains must be 1 or 2");
@@ -1843,6 +1893,15 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
+// kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
+static int g_op_conv_kind = 1, g_op_reserved_cus = 0;
+int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
+  if ((kind != 0 && kind != 1) || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;
+  g_op_conv_kind = kind;
+  g_op_reserved_cus = reserved_cus;
+  return D2T_OK;
+}
+
 int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
                                int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream) {
@@ -1867,6 +1926,7 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   ConvP p{};
   p.w = wp; p.w_hi = whi; p.w_lo = wlo; p.bias = bias;
   p.in_hi = xs; p.out_hi = ys; p.res_hi = rs; p.zero16 = zero;
+  p.pipelined = g_op_conv_kind; p.reserved_cus = g_op_reserved_cus;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;

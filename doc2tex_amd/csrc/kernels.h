@@ -27,6 +27,9 @@ struct ConvP {
   const uint16_t* res_hi;
   const void* zero16;
   int max_blocks;        // > 0: launch at most this many (persistent) blocks of the split-bf16 kernel
+  int reserved_cus;      // pipelined split-bf16 kernel (one block per CU): CUs left free for other streams' kernels
+  int wave_prio;         // pipelined kernel: s_setprio of its waves (experiments; 0 = default)
+  int pipelined;         // != 0: take the pipelined 256x128 kernel (conv_bf16x3p.hip) when the layer qualifies
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
@@ -45,6 +48,7 @@ struct ConvP {
 };
 hipError_t launch_conv(const ConvP& p, hipStream_t s);         // fp32 MFMA, or bf16x3 when p.w_hi != nullptr
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s);
+hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s);  // 256x128 tile, 3 LDS stages, one block per CU
 // hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 
@@ -54,6 +58,8 @@ struct SkinnyP {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int M, K, N;
   int ldx, ldy, ldres;  // row strides (floats)
+  int wld;              // row stride of w (floats); 0 = K
+  unsigned long long* trace;  // debug (D2T_DECODE_TRACE): [2] = min block start / max block end, s_memrealtime ticks
   int act;
   const int* step_ptr;
   long long out_step_stride;
@@ -186,6 +192,7 @@ struct DecRowP {
   float* y2;                          // [M][D]
   const int* step_ptr;
   int M, D, heads;
+  unsigned long long* trace;          // debug (D2T_DECODE_TRACE), as SkinnyP::trace
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
@@ -205,6 +212,7 @@ struct ArgmaxP {
   int B, V, end_token;
   // next-step embedding written by the same kernel: x[b] = emb[token]*sqrt(d) + pe[t+1]
   const float* emb; const float* pe; float* x; int d;
+  unsigned long long* trace;  // debug (D2T_DECODE_TRACE), as SkinnyP::trace
 };
 hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s);
 

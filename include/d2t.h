@@ -225,6 +225,13 @@ int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
  * for a convolution block to retire.  0 (default) = use every slot. */
 int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
 
+/* The split-bf16 convolution kernel and its grid.  kind 1 (default): the pipelined 256x128 kernel -- ONE block per CU
+ * holding three LDS stages, LDS-DMA two K-steps ahead behind counted waits; its persistent grid spans (CUs - reserved)
+ * compute units, d2t_set_reserved_cus leaving the rest to the decode streams of the previous batches (pipelined serving;
+ * also the place where the tile count of the dominant layer comes out in whole rounds).  kind 0: the 128x128 kernel with
+ * two blocks per CU (d2t_set_reserved_blocks applies to that one).  Results are bit-identical between the two. */
+int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
+int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
 /* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
  * its own stream, self-attention cache and workspace, so with 2 the step loops of two consecutive batches
  * run side by side (the loop is a dependent chain of small kernels that cannot fill the chip alone). */
@@ -294,6 +301,9 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
                          int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
 /* Same again on the split-activation kernel: x, residual and y cross the kernel boundary as bf16 hi/lo
  * planes (split / merged around the launch by this test entry point). */
+/* which split-bf16 kernel d2t_op_conv2d_bf16x3_split launches (d2t_set_conv_kernel / d2t_set_reserved_cus of a context,
+ * but process-wide: tests and tools only) */
+int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus);
 int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
                                int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);
