@@ -60,6 +60,8 @@ SIGNATURES = {
     "d2t_decode_attn_greedy": (_I, [_P, _P, _I, _I, _I, _P, _P, C.POINTER(_I), _P]),
     "d2t_decode_greedy_async": (_I, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "d2t_decode_wait": (_I, [_P, _P, _I]),
+    "d2t_decode_greedy_submit": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P, _P, C.POINTER(_L)]),
+    "d2t_decode_steps": (_I, [_P, _L, C.POINTER(_I), _I, C.POINTER(_I)]),
     "d2t_decode_last_ticket": (_L, [_P]),
     "d2t_decode_query": (_I, [_P, _L]),
     "d2t_decode_wait_ticket": (_I, [_P, _L, _P, _I]),

@@ -95,10 +95,22 @@ class PredictBuilder(nn.Module):
 class DecodeHandle:
     """Completion handle of a pipelined forward (addition_outputs["decode"]): the forward's tokens / logits are views the
     engine's decode stream is still writing.  `wait()` orders the current stream (optionally the host) after exactly that
-    decode -- launching the group first if it is still collecting batches -- and `done()` polls without blocking."""
+    decode -- launching the group first if it is still collecting batches -- and `done()` polls without blocking.
+    `result()` waits and returns (prediction, logits) as the synchronous call would: with is_test they are cut at the
+    first step at which every row of THIS batch had emitted [s] (tfm.py:138-140)."""
 
-    def __init__(self, model, eng, ticket=None):
+    def __init__(self, model, eng, ticket=None, index=0, tensors=None):
         self._model, self._eng, self.ticket = model, eng, ticket
+        self._index, self._tensors = index, tensors  # position of this batch inside its decode group; full-size views
+
+    def steps(self):
+        self._launch()
+        return self._eng.decode_steps(self.ticket)[self._index]
+
+    def result(self):
+        n = self.steps()  # blocks the host until the decode is complete
+        p, l = self._tensors
+        return p[:, :n], l[:, :n]
 
     def _launch(self):
         if self.ticket is None:  # the group this forward belongs to has not been launched yet
@@ -166,7 +178,7 @@ class Model(nn.Module):
             return self.engine().decode_beam_batch(memory.contiguous(), beam)
         return self.engine().decode_attn_beam_batch(memory.contiguous(), beam)
 
-    def _group_decode(self, eng, memory, start):
+    def _group_decode(self, eng, memory, start, is_test=False):
         """pipelined + decode_group > 1: collect the encoder memories of consecutive calls, launch one decode per group.
         Every group writes into fresh tensors (no ring to overrun): the views handed out stay valid for as long as the
         caller keeps them, and become readable once the group's ticket is complete."""
@@ -174,13 +186,13 @@ class Model(nn.Module):
         G = int(self.decode_group)
         B, T, d = memory.shape
         S, V = eng.cfg.max_seq_len + 1, eng.cfg.vocab
-        key = (G, B, T, d, S, V, memory.device)
+        key = (G, B, T, d, S, V, memory.device, bool(is_test))
         g = self._grp
         if g is not None and g["key"] != key:
             self._flush_group(eng)
             g = None
         if g is None:
-            g = self._grp = {"key": key, "n": 0, "handle": DecodeHandle(self, eng),
+            g = self._grp = {"key": key, "n": 0, "handles": [],
                              "mem": torch.empty((G * B, T, d), dtype=torch.float32, device=memory.device),
                              "start": torch.empty((G * B,), dtype=torch.int64, device=memory.device),
                              "tokens": torch.empty((G * B, S), dtype=torch.int64, device=memory.device),
@@ -188,7 +200,10 @@ class Model(nn.Module):
         k = g["n"]
         g["mem"][k * B:(k + 1) * B].copy_(memory)
         g["start"][k * B:(k + 1) * B].copy_(start.to(device=memory.device, dtype=torch.int64))
-        out = g["tokens"][k * B:(k + 1) * B], g["logits"][k * B:(k + 1) * B], g["handle"]
+        views = g["tokens"][k * B:(k + 1) * B], g["logits"][k * B:(k + 1) * B]
+        handle = DecodeHandle(self, eng, None, k, views)
+        g["handles"].append(handle)
+        out = views + (handle,)
         g["n"] += 1
         if g["n"] == G:
             self._flush_group(eng)
@@ -199,8 +214,10 @@ class Model(nn.Module):
         if g is None or g["n"] == 0:
             return
         rows = g["n"] * g["key"][1]
-        g["handle"].ticket = eng.decode_greedy_async_into(g["mem"][:rows], g["start"][:rows], g["tokens"][:rows],
-                                                          g["logits"][:rows])
+        ticket = eng.decode_greedy_async_into(g["mem"][:rows], g["start"][:rows], g["tokens"][:rows], g["logits"][:rows],
+                                              is_test=g["key"][-1], rows_per_batch=g["key"][1])
+        for h in g["handles"]:
+            h.ticket = ticket
         self._grp = None
 
     def synchronize(self, host_sync=True, flush=True):
@@ -286,12 +303,15 @@ class Model(nn.Module):
         else:
             if text.dim() != 2 or text.shape[1] != 1:
                 raise ValueError("eval decoding expects text = [B,1] start tokens ([GO])")
-            if self.pipelined and not is_test and int(self.decode_group) > 1:
-                prediction, logits, handle = self._group_decode(eng, contextual_feature.contiguous(), text[:, 0])
+            # pipelined: the forward returns while the step loop runs on an engine stream.  With is_test the early exit is
+            # taken on the device; prediction / logits are then FULL-SIZE tensors whose valid length is only known once the
+            # decode is complete -- addition_outputs["decode"].result() waits and returns them cut as the reference does
+            if self.pipelined and int(self.decode_group) > 1:
+                prediction, logits, handle = self._group_decode(eng, contextual_feature.contiguous(), text[:, 0], is_test)
                 return prediction, logits, None, {"decode": handle}
-            elif self.pipelined and not is_test:
-                prediction, logits, ticket = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0])
-                return prediction, logits, None, {"decode": DecodeHandle(self, eng, ticket)}
+            elif self.pipelined:
+                prediction, logits, ticket = eng.decode_greedy_async(contextual_feature.contiguous(), text[:, 0], is_test)
+                return prediction, logits, None, {"decode": DecodeHandle(self, eng, ticket, 0, (prediction, logits))}
             else:
                 prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
         return prediction, logits, None, {}

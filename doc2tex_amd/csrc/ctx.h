@@ -136,6 +136,8 @@ struct d2t_ctx {
   static constexpr int TICKET_RING = 64;
   int64_t last_ticket = 0;
   hipEvent_t ticket_ev[TICKET_RING] = {};
+  int* h_steps = nullptr;               // pinned [TICKET_RING][64]: per-batch step counts of early-exit decodes
+  int ticket_batches[TICKET_RING] = {};  // batches of that decode's group (< 0: not an early-exit decode)
   float* skv = nullptr; size_t skv_cap = 0;
   float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
@@ -157,7 +159,7 @@ struct d2t_ctx {
   float* dout = nullptr; size_t dout_cap = 0;
   int active_chain = 0, n_chains = 1;
   hipEvent_t ev_in = nullptr;
-  struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; };
+  struct GraphKey { int B, T, steps; const void* tok; const void* logits; const void* ckv; const void* dws; const void* skv; const void* dstate; long long variant; };
   struct GraphEnt { GraphKey key; hipGraphExec_t exec; };
   std::vector<GraphEnt> graphs;  // small cache of captured decode steps (most recent last)
   // kernel timing log (d2t_profile_*)

@@ -53,6 +53,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // ---------------------------------------------------------------------------
 template <int NW, int NCH, int MT>  // K == NW * NCH * 16; block tile (16*MT) rows x 16 columns
 __global__ __launch_bounds__(NW * 64) void skinny_splitk_kernel(const SkinnyP p) {
+  if (p.stop_at && *p.stop_at && *p.cur_step >= *p.stop_at) return;  // block-uniform
   decode_wave_priority();
   TraceScope trace_(p.trace);
   constexpr int KS = NCH * 16;
@@ -386,10 +387,11 @@ hipError_t launch_embed(const float* emb, const float* pe, const int64_t* start,
 // end-of-sequence bookkeeping stays on the device.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void argmax_embed_kernel(const ArgmaxP p) {
+  const int t = *p.step_ptr;
+  if (p.stop_at && *p.stop_at && t >= *p.stop_at) return;  // block-uniform; set by an EARLIER launch only (t + 1 > t)
   decode_wave_priority();
   TraceScope trace_(p.trace);
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int t = *p.step_ptr;
   const float* row = p.logits + (size_t)b * p.row_stride + (size_t)t * p.step_stride;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -416,6 +418,14 @@ __global__ __launch_bounds__(64) void argmax_embed_kernel(const ArgmaxP p) {
       p.ended[b] = 1;
       const int c = atomicAdd(p.end_count, 1) + 1;
       if (c == p.B) *p.steps_done = t + 1;
+      if (p.n_batches > 0) {  // decode group: this row's encoder batch may have finished
+        const int k = b / p.rows_per_batch;
+        if (atomicAdd(p.batch_end_count + k, 1) + 1 == p.rows_per_batch) {
+          p.batch_steps_done[k] = t + 1;
+          // every block of THIS launch read step t before the stop takes effect (t < t + 1); the kernels of step t + 1 see it
+          if (atomicAdd(p.batches_done, 1) + 1 == p.n_batches && p.stop_at) *p.stop_at = t + 1;
+        }
+      }
     }
     // every block has read the step counter before it arrives here, so the
     // last arriver may advance it (the kernel boundary publishes the store)
@@ -515,6 +525,7 @@ template <int D, int HD, int NTH>  // NTH = 512: one wave per head; 256: four wa
 __global__ __launch_bounds__(NTH, NTH == 256 ? 4 : 2) void decoder_row_kernel(const DecRowP p) {
   constexpr int G = NTH / (D / 4);
   constexpr int HPW = 8 * 64 / NTH;  // heads per wave
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
   decode_wave_priority();
   TraceScope trace_(p.trace);
   __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D], part_s[G * D];

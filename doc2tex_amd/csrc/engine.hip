@@ -336,6 +336,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->zero_page) hipFree(c->zero_page);
   if (c->gc_ws) hipFree(c->gc_ws);
   if (c->ev_in) hipEventDestroy(c->ev_in);
+  if (c->h_steps) hipHostFree(c->h_steps);
   for (hipEvent_t ev : c->ticket_ev) if (ev) hipEventDestroy(ev);
   if (c->dstream) hipStreamDestroy(c->dstream);
   if (c->parked.skv) hipFree(c->parked.skv);
@@ -811,6 +812,10 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
 // decoder
 // ---------------------------------------------------------------------------
 namespace {
+// decode-group bookkeeping words behind the per-row `ended` flags of the device state array:
+// [0, MAXB) per-batch end counters, [MAXB, 2 MAXB) per-batch "steps done", [2 MAXB] batches done, [2 MAXB + 1] stop-at step
+constexpr int GRP_MAXB = 64, GRP_WORDS = 2 * GRP_MAXB + 2;
+
 struct DecBufs {
   float *x;    // normalised layer input (x0 embedding, or LN3 of the previous layer)
   float *y1, *x1, *y2, *x2, *y3;  // pre-LayerNorm sums y* and their normalised forms x*
@@ -838,7 +843,7 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   if ((rc = ensure(c, &c->skv, &c->skv_cap, (size_t)g.dec_layers * 2 * B * Lmax * d * 4))) return rc;
   const size_t per = (size_t)B * (8 * d + 3 * d + g.dec_ff);
   if ((rc = ensure(c, &c->dws, &c->dws_cap, per * 4))) return rc;
-  if ((rc = ensure(c, &c->dstate, &c->dstate_cap, (size_t)(4 + B) * 4))) return rc;
+  if ((rc = ensure(c, &c->dstate, &c->dstate_cap, (size_t)(4 + B + GRP_WORDS) * 4))) return rc;
   float* p = c->dws;
   float** six[] = {&bufs->x, &bufs->y1, &bufs->x1, &bufs->y2, &bufs->x2, &bufs->y3, &bufs->q2, &bufs->a};
   for (float** q : six) { *q = p; p += (size_t)B * d; }
@@ -849,15 +854,18 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
 
 struct Lin { const float* x; int ldx; const LinW* w; const float* res; float* y; int ldy; int act; };
 
+
 unsigned long long* trace_slot(d2t_ctx* c) {
   if (!c->dtrace || c->dtrace_next >= d2t_ctx::DTRACE_SLOTS) return nullptr;
   return c->dtrace + 2 * (size_t)(c->dtrace_next++);
 }
 
 hipError_t skinny(hipStream_t s, const Lin& l, int M, const LNW* ln = nullptr, float* ln_out = nullptr,
-                  const int* step_ptr = nullptr, long long step_stride = 0, unsigned long long* trace = nullptr) {
+                  const int* step_ptr = nullptr, long long step_stride = 0, unsigned long long* trace = nullptr,
+                  const int* stop_at = nullptr, const int* cur_step = nullptr) {
   SkinnyP p{};
   p.trace = trace;
+  p.stop_at = stop_at; p.cur_step = cur_step;
   p.x = l.x; p.w = l.w->w; p.bias = l.w->b; p.res = l.res; p.y = l.y;
   p.M = M; p.K = l.w->K; p.N = l.w->N; p.ldx = l.ldx; p.ldy = l.ldy; p.ldres = l.w->N; p.act = l.act;
   p.step_ptr = step_ptr; p.out_step_stride = step_stride;
@@ -889,7 +897,7 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 // shared_mem: cross K/V of sample 0 shared by every row (beam search over one sample).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
                        float* logits, long long logit_row_stride, long long logit_step_stride, int ckvB = -1,
-                       const int* row_map = nullptr) {
+                       const int* row_map = nullptr, const int* stop = nullptr) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
@@ -901,9 +909,9 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
   for (int l = 0; l < g.dec_layers; ++l) {
     const DecLayer& L = c->dec[l];
     if (l == 0) {
-      TRY(skinny(s, Lin{bf.x, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c)));
+      TRY(skinny(s, Lin{bf.x, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c), stop, step));
     } else {
-      TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x, nullptr, 0, trace_slot(c)));
+      TRY(skinny(s, Lin{bf.y3, d, &L.sa_in, nullptr, bf.qkv, 3 * d, ACT_NONE}, M, &c->dec[l - 1].n3, bf.x, nullptr, 0, trace_slot(c), stop, step));
     }
     DecRowP r{};
     r.qkv = bf.qkv; r.qkv_stride = 3 * d; r.xres = bf.x;
@@ -917,12 +925,13 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.wq_t = L.ca_q_t; r.bq = L.ca_q.b; r.wco_t = L.ca_out_t; r.bco = L.ca_out.b;
     r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
     r.trace = trace_slot(c);
+    r.stop_at = stop;
     TRY(launch_decoder_row(r, s));
-    TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c)));
-    TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c)));
+    TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c), stop, step));
+    TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c), stop, step));
   }
   TRY(skinny(s, Lin{bf.y3, d, &c->out_proj, nullptr, logits, (int)logit_row_stride, ACT_NONE}, M,
-             &c->dec[g.dec_layers - 1].n3, nullptr, step, logit_step_stride, trace_slot(c)));
+             &c->dec[g.dec_layers - 1].n3, nullptr, step, logit_step_stride, trace_slot(c), stop, step));
 #undef TRY
   return hipSuccess;
 }
@@ -932,8 +941,11 @@ namespace {
 // Greedy decode.  The cross-attention K/V projection runs on the caller's stream into one of two slots;
 // the step loop runs on the internal stream, ordered after it.  async != 0: return right after
 // enqueueing (always max_seq_len+1 steps); the caller orders later work with d2t_decode_wait.
+// rows_per_batch > 0 (async only): the B rows are rows_per_batch-row encoder batches decoded by one loop (a decode group);
+// with is_test every batch gets its own "first step at which all ITS rows had ended", and the captured loop stops working
+// once every batch has one (device-side early exit: the remaining kernels of the graph return at their first instruction).
 int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* start_tokens, int is_test,
-                int64_t* tokens, float* logits, int* steps_out, hipStream_t user, bool async) {
+                int64_t* tokens, float* logits, int* steps_out, hipStream_t user, bool async, int rows_per_batch = 0) {
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab;
   const int slot = (int)(c->decode_seq++ & 1u);
@@ -961,7 +973,13 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   // order the internal stream after the caller's work (K/V slot, start tokens)
   HIPCHK(c, hipEventRecord(c->ev_in, user));
   HIPCHK(c, hipStreamWaitEvent(s, c->ev_in, 0));
-  HIPCHK(c, hipMemsetAsync(c->dstate, 0, (size_t)(4 + B) * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->dstate, 0, (size_t)(4 + B + GRP_WORDS) * 4, s));
+  const bool dev_exit = async && is_test;  // early exit decided on the device inside the whole-loop graph
+  if (rows_per_batch <= 0 || B % rows_per_batch) rows_per_batch = B;
+  const int n_batches = B / rows_per_batch;
+  if (n_batches > GRP_MAXB) return fail(c, D2T_EINVAL, "a decode group holds at most %d batches", GRP_MAXB);
+  int* grp = c->dstate + 4 + B;
+  const int* stop = dev_exit ? grp + 2 * GRP_MAXB + 1 : nullptr;
   // step 0 input: Embedding([GO]) * sqrt(d) + pe[0]; later inputs are written by argmax_embed
   HIPCHK(c, launch_embed(c->word_embed, c->word_pe, start_tokens, tokens, S, c->dstate, bf.x, B, g.dec_dim, s));
 
@@ -972,8 +990,11 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   am.B = B; am.V = V; am.end_token = TOK_END;
   am.emb = c->word_embed; am.pe = c->word_pe; am.x = bf.x; am.d = g.dec_dim;
   am.done_count = c->dstate + 3;
+  am.rows_per_batch = rows_per_batch; am.n_batches = n_batches;
+  am.batch_end_count = grp; am.batch_steps_done = grp + GRP_MAXB; am.batches_done = grp + 2 * GRP_MAXB;
+  am.stop_at = dev_exit ? grp + 2 * GRP_MAXB + 1 : nullptr;
   auto one_step = [&](hipStream_t st) -> hipError_t {
-    hipError_t e = decode_step(c, st, bf, B, T, B, false, logits, (long long)S * V, V);
+    hipError_t e = decode_step(c, st, bf, B, T, B, false, logits, (long long)S * V, V, -1, nullptr, stop);
     if (e != hipSuccess) return e;
     am.trace = trace_slot(c);
     return launch_argmax_embed(am, st);
@@ -982,10 +1003,14 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   // With early exit the host polls between steps, so one captured graph = one step, replayed.  Without it
   // (async, or is_test == 0) the whole max_seq_len+1 step loop is ONE graph: a single launch per batch keeps
   // the host free to enqueue the next batch's encoder while this one decodes.
-  const int steps_per_graph = (!is_test) ? S : 1;
+  const int steps_per_graph = (!is_test || dev_exit) ? S : 1;
   hipGraphExec_t exec = nullptr;
   if (use_graph) {
-    d2t_ctx::GraphKey k{B, T, steps_per_graph, tokens, logits, c->ckv, c->dws, c->skv, c->dstate};
+    d2t_ctx::GraphKey k;
+    memset(&k, 0, sizeof k);  // compared with memcmp: the padding must be defined
+    k.B = B; k.T = T; k.steps = steps_per_graph; k.tok = tokens; k.logits = logits; k.ckv = c->ckv; k.dws = c->dws;
+    k.skv = c->skv; k.dstate = c->dstate;
+    k.variant = (dev_exit ? 1 : 0) | ((long long)rows_per_batch << 1);
     for (size_t i = 0; i < c->graphs.size(); ++i)
       if (memcmp(&k, &c->graphs[i].key, sizeof k) == 0) {
         exec = c->graphs[i].exec;
@@ -1042,6 +1067,12 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   c->ev_done_valid[slot] = true;
   if (async) {  // serving ticket: this decode's outputs are complete once its event has fired
     const int64_t t = ++c->last_ticket;
+    {  // per-batch step counts of this decode, readable through d2t_decode_steps once the ticket is complete
+      if (!c->h_steps) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_steps), (size_t)d2t_ctx::TICKET_RING * GRP_MAXB * 4, hipHostMallocDefault));
+      int* slot_steps = c->h_steps + (size_t)(t % d2t_ctx::TICKET_RING) * GRP_MAXB;
+      c->ticket_batches[t % d2t_ctx::TICKET_RING] = dev_exit ? n_batches : -S;
+      if (dev_exit) HIPCHK(c, hipMemcpyAsync(slot_steps, grp + GRP_MAXB, (size_t)n_batches * 4, hipMemcpyDeviceToHost, s));
+    }
     hipEvent_t& ev = c->ticket_ev[t % d2t_ctx::TICKET_RING];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(ev, s));
@@ -1445,6 +1476,22 @@ int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t 
   return greedy_impl(c, memory, B, T, start_tokens, 0, tokens, logits, nullptr, (hipStream_t)stream, true);
 }
 
+int d2t_decode_greedy_submit(d2t_ctx* c, const float* memory, int32_t B, int32_t T, const int64_t* start_tokens,
+                             int32_t is_test, int32_t rows_per_batch, int64_t* tokens, float* logits, d2t_stream stream,
+                             int64_t* ticket_out) {
+  DevGuard dg_(c);
+  if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
+  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
+  if (rows_per_batch < 0 || (rows_per_batch > 0 && B % rows_per_batch)) return fail(c, D2T_EINVAL, "rows_per_batch must divide the row count");
+  if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
+  if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
+  const int rc = greedy_impl(c, memory, B, T, start_tokens, is_test, tokens, logits, nullptr, (hipStream_t)stream, true, rows_per_batch);
+  if (rc == D2T_OK && ticket_out) *ticket_out = c->last_ticket;
+  return rc;
+}
+
 int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
   DevGuard dg_(c);
   if (!c) return D2T_EINVAL;
@@ -1485,6 +1532,32 @@ int d2t_decode_query(d2t_ctx* c, int64_t ticket) {
   if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
   fail(c, D2T_EHIP, "hipEventQuery: %s", hipGetErrorString(e));
   return -D2T_EHIP;
+}
+
+// Decode steps of the batches of one asynchronous decode (blocks until that decode is complete): for an is_test decode the
+// first step at which all rows of batch k had emitted [s] (max_seq_len + 1 if that never happened); otherwise max_seq_len + 1.
+// n_out receives the number of batches in the decode's group.
+int d2t_decode_steps(d2t_ctx* c, int64_t ticket, int32_t* steps_out, int32_t max_batches, int32_t* n_out) {
+  DevGuard dg_(c);
+  if (!c || !steps_out || ticket < 1 || ticket > c->last_ticket) return fail(c, D2T_EINVAL, "unknown decode ticket %lld", (long long)ticket);
+  if (ticket + d2t_ctx::TICKET_RING <= c->last_ticket) return fail(c, D2T_ESTATE, "decode ticket %lld is too old", (long long)ticket);
+  const int slot = (int)(ticket % d2t_ctx::TICKET_RING);
+  HIPCHK(c, hipEventSynchronize(c->ticket_ev[slot]));
+  const int nb = c->ticket_batches[slot];
+  const int S = c->cfg.max_seq_len + 1;
+  if (nb < 0) {  // not an early-exit decode: one entry, all steps
+    if (max_batches < 1) return fail(c, D2T_EINVAL, "steps_out too small");
+    steps_out[0] = S;
+    if (n_out) *n_out = 1;
+    return D2T_OK;
+  }
+  if (nb > max_batches) return fail(c, D2T_EINVAL, "steps_out holds %d entries, the decode has %d batches", max_batches, nb);
+  for (int k = 0; k < nb; ++k) {
+    const int v = c->h_steps[(size_t)slot * GRP_MAXB + k];
+    steps_out[k] = v > 0 ? v : S;
+  }
+  if (n_out) *n_out = nb;
+  return D2T_OK;
 }
 
 int d2t_decode_wait_ticket(d2t_ctx* c, int64_t ticket, d2t_stream stream, int32_t host_sync) {

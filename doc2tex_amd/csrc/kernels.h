@@ -60,6 +60,8 @@ struct SkinnyP {
   int ldx, ldy, ldres;  // row strides (floats)
   int wld;              // row stride of w (floats); 0 = K
   unsigned long long* trace;  // debug (D2T_DECODE_TRACE): [2] = min block start / max block end, s_memrealtime ticks
+  // early exit of a captured whole-loop graph: the kernel returns at once when *stop_at != 0 and *cur_step >= *stop_at
+  const int* stop_at; const int* cur_step;
   int act;
   const int* step_ptr;
   long long out_step_stride;
@@ -193,6 +195,7 @@ struct DecRowP {
   const int* step_ptr;
   int M, D, heads;
   unsigned long long* trace;          // debug (D2T_DECODE_TRACE), as SkinnyP::trace
+  const int* stop_at;                 // early exit, as SkinnyP::stop_at (the step counter is step_ptr)
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
@@ -213,6 +216,11 @@ struct ArgmaxP {
   // next-step embedding written by the same kernel: x[b] = emb[token]*sqrt(d) + pe[t+1]
   const float* emb; const float* pe; float* x; int d;
   unsigned long long* trace;  // debug (D2T_DECODE_TRACE), as SkinnyP::trace
+  // per-batch bookkeeping of a decode group (rows of several encoder batches in one loop): batch k = rows [k*rows_per_batch,
+  // (k+1)*rows_per_batch); batch_end_count[k] / batch_steps_done[k] as end_count / steps_done; when every batch is done and
+  // stop_at != nullptr, *stop_at = t + 1 makes the remaining kernels of a captured loop return immediately
+  int rows_per_batch, n_batches;
+  int* batch_end_count; int* batch_steps_done; int* batches_done; int* stop_at;
 };
 hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s);
 

@@ -297,8 +297,8 @@ class Engine:
                                                     _lib.stream_of(memory)), "decode_attn_greedy")
         return tokens, probs
 
-    def decode_greedy_async(self, memory, start_tokens):
-        """Pipelined greedy decode (always max_seq_len+1 steps): returns (tokens, logits, ticket).  The tensors are fresh
+    def decode_greedy_async(self, memory, start_tokens, is_test=False):
+        """Pipelined greedy decode (max_seq_len+1 steps; with is_test the device stops early): returns (tokens, logits, ticket).  The tensors are fresh
         allocations written by the engine's decode stream; they are valid once `ticket` is complete (wait_ticket /
         decode_wait) and are never recycled behind the caller's back -- the engine keeps them alive until then."""
         self._on_device(memory, "memory")
@@ -308,18 +308,20 @@ class Engine:
         start = start_tokens.to(device=memory.device, dtype=torch.int64).contiguous()
         tokens = torch.empty((B, S), dtype=torch.int64, device=memory.device)
         logits = torch.empty((B, S, V), dtype=torch.float32, device=memory.device)
-        ticket = self.decode_greedy_async_into(memory, start, tokens, logits)
+        ticket = self.decode_greedy_async_into(memory, start, tokens, logits, is_test=is_test)
         return tokens, logits, ticket
 
-    def decode_greedy_async_into(self, memory, start, tokens, logits):
-        """d2t_decode_greedy_async on caller-held buffers; returns the decode's ticket.  The buffers are referenced here
-        until the ticket completes, so dropping them early cannot hand their memory to another allocation mid-write."""
+    def decode_greedy_async_into(self, memory, start, tokens, logits, is_test=False, rows_per_batch=0):
+        """d2t_decode_greedy_submit on caller-held buffers; returns the decode's ticket.  The buffers are referenced here
+        until the ticket completes, so dropping them early cannot hand their memory to another allocation mid-write.
+        rows_per_batch: the rows are several encoder batches of that size (a decode group)."""
         B, T, _ = memory.shape
-        self._check(self.lib.d2t_decode_greedy_async(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start),
-                                                     _lib.ptr(tokens), _lib.ptr(logits), _lib.stream_of(memory)),
-                    "decode_greedy_async")
+        t = C.c_int64(0)
+        self._check(self.lib.d2t_decode_greedy_submit(self.ctx, _lib.ptr(memory), B, T, _lib.ptr(start), int(bool(is_test)),
+                                                      int(rows_per_batch), _lib.ptr(tokens), _lib.ptr(logits),
+                                                      _lib.stream_of(memory), C.byref(t)), "decode_greedy_submit")
         self._wait_dev = memory.device
-        ticket = int(self.lib.d2t_decode_last_ticket(self.ctx))
+        ticket = int(t.value)
         held = getattr(self, "_held", None)
         if held is None:
             held = self._held = []
@@ -329,6 +331,13 @@ class Engine:
         if len(held) > 48:  # the C side keeps 64 ticket events: never let a live ticket fall out of its ring
             self.wait_ticket(held[0][0], host_sync=True)
         return ticket
+
+    def decode_steps(self, ticket):
+        """Per-batch step counts of an asynchronous decode (waits for it): [steps of batch 0, batch 1, ...]."""
+        out = (C.c_int32 * 64)()
+        n = C.c_int32(0)
+        self._check(self.lib.d2t_decode_steps(self.ctx, int(ticket), out, 64, C.byref(n)), "decode_steps")
+        return [int(out[i]) for i in range(n.value)]
 
     def ticket_done(self, ticket):
         r = int(self.lib.d2t_decode_query(self.ctx, int(ticket)))

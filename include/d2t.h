@@ -181,6 +181,19 @@ int d2t_decode_wait(d2t_ctx* ctx, d2t_stream stream, int32_t host_sync);
  * host_sync != 0) after THAT decode only -- a consumer of batch i need not wait for batches i+1, i+2 that are already
  * in flight; d2t_decode_query polls: 1 complete, 0 still running, < 0 error (-D2T_E*).  The output buffers of a decode
  * belong to the engine until its ticket is complete: a caller that recycles buffers checks the ticket first. */
+/* The general asynchronous entry point: as d2t_decode_greedy_async, plus
+ *   is_test != 0       the reference's early exit (tfm.py:138-140) decided ON THE DEVICE: the whole step loop is still one
+ *                      graph launch, but once every batch of the group has emitted [s] in all its rows the remaining
+ *                      kernels return at their first instruction; d2t_decode_steps then reports, per batch, the first step
+ *                      at which all ITS rows had ended (entries of tokens / logits beyond it are unspecified);
+ *   rows_per_batch     > 0: the B rows are B / rows_per_batch encoder batches of that many rows (a decode group, at most
+ *                      64 batches); 0: one batch.
+ * *ticket_out (optional) receives the decode's ticket. */
+int d2t_decode_greedy_submit(d2t_ctx* ctx, const float* memory_dev, int32_t B, int32_t T, const int64_t* start_tokens_dev,
+                             int32_t is_test, int32_t rows_per_batch, int64_t* tokens_dev, float* logits_dev,
+                             d2t_stream stream, int64_t* ticket_out);
+/* Step counts of the batches of one asynchronous decode (blocks until it is complete). */
+int d2t_decode_steps(d2t_ctx* ctx, int64_t ticket, int32_t* steps_out, int32_t max_batches, int32_t* n_out);
 int64_t d2t_decode_last_ticket(const d2t_ctx* ctx);
 int d2t_decode_query(d2t_ctx* ctx, int64_t ticket);
 int d2t_decode_wait_ticket(d2t_ctx* ctx, int64_t ticket, d2t_stream stream, int32_t host_sync);

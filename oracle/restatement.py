@@ -470,20 +470,20 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
         h = F.linear(init, sd[p + "proj_init_h.weight"], sd[p + "proj_init_h.bias"])
         c = F.linear(init, sd[p + "proj_init_c.weight"], sd[p + "proj_init_c.bias"])
     else:
-        h, c = torch.zeros(B, Hd), torch.zeros(B, Hd)
+        h, c = torch.zeros(B, Hd, dtype=keys.dtype), torch.zeros(B, Hd, dtype=keys.dtype)
     V = sd[a + "generator.weight"].shape[0]
     T = keys.shape[1]
-    probs = torch.zeros(B, num_steps, V)
+    probs = torch.zeros(B, num_steps, V, dtype=keys.dtype)
     targets = torch.zeros(B, dtype=torch.long)  # [GO]
     mem = None  # attention memory: None on the first step (-> zeros, attention1D.py:147-148)
-    alpha_cum = torch.zeros(B, T, 1)
+    alpha_cum = torch.zeros(B, T, 1, dtype=keys.dtype)
     end = torch.zeros(B, dtype=torch.bool)
     kp = F.linear(keys, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
     pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
     for i in range(num_steps):
         emb = F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)  # seq2seq.py:33-35
         hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
-        last = torch.zeros(B, T, 1) if mem is None else mem
+        last = torch.zeros(B, T, 1, dtype=keys.dtype) if mem is None else mem
         loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
         loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
         e = F.linear(torch.tanh(kp + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])

@@ -388,6 +388,40 @@ def test_pipelined_results_carry_a_completion_handle(cases):
     m.pipelined, m.decode_group = False, 1
 
 
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_pipelined_early_exit_decided_on_the_device(cases, group):
+    """What api/infer.py calls -- model(image, text, is_test=True) (early exit, tfm.py:138-140) -- in pipelined serving
+    mode: the loop is one graph launch whose kernels stop working once every batch of the decode group has ended; each
+    batch comes back cut at ITS OWN first all-ended step, exactly as its synchronous is_test call returns it.  Batches end
+    at different steps (and one never does), so groups mix them."""
+    c = _case(cases, "greedy", "t2_greedy_early")  # end_bias 1.81: rows end at different steps
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    imgs = [synth.synth_images(3, c["H"], c["W"], seed=c["iseed"] + i).cuda() for i in range(6)]
+    imgs.append((synth.synth_images(3, c["H"], c["W"], seed=77) * 0.05).cuda())  # a faint crop: different dynamics
+    text = torch.full((3, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        ref = [tuple(t.clone() for t in m(x, text, is_train=False, is_test=True)[:2]) for x in imgs]
+        steps = [p.shape[1] for p, _ in ref]
+        assert len(set(steps)) > 1, steps  # the batches really stop at different steps
+        m.pipelined, m.decode_chains, m.decode_group = True, 2, group
+        outs = [m(x, text, is_train=False, is_test=True) for x in imgs]
+        full = c["max_seq_len"] + 1
+        for (p, l, extra), (rp, rl) in zip(outs, ref):
+            assert p.shape == (3, full) and l.shape[:2] == (3, full)  # full-size buffers while the decode is in flight
+            cp, cl = extra["decode"].result()
+            assert cp.shape == rp.shape, (cp.shape, rp.shape)
+            assert torch.equal(cp, rp) and torch.equal(cl, rl)
+        m.synchronize()
+        # a mixed stream: is_test and plain forwards interleaved keep their own groups
+        a = m(imgs[0], text, is_train=False, is_test=True)
+        b = m(imgs[1], text, is_train=False, is_test=False)
+        pa, la = a[2]["decode"].result()
+        pb, lb = b[2]["decode"].result()
+        assert torch.equal(pa, ref[0][0]) and pb.shape[1] == full
+        assert torch.equal(pb[:, :steps[1]], ref[1][0])
+    m.pipelined, m.decode_group = False, 1
+
+
 @pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop", "c2_greedy", "c1_greedy", "s0_greedy"])
 def test_fp32_convolutions_keep_parity(cases, name):
     """The exact-fp32 arithmetic mode (conv_precision = 'fp32'; the default is the split-bf16 path every other test
