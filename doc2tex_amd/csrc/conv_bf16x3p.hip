@@ -100,11 +100,17 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
 // The vector-memory side of a tile for ONE issuing wave: which 16-row pieces of the A / B planes it copies, their per-lane
 // source addresses (XOR-swizzled k-chunk applied on the SOURCE: the LDS destination of a wave's LDS-DMA is linear) and the
 // per-row validity mask over the filter taps (out-of-image taps and rows beyond M / Cout read a zero page).
+// A operand: one LDS row per tile row holding the whole 128-byte record [hi 64 | lo 64]; a 1 KiB piece = 8 rows x 128 B, i.e.
+// a wave's LDS-DMA touches 8 full cache lines instead of 16 half lines (the vector-memory path's cost is per line touched:
+// 32-byte segments measured half the rate of 64-byte ones).  The eight 16-byte chunks of a row are XOR-ed with (row >> 1) & 7
+// -- on the source side of the DMA and on the ds_read side -- so that the 16-lane groups of a ds_read_b128 hit every bank once.
+__device__ __forceinline__ int aswz(int row, int c) { return c ^ ((row >> 1) & 7); }
+
 template <int BM, int BN, int LW, int ABL>
 struct DmaIssuer {
-  static constexpr int AJ = BM / (16 * LW), BJ = BN / (16 * LW);
+  static constexpr int AJ = BM / (8 * LW), BJ = BN / (16 * LW);
   static constexpr int PLANE_A = BM * PROW, PLANE_B = BN * PROW, STAGE = 2 * PLANE_A + 2 * PLANE_B;
-  static constexpr int PER_STEP = 2 * AJ + 2 * BJ;  // LDS-DMA instructions per K-step
+  static constexpr int PER_STEP = AJ + 2 * BJ;  // LDS-DMA instructions per K-step
   static_assert(AJ >= 1 && BJ >= 1, "tile too small for the issuing waves");
   static_assert(PER_STEP <= 31, "two K-steps of pieces must fit the 6-bit vmcnt");
   int a_off[AJ];
@@ -120,8 +126,8 @@ struct DmaIssuer {
     const int ohow = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int row = (lw * AJ + j) * 16 + lr;
-      const int c = pswz(row, pos);  // the chunk that belongs at LDS position `pos` of this row
+      const int row = (lw * AJ + j) * 8 + (lane >> 3);
+      const int c = aswz(row, lane & 7);  // the chunk of the record that belongs at LDS position lane & 7 of this row
       const int m = m0 + row;
       a_off[j] = 0;
       a_mask[j] = 0;
@@ -148,8 +154,7 @@ struct DmaIssuer {
   // K-steps must be issued in order (the tap / channel-chunk cursor advances)
   __device__ __forceinline__ void issue(const ConvP& p, unsigned char* smem, int kt, int buf) {
     unsigned char* ah = smem + buf * STAGE;
-    unsigned char* al = ah + PLANE_A;
-    unsigned char* bh = al + PLANE_A;
+    unsigned char* bh = ah + 2 * PLANE_A;
     unsigned char* bl = bh + PLANE_B;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
     const int tap = kh * p.KW + kw;
@@ -161,7 +166,6 @@ struct DmaIssuer {
       const int piece = (lw * AJ + j) * 1024;
       if (ABL == 1) continue;
       __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ah + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(ok ? src + 32 : zero, (lds_ptr_t)(al + piece), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -245,15 +249,17 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ds_read byte offsets of this lane's fragments inside a plane, for the two 16-deep halves of a K-step
-    int offa[2][MI], offb[2][NJ];
+    // ds_read byte offsets of this lane's fragments, for the two 16-deep halves of a K-step: A rows are 128-byte records
+    // (hi chunks 0..3, lo chunks 4..7, swizzled by aswz), B rows 64 bytes per plane (pswz)
+    int offa[2][MI], offal[2][MI], offb[2][NJ];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int c = 2 * kk + h;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int row = wm * WTM + i * 32 + r;
-        offa[kk][i] = row * PROW + pswz(row, c) * 16;
+        offa[kk][i] = row * 128 + aswz(row, c) * 16;
+        offal[kk][i] = row * 128 + aswz(row, 4 + c) * 16;
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -270,8 +276,7 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
       if (NL == 0 && kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
       __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the ds_reads / MFMAs
       const unsigned char* ah = smem + cur * STAGE;
-      const unsigned char* al = ah + PLANE_A;
-      const unsigned char* bh = al + PLANE_A;
+      const unsigned char* bh = ah + 2 * PLANE_A;
       const unsigned char* bl = bh + PLANE_B;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -280,7 +285,7 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[kk][i]);
-          fal[i] = *reinterpret_cast<const bf16x8*>(al + offa[kk][i]);
+          fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[kk][i]);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
