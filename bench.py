@@ -151,7 +151,8 @@ def train_bench(args, rank, world, dev, dist):
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     img = synth.synth_images(B, H, W, seed=3000 + rank).to(dev)
     text = synth.synth_labels(B, max_len=L, seed=3000 + rank).to(dev)
-    crit = torch.nn.CrossEntropyLoss(ignore_index=0, reduction="none")
+    from doc2tex_amd.loss import create_criterion
+    crit = create_criterion("entropy", {"ignore_index": 0, "reduction": "none"})  # fused log-softmax + NLL (d2t_ce_*)
 
     def step():
         _, preds, _ = model(img, text[:, :-1])
@@ -165,6 +166,8 @@ def train_bench(args, rank, world, dev, dist):
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize(dev)
+    eng = model.engine(finalize=False)
+    eng.profile(True)  # HIP events around every forward / data-gradient GEMM launch of the timed steps
     if dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -175,11 +178,34 @@ def train_bench(args, rank, world, dev, dist):
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    recs = [r for r in eng.profile_read(16384) if r[3] > 0 and r[0] > 0]
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
+        # roofline of the step's dominant GEMM shape (forward convolutions and their data gradients share shapes and kernel):
+        # algorithmic 2*M*N*K per launch / average launch time, against the dense peak of the MFMA type in use
+        by_shape = {}
+        for M_, N_, K_, ms in recs:
+            by_shape.setdefault((M_, N_, K_), []).append(ms)
+        roofline = None
+        if by_shape:
+            dom = max(by_shape, key=lambda q: sum(by_shape[q]))
+            dom_ms = sum(by_shape[dom]) / len(by_shape[dom])
+            flop = 2.0 * dom[0] * dom[1] * dom[2]
+            bf = args.precision == "bf16x3"
+            peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+            ach = flop / (dom_ms * 1e-3) / 1e12
+            total_ms = sum(sum(v) for v in by_shape.values())
+            roofline = {"bound": "mfma", "kernel": "forward / data-gradient convolution GEMM (split-bf16 on-the-fly kernel)" if bf
+                        else "forward / data-gradient convolution GEMM (fp32 MFMA)",
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "gemm_MNK": list(dom), "avg_launch_ms": round(dom_ms, 4), "launches_timed": len(by_shape[dom]),
+                        "gemm_ms_per_step": round(total_ms / args.steps, 2),
+                        "note": "GEMM launches timed with HIP events (weight-gradient kernels, BatchNorm / attention / element-wise "
+                                "kernels, CE, clip and AdamW make up the rest of the step)"}
         print(json.dumps({
             "metric": "formulas/s (training step, 128x512 crops, CE loss)", "value": round(B * world * args.steps / elapsed, 2),
             "unit": "formulas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,6 +215,7 @@ def train_bench(args, rank, world, dev, dist):
                                    "forward + CE + backward + clip + AdamW",
                        "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world} (per-rank batches, gradient all-reduce-mean in 64 MB buckets over RCCL)"},
+            "roofline": roofline, "criterion": "fused CE (d2t_ce_forward / d2t_ce_backward)",
             "loss": round(float(loss), 4)}), flush=True)
     if dist:
         dist.destroy_process_group()

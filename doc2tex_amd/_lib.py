@@ -96,6 +96,8 @@ SIGNATURES = {
     "d2t_op_layernorm": (_I, [_P] * 4 + [_I, _I, C.c_float, _P]),
     "d2t_op_vit_attention": (_I, [_P, _P, _I, _I, _I, _P]),
     "d2t_op_decode_attention": (_I, [_P] * 4 + [_I] * 5 + [_P]),
+    "d2t_ce_forward": (_I, [_P, _P, _P, _P, _I, _I, _L, _P]),
+    "d2t_ce_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _P]),
     "d2t_op_train_conv": (_I, [_P] * 14 + [_I] * 13 + [_P]),
     "d2t_op_train_linear": (_I, [_P] * 10 + [_I] * 5 + [_P]),
     "d2t_op_train_layernorm": (_I, [_P] * 8 + [_I, _I, C.c_float, _P]),

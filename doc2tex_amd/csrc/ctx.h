@@ -248,3 +248,5 @@ int need(d2t_ctx* c, const std::string& k, const RawW** out, std::vector<int64_t
 
 // engine.hip: PositionalEncoding2D crop [h][w][C] (cached per (h, w) in the context)
 int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out);
+// engine.hip: launch_conv bracketed by HIP events while d2t_profile_enable is on (training GEMMs report through it too)
+hipError_t d2t_internal_conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s);

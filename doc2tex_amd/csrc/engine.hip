@@ -246,6 +246,7 @@ int get_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) 
 }  // namespace
 
 int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) { return get_pe2d(c, h, w, C, s, out); }
+hipError_t d2t_internal_conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) { return conv_timed(c, p, s); }
 
 // ===========================================================================
 // C-ABI

@@ -324,6 +324,10 @@ hipError_t launch_dropout_mask(uint8_t* mask, size_t n, float p, unsigned long l
                                hipStream_t s);
 // out = a * mask * scale
 hipError_t launch_apply_mask(const float* a, const uint8_t* mask, float scale, float* out, size_t n, hipStream_t s);
+hipError_t launch_ce_fwd(const float* x, const int64_t* tgt, float* loss, float* lse, int rows, int V, long long ignore,
+                         hipStream_t s);
+hipError_t launch_ce_bwd(const float* x, const int64_t* tgt, const float* lse, const float* dloss, float* dx, int rows, int V,
+                         long long ignore, hipStream_t s);
 hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s);
 hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
                               hipStream_t s);

@@ -173,7 +173,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.in = a; p.w = w; p.bias = bias; p.res = res; p.out = out;
     p.B = 1; p.H = 1; p.W = (int)M; p.Cin = K; p.OH = 1; p.OW = (int)M; p.Cout = N;
     p.KH = p.KW = p.SH = p.SW = 1; p.M = (int)M; p.K = K; p.act = act;
-    TCHK(launch_conv(p, s));
+    TCHK(d2t_internal_conv_timed(c, p, s));
     return D2T_OK;
   }
   // dst[c] (+)= column sums of a[R][C]
@@ -260,7 +260,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.in = x.p; p.w = wp; p.bias = bias; p.out = n.z;
     p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
-    TCHK(launch_conv(p, s));
+    TCHK(d2t_internal_conv_timed(c, p, s));
     if (bnkey.empty()) {
       RC(new_tensor(P, Cout, out, x.B, OH, OW, n.z));
     } else {
@@ -867,7 +867,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.B = x.B; p.H = DH; p.W = DW; p.Cin = Cout; p.OH = x.H; p.OW = x.W; p.Cout = Cin;
     p.KH = n.KH; p.KW = n.KW; p.SH = p.SW = 1; p.PH = n.KH - 1 - n.PH; p.PW = n.KW - 1 - n.PW;
     p.M = (int)x.rows; p.K = Kd; p.act = ACT_NONE;
-    TCHK(launch_conv(p, s));
+    TCHK(d2t_internal_conv_timed(c, p, s));
     return add_grad(n.in, dx);
   }
   int bwd_pool(const Node& n) {
@@ -1153,6 +1153,18 @@ struct OpCtx {
   }
 };
 }  // namespace
+
+// Fused cross-entropy, reduction 'none' (the criterion of engine/training.py:50-53): no context needed.
+int d2t_ce_forward(const float* logits, const int64_t* target, float* loss, float* lse, int32_t rows, int32_t V,
+                   int64_t ignore_index, d2t_stream stream) {
+  if (!logits || !target || !loss || !lse || rows < 0 || V < 1) return D2T_EINVAL;
+  return launch_ce_fwd(logits, target, loss, lse, rows, V, ignore_index, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+int d2t_ce_backward(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits,
+                    int32_t rows, int32_t V, int64_t ignore_index, d2t_stream stream) {
+  if (!logits || !target || !lse || !dloss || !dlogits || rows < 0 || V < 1) return D2T_EINVAL;
+  return launch_ce_bwd(logits, target, lse, dloss, dlogits, rows, V, ignore_index, (hipStream_t)stream) == hipSuccess ? D2T_OK : D2T_EHIP;
+}
 
 int d2t_op_train_conv(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                       const float* residual, const float* dy, float* y, float* dx, float* dw, float* dbias,

@@ -567,6 +567,58 @@ hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B,
 }
 
 // ---------------------------------------------------------------------------
+// Fused cross-entropy (nn.CrossEntropyLoss(ignore_index, reduction='none') of engine/training.py:50-53,83,90): one wave per
+// row of the [rows][V] logits.  Forward: lse = max + log(sum exp(x - max)); loss = lse - x[target] (0 where target ==
+// ignore_index); backward: dx[v] = (exp(x[v] - lse) - [v == target]) * dloss, 0 for ignored rows.  Replaces torch's
+// log_softmax + nll_loss pair (four passes over the logits) with one pass each way.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                                     float* __restrict__ loss, float* __restrict__ lse, int rows, int V,
+                                                     long long ignore) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * V;
+  float m = -INFINITY;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, xr[v]);
+  m = wmax(m);
+  float sum = 0.f;
+  for (int v = lane; v < V; v += 64) sum += expf(xr[v] - m);
+  sum = wsum(sum);
+  if (lane == 0) {
+    const float l = m + logf(sum);
+    const long long t = tgt[row];
+    lse[row] = l;
+    loss[row] = (t == ignore || t < 0 || t >= V) ? 0.f : l - xr[t];
+  }
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                                     const float* __restrict__ lse, const float* __restrict__ dloss,
+                                                     float* __restrict__ dx, int rows, int V, long long ignore) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * V;
+  float* dr = dx + (size_t)row * V;
+  const long long t = tgt[row];
+  const bool live = !(t == ignore || t < 0 || t >= V);
+  const float g = live ? dloss[row] : 0.f, l = lse[row];
+  for (int v = lane; v < V; v += 64) dr[v] = live ? (expf(xr[v] - l) - (v == t ? 1.f : 0.f)) * g : 0.f;
+}
+hipError_t launch_ce_fwd(const float* x, const int64_t* tgt, float* loss, float* lse, int rows, int V, long long ignore,
+                         hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, tgt, loss, lse, rows, V, ignore);
+  return hipGetLastError();
+}
+hipError_t launch_ce_bwd(const float* x, const int64_t* tgt, const float* lse, const float* dloss, float* dx, int rows, int V,
+                         long long ignore, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, tgt, lse, dloss, dx, rows, V, ignore);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // The discrete decisions of a training forward, for tests that replay them in the oracle (d2t_train_read_decision):
 // ReLU keep masks (y > 0) and, per max-pool output element, which window element (kh*2 + kw) the backward routes the
 // gradient to -- the same first-maximum scan as maxpool_bwd_kernel.

@@ -336,6 +336,17 @@ int d2t_op_vit_attention(const float* qkv, float* y, int32_t B, int32_t N, int32
 int d2t_op_decode_attention(const float* q, const float* k, const float* v, float* y, int32_t B, int32_t heads,
                             int32_t hd, int32_t L, int32_t Lmax, d2t_stream stream);
 
+/* ---- fused cross-entropy ------------------------------------------------------------------------------------------
+ * The criterion of the reference's training step -- nn.CrossEntropyLoss(ignore_index = PAD, reduction = 'none') on
+ * preds.view(-1, V) / target.view(-1) (engine/training.py:50-53, 83, 90; modules/loss/builder.py:18-24) -- as one kernel
+ * each way instead of torch's log_softmax + nll_loss pair.  logits [rows][V] fp32, target [rows] int64; loss [rows] and
+ * lse [rows] (log-sum-exp, kept for the backward) are written; rows whose target equals ignore_index give loss 0 and a
+ * zero gradient.  dloss [rows] is the incoming gradient of the per-row losses (1 / rows for the reference's .mean()). */
+int d2t_ce_forward(const float* logits, const int64_t* target, float* loss, float* lse, int32_t rows, int32_t V,
+                   int64_t ignore_index, d2t_stream stream);
+int d2t_ce_backward(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits,
+                    int32_t rows, int32_t V, int64_t ignore_index, d2t_stream stream);
+
 /* ---- op-level TRAINING test entry points ---------------------------------------------------------------------
  * One node of the training tape, forward + backward, on caller tensors (fp32, device, row-major [rows][cols]; maps
  * NHWC; convolution weights OIHW as in the state_dict).  They run the very builders / backward functions of

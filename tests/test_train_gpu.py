@@ -126,6 +126,32 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
     assert float((mem.cpu() - omem).abs().max()) / max(1.0, float(omem.abs().max())) <= 1e-4
 
 
+def test_fused_criterion_in_the_training_step(cases):
+    """engine/training.py:83-90,126 with the criterion built by doc2tex_amd.loss.create_criterion (fused log-softmax + NLL,
+    d2t_ce_forward / d2t_ce_backward) instead of torch's: same loss, same gradients in every parameter."""
+    from doc2tex_amd.loss import create_criterion
+    c = _case(cases, "train_step", "t2_train_step")
+    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"])
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    loss_ref, _ = _step(m, img, text)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.load_state_dict(state0)
+    m.train()
+    m.zero_grad()
+    crit = create_criterion("entropy", {"ignore_index": 0, "reduction": "none"})
+    _, preds, _ = m(img.cuda(), text[:, :-1].cuda())
+    cost = crit(preds.view(-1, preds.shape[-1]), text[:, 1:].cuda().contiguous().view(-1))
+    loss = cost.mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6 * max(1.0, abs(float(loss_ref)))
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert _rel(p.grad, ref[k]) <= 1e-5, k
+
+
 def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
     """model.grad_sync (bucketed copies on a communication stream, each ordered after its producing kernels by a
     device event; world size 1 here, so no collective) returns bit-identical gradients."""

@@ -269,3 +269,37 @@ def test_maxpool_backward(B, H, W, C, stride, pad):
     torch.cuda.synchronize()
     assert torch.equal(_nchw(y), yr.detach().float())
     assert _rel(_nchw(dx), gx) <= 1e-6
+
+
+@pytest.mark.parametrize("rows,V", [(453, 500), (4832, 500), (37, 93), (64, 1000)])
+def test_fused_cross_entropy(rows, V):
+    """d2t_ce_forward / d2t_ce_backward (doc2tex_amd.loss.CrossEntropyLoss) against float64 torch: per-row losses with PAD
+    rows ignored, the reference's `cost.mean()` over ALL positions (engine/training.py:126), and 'mean' / 'sum' reductions."""
+    from doc2tex_amd.loss import CrossEntropyLoss, create_criterion
+    g = torch.Generator().manual_seed(rows + V)
+    logits = _rand(rows, V, seed=60, scale=3.0)
+    target = torch.randint(0, V, (rows,), generator=g)
+    target[::5] = 0  # PAD
+    for reduction in ("none", "mean", "sum"):
+        x = logits.clone().to(DEV).requires_grad_(True)
+        crit = create_criterion("entropy", {"ignore_index": 0, "reduction": reduction})
+        assert isinstance(crit, CrossEntropyLoss)
+        out = crit(x, target.to(DEV))
+        xd = logits.double().requires_grad_(True)
+        ref = F.cross_entropy(xd, target, ignore_index=0, reduction=reduction)
+        if reduction == "none":
+            assert out.shape == (rows,) and float(out[::5].abs().max()) == 0.0
+            assert _rel(out, ref.detach()) <= 1e-6
+            out.mean().backward()   # training.py:126: mean over all positions, ignored ones included
+            ref.mean().backward()
+        else:
+            assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+            out.backward()
+            ref.backward()
+        torch.cuda.synchronize()
+        assert _rel(x.grad, xd.grad) <= 1e-6
+        assert float(x.grad[::5].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        create_criterion("smooth", {"classes": V})
+    with pytest.raises(RuntimeError):
+        CrossEntropyLoss(ignore_index=0, reduction="none")(logits, target)  # CPU tensors: no fallback

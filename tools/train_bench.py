@@ -27,7 +27,8 @@ text = synth.synth_labels(B, max_len=L, seed=7)
 if cfg["Prediction"]["name"] != "TFM":  # Attn converter: [GO] = 0, [s] = 1 (attn_converter.py:8)
     t = text.clone(); t[text == 1] = 0; t[text == 2] = 1; text = t
 text = text.cuda()
-crit = torch.nn.CrossEntropyLoss(ignore_index=0, reduction="none")
+from doc2tex_amd.loss import create_criterion
+crit = create_criterion("entropy", {"ignore_index": 0, "reduction": "none"})  # fused log-softmax + NLL (d2t_ce_*)
 
 
 def step():
