@@ -149,7 +149,7 @@ def test_fused_criterion_in_the_training_step(cases):
     assert abs(float(loss) - float(loss_ref)) <= 1e-6 * max(1.0, abs(float(loss_ref)))
     for k, p in m.named_parameters():
         if p.grad is not None:
-            assert _rel(p.grad, ref[k]) <= 1e-5, k
+            assert _rel(p.grad, ref[k].cpu()) <= 1e-5, k
 
 
 def test_grad_sync_path_returns_the_same_gradients(cases, manifests):
