@@ -15,9 +15,27 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc --output-form
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o pmc --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_write.log 2>&1
 echo "write done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -d $out/pmc_mfma -o pmc --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d $out/pmc_mfma -o pmc --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_mfma.log 2>&1
 echo "mfma done"
 # keep only what the aggregator needs from the PMC passes (the raw CSVs are large)
 python3 $R/tools/pmc_aggregate.py $out > $out/pmc_dominant.json
 cat $out/pmc_dominant.json
+cat $out/pmc_stem.json 2>/dev/null || true
+# the per-kernel table of the trace (top rows) for profiles/
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = acc[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+tot = sum(v[1] for v in acc.values())
+with open(out + "/kernel_stats.csv", "w") as fh:
+    fh.write("kernel,calls,total_us,avg_us,percent\n")
+    for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        fh.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k.replace('"', "'"), n, t, t / n, 100 * t / tot))
+PY
+head -25 $out/kernel_stats.csv
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_mfma
