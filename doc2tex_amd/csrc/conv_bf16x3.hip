@@ -279,7 +279,7 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
 
   const int nt = (p.Cout + BN - 1) / BN;
-  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int ntiles = nt * ((p.M - p.m_base + BM - 1) / BM);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane >> 2, pos = lane & 3;
   // Persistent over tiles: the grid may be smaller than the tile count (p.max_blocks), which leaves
@@ -290,7 +290,7 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
   int logical = tile0 + blockIdx.x;
   if ((G & 7) == 0) logical = tile0 + (blockIdx.x & 7) * gx + (blockIdx.x >> 3);
   if (logical >= ntiles) break;  // block-uniform
-  const int m0 = (logical / nt) * BM;
+  const int m0 = p.m_base + (logical / nt) * BM;
   const int n0 = (logical % nt) * BN;
 
   int a_off[AJ];
@@ -437,9 +437,20 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3g_128x64(const ConvP p) {
   conv_bf16x3g_body<128, 64, 2>(p, smem);
 }
 
+// The 128-row LDS-DMA kernels over output rows [p.m_base, p.M) with a column tile of `bn` (64 | 128): the pipelined kernel
+// hands the rows of its last, partial round of tiles to this one (conv_bf16x3p.hip).
+hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s) {
+  if (p.M <= p.m_base) return hipSuccess;
+  if (!p.in_hi || !p.w_hi || !p.w_lo || !p.zero16 || p.m_base < 0 || (bn != 64 && bn != 128)) return hipErrorInvalidValue;
+  const int tiles = ((p.M - p.m_base + 127) / 128) * ((p.Cout + bn - 1) / bn);
+  if (bn == 64) hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(tiles), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(tiles), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
-  if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
+  if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin || p.m_base != 0) return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes
     if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -373,6 +373,11 @@ __global__ __launch_bounds__(768, 3) void conv_bf16x3p_probe_dma_only(const Conv
   conv_bf16x3p_body<256, 128, 4, 2, 4, 3>(p, smem);
 }
 
+static int abl_probe() {
+  static const int abl = getenv("D2T_CONV_ABL") ? atoi(getenv("D2T_CONV_ABL")) : 0;
+  return abl;
+}
+
 // grid of the pipelined kernel: one block per CU on (CUs - reserved) CUs, never more blocks than tiles
 hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   static int cus = 0;
@@ -386,11 +391,27 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   ConvP q = p;
   q.wave_prio = prio;
   const ConvP& p2 = q;
-  const int tiles = ((p.M + 255) / 256) * ((p.Cout + 127) / 128);
+  const int nt = (p.Cout + 127) / 128;
+  int tiles = ((p.M + 255) / 256) * nt;
   int grid = cus - (p.reserved_cus > 0 ? p.reserved_cus : 0);
   if (grid < 8) grid = 8;
+  // Whole rounds only.  The dominant layer has 2064 tiles: eight rounds on 256 CUs and then sixteen tiles that keep 16 CUs
+  // busy for a ninth of the kernel's duration while 240 idle.  When the last round is less than `tail_frac` full, the pipelined
+  // kernel stops after the whole rounds (cut back to whole rows of tiles) and the remaining rows go to the 128-row kernel,
+  // whose small tiles spread over the chip.  Same arithmetic per output element in both kernels (tests assert bit-identity),
+  // and the split depends on the layer shape and the batch only through which kernel computes a row -- never on the values.
+  static const float tail_frac = getenv("D2T_CONV_TAIL") ? (float)atof(getenv("D2T_CONV_TAIL")) : 0.5f;
+  static const int tail_bn = getenv("D2T_CONV_TAIL_BN") ? atoi(getenv("D2T_CONV_TAIL_BN")) : 64;
+  int tail_from = -1;
+  const int rounds = tiles / grid, rem = tiles - rounds * grid;
+  if (rounds >= 1 && rem > 0 && rem < tail_frac * grid && !abl_probe()) {
+    const int main_mt = rounds * grid / nt;  // whole rows of tiles that fit into the whole rounds
+    tail_from = main_mt * 256;
+    q.M = tail_from;
+    tiles = main_mt * nt;
+  }
   if (grid > tiles) grid = tiles;
-  static const int abl = getenv("D2T_CONV_ABL") ? atoi(getenv("D2T_CONV_ABL")) : 0;
+  const int abl = abl_probe();
   static const int loaders = getenv("D2T_CONV_LOADERS") ? atoi(getenv("D2T_CONV_LOADERS")) : 4;
   if (abl == 1) hipLaunchKernelGGL(conv_bf16x3p_probe_no_dma, dim3(grid), dim3(768), 0, s, p2);
   else if (abl == 2) hipLaunchKernelGGL(conv_bf16x3p_probe_no_mfma, dim3(grid), dim3(768), 0, s, p2);
@@ -399,7 +420,11 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   else if (loaders == 0) hipLaunchKernelGGL(conv_bf16x3p_256x128_w8, dim3(grid), dim3(512), 0, s, p2);
   else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_k4608, dim3(grid), dim3(768), 0, s, p2);
   else hipLaunchKernelGGL(conv_bf16x3p_256x128, dim3(grid), dim3(768), 0, s, p2);
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || tail_from < 0) return e;
+  ConvP t = p;
+  t.m_base = tail_from;
+  return launch_conv_bf16x3g_rows(t, tail_bn, s);
 }
 
 }  // namespace d2t

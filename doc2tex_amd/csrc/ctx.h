@@ -91,7 +91,7 @@ struct d2t_ctx {
   std::map<std::string, RawW> raw;
   std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
   bool finalized = false;
-  bool conv_bf16x3 = false;  // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
+  bool conv_bf16x3 = true;   // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
   int conv_pipelined = 1;    // d2t_set_conv_kernel: 1 = pipelined 256x128 split-bf16 kernel (one block per CU), 0 = 128x128 (two per CU)

@@ -37,6 +37,7 @@ struct ConvP {
   int B, H, W, Cin, OH, OW, Cout;
   int KH, KW, SH, SW, PH, PW;
   int M;    // B*OH*OW
+  int m_base;  // LDS-DMA split-bf16 kernel only: this launch covers output rows [m_base, M) (tiles count from m_base)
   int K;    // KH*KW*Cin
   int act;
   // output row remap: row(m) = (m / rows_per_img) * img_stride + row_off + m % rows_per_img
@@ -49,6 +50,7 @@ struct ConvP {
 hipError_t launch_conv(const ConvP& p, hipStream_t s);         // fp32 MFMA, or bf16x3 when p.w_hi != nullptr
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s);
 hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s);  // 256x128 tile, 3 LDS stages, one block per CU
+hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s);  // 128-row LDS-DMA kernel over rows [m_base, M)
 // hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 

@@ -239,7 +239,7 @@ class Engine:
         return memory, (gh, gw), (pw, ph)
 
     def set_conv_precision(self, mode):
-        """'fp32' (exact, default) or 'bf16x3' (split-bf16 matrix-core path for the convolutions)."""
+        """'fp32' (exact) or 'bf16x3' (the default: split-bf16 matrix-core path for the convolutions)."""
         code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3}[mode]
         self._check(self.lib.d2t_set_conv_precision(self.ctx, code), "set_conv_precision")
 
