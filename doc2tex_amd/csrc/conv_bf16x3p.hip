@@ -399,12 +399,15 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   // busy for a ninth of the kernel's duration while 240 idle.  When the last round is less than `tail_frac` full, the pipelined
   // kernel stops after the whole rounds (cut back to whole rows of tiles) and the remaining rows go to the 128-row kernel,
   // whose small tiles spread over the chip.  Same arithmetic per output element in both kernels (tests assert bit-identity),
-  // and the split depends on the layer shape and the batch only through which kernel computes a row -- never on the values.
+  // so which kernel computes a row never shows in the values.  Alone this is worth 2.4 % on the dominant layer (1.72 ->
+  // 1.68 ms: the ninth round runs at a higher clock and without contention, so it costs 145 us, the 128-row kernel 105 us).
+  // The caller switches it off (split_tail = 0) while decode loops of earlier batches are in flight: their kernels run in
+  // exactly that hole, and the end-to-end rate is the same either way.
   static const float tail_frac = getenv("D2T_CONV_TAIL") ? (float)atof(getenv("D2T_CONV_TAIL")) : 0.5f;
   static const int tail_bn = getenv("D2T_CONV_TAIL_BN") ? atoi(getenv("D2T_CONV_TAIL_BN")) : 64;
   int tail_from = -1;
   const int rounds = tiles / grid, rem = tiles - rounds * grid;
-  if (rounds >= 1 && rem > 0 && rem < tail_frac * grid && !abl_probe()) {
+  if (p.split_tail && rounds >= 1 && rem > 0 && rem < tail_frac * grid && !abl_probe()) {
     const int main_mt = rounds * grid / nt;  // whole rows of tiles that fit into the whole rounds
     tail_from = main_mt * 256;
     q.M = tail_from;

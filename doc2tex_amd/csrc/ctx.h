@@ -91,6 +91,7 @@ struct d2t_ctx {
   std::map<std::string, RawW> raw;
   std::vector<void*> owned;  // packed buffers (freed on destroy / re-finalize)
   bool finalized = false;
+  bool decode_in_flight = false;  // a submitted decode loop may still be running (cleared by a host-synchronising wait)
   bool conv_bf16x3 = true;   // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;

@@ -112,7 +112,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
-  p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus;
+  p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
   if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
   if (res) {
     if (res->split) { p.res_hi = res->planes(); } else { p.res = res->p; }
@@ -782,7 +782,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
-    p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus;
+    p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -1068,6 +1068,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   c->ev_done_valid[slot] = true;
   if (async) {  // serving ticket: this decode's outputs are complete once its event has fired
     const int64_t t = ++c->last_ticket;
+    c->decode_in_flight = true;
     {  // per-batch step counts of this decode, readable through d2t_decode_steps once the ticket is complete
       if (!c->h_steps) HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_steps), (size_t)d2t_ctx::TICKET_RING * GRP_MAXB * 4, hipHostMallocDefault));
       int* slot_steps = c->h_steps + (size_t)(t % d2t_ctx::TICKET_RING) * GRP_MAXB;
@@ -1501,6 +1502,7 @@ int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
   if (host_sync) {
     HIPCHK(c, hipStreamSynchronize(c->dstream));
     HIPCHK(c, hipStreamSynchronize(c->parked.stream));
+    c->decode_in_flight = false;
   }
   return D2T_OK;
 }
@@ -2000,7 +2002,7 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   ConvP p{};
   p.w = wp; p.w_hi = whi; p.w_lo = wlo; p.bias = bias;
   p.in_hi = xs; p.out_hi = ys; p.res_hi = rs; p.zero16 = zero;
-  p.pipelined = g_op_conv_kind; p.reserved_cus = g_op_reserved_cus;
+  p.pipelined = g_op_conv_kind; p.reserved_cus = g_op_reserved_cus; p.split_tail = 1;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;

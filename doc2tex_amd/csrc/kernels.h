@@ -30,6 +30,7 @@ struct ConvP {
   int reserved_cus;      // pipelined split-bf16 kernel (one block per CU): CUs left free for other streams' kernels
   int wave_prio;         // pipelined kernel: s_setprio of its waves (experiments; 0 = default)
   int pipelined;         // != 0: take the pipelined 256x128 kernel (conv_bf16x3p.hip) when the layer qualifies
+  int split_tail;        // pipelined kernel: hand the rows of a sparsely filled last round of tiles to the 128-row kernel
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation

@@ -240,3 +240,46 @@ def test_conv_bf16x3_large_tiles():
         torch.cuda.synchronize()
         ref = _ref_conv(x, w, b, None, (1, 1), (1, 1), 1)
         assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= 3e-4
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, k, stride, pad, residual
+    (1, 257, 256, 32, 128, (3, 3), (1, 1), (1, 1), True),    # 257 tiles: one whole round on 256 CUs + a one-tile last round
+    (2, 129, 256, 64, 256, (3, 3), (1, 1), (1, 1), False),   # 516 tiles: two rounds + four
+    (2, 16, 129, 512, 512, (3, 3), (1, 1), (1, 1), True),    # the dominant layer's geometry at B = 2
+    (3, 7, 37, 128, 384, (3, 3), (1, 1), (1, 1), True),      # ragged rows and a partial last row tile
+    (1, 16, 129, 256, 512, (2, 2), (2, 1), (0, 1), False),   # conv4_1's strided, asymmetrically padded window
+    (1, 5, 9, 64, 128, (2, 2), (2, 2), (0, 0), False),       # 8 output rows
+])
+def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
+    """The pipelined 256x128 kernel (default) and the 128x128 LDS-DMA kernel stage the same records and run the same three-MFMA
+    sequence per output element in the same K order, so every output must agree BIT FOR BIT -- which is what lets the engine
+    pick either per layer, hand a sparsely filled last round of tiles to the small kernel, and keep a sample's results
+    independent of its batch.  Both are also checked against float64."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout, k, st, pd, use_res = shape
+    x = _rand(B, Cin, H, W, seed=31)
+    w = _rand(Cout, Cin, *k, seed=32, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = _rand(Cout, seed=33, scale=0.1)
+    OH, OW = (H + 2 * pd[0] - k[0]) // st[0] + 1, (W + 2 * pd[1] - k[1]) // st[1] + 1
+    res = _rand(B, Cout, OH, OW, seed=34) if use_res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = b.to(DEV)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
+    outs = []
+    try:
+        for kind in (0, 1):
+            assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
+            y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+            assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
+                                                  Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
+                                                  _lib.stream_of(xd)) == 0
+            torch.cuda.synchronize()
+            outs.append(y.cpu())
+    finally:
+        lib.d2t_op_set_conv_kernel(1, 0)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = _ref_conv(x, w, b, res, st, pd, 1)
+    assert float((outs[1].permute(0, 3, 1, 2) - ref).abs().max()) <= 4e-4
