@@ -16,6 +16,7 @@ DEC_TFM, DEC_ATTN = 0, 1
 ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV_FP32, CONV_BF16X3 = 0, 1
+ATTN_CELL_LOCATION, ATTN_CELL_BAHDANAU = 0, 1
 
 
 class D2TConfig(C.Structure):
@@ -23,7 +24,7 @@ class D2TConfig(C.Structure):
         "encoder", "in_channels", "backbone_out", "vit_depth", "vit_heads", "vit_dim", "patch_h", "patch_w",
         "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len",
         "decoder", "attn_hidden", "attn_kernel_size", "attn_kernel_dim", "attn_keys", "attn_enc_init",
-        "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb")]
+        "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb", "attn_cell", "attn_onehot")]
 
 
 class D2TPrepConfig(C.Structure):  # include/d2t_prep.h d2t_prep_config

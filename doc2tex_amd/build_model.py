@@ -278,6 +278,7 @@ class Model(nn.Module):
     def forward_decoder(self, contextual_feature, text, is_train=True, is_test=False, rtl_text=None):
         """build_model.py:45-53 / build_pred.py:28-50 / tfm.py:188-195."""
         beam_size = self.opt.get("beam_size", 1)  # read on every call, build_pred.py:31
+        self._luong_check()
         eng = self.engine()
         if self.stages["Pred"] in ("Attn", "Attnv2"):
             # build_pred.py:36-44 -> Attention.forward (seq2seq.py:333-347)
@@ -316,7 +317,15 @@ class Model(nn.Module):
                 prediction, logits = eng.decode_greedy(contextual_feature.contiguous(), text[:, 0], is_test)
         return prediction, logits, None, {}
 
+    def _luong_check(self):
+        """attn_type 'luong': Attention.forward_greedy / forward_beam call `self.attention_cell.reset_mem()` first thing
+        (seq2seq.py:114,285; seq2seq_v2.py:65,247) and LuongAttention has no such method, so in the reference every forward
+        of such a model -- training or evaluation -- ends in this AttributeError.  Same here, before any GPU work."""
+        if self.stages["Pred"] in ("Attn", "Attnv2") and self.opt["Prediction"]["params"].get("attn_type", "coverage") == "luong":
+            raise AttributeError("'LuongAttention' object has no attribute 'reset_mem'")
+
     def forward(self, input, text, is_train=True, is_test=False, rtl_text=None):
+        self._luong_check()
         if self.training:
             # module.train(): teacher-forced pass with BatchNorm on batch statistics (tfm.py:103-118 / seq2seq.py:224-331
             # with is_train), one autograd node over the whole network so that loss.backward() (engine/training.py:137)
@@ -328,6 +337,10 @@ class Model(nn.Module):
             else:  # Attn / Attnv2
                 if self.stages["Seq"] != "ViT":
                     raise NotImplementedError("training the LSTM-attention head is implemented on the HybridViT encoder only")
+                pp = self.opt["Prediction"]["params"]
+                if pp.get("attn_type", "coverage") not in ("coverage", "loc_aware") or not pp.get("embed_target", False):
+                    raise NotImplementedError("training the LSTM-attention head is implemented for the location-aware cells "
+                                              "(attn_type 'coverage' / 'loc_aware') with embed_target: True")
             if self.engine(finalize=False).cfg.gcb:
                 raise NotImplementedError("training with GlobalContext blocks (gcb: True) is not implemented in the HIP engine")
             logits = train_forward(self, input, text)

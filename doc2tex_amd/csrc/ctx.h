@@ -67,8 +67,9 @@ struct BiLstmW {
   int in = 0;
 };
 struct AttnW {
-  const float* emb = nullptr;
-  LinW key;                    // key_proj
+  const float* emb = nullptr;     // embedding table [V][H], or nullptr with one-hot targets ...
+  const float* tokgate = nullptr; // ... whose gate contribution is row `token` of this [V][4H] table (W_ih[:, H:]^T)
+  LinW key;                    // key_proj (Bahdanau: i2h, no bias)
   float *wq_t = nullptr, *wloc = nullptr, *bloc = nullptr, *wx_t = nullptr, *bx = nullptr, *wg_t = nullptr;
   float *wih_t = nullptr, *wic_t = nullptr;
   const float *bq = nullptr, *wscore = nullptr, *bg = nullptr, *bih = nullptr, *bic = nullptr;

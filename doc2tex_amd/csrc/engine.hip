@@ -38,11 +38,11 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
   }
   return D2T_OK;
 }
-int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K) {
-  const RawW *w, *b;
+int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K, bool bias = true) {
+  const RawW *w, *b = nullptr;
   int rc;
-  if ((rc = need(c, k + ".weight", &w, {N, K})) || (rc = need(c, k + ".bias", &b, {N}))) return rc;
-  *out = LinW{w->p, b->p, N, K};
+  if ((rc = need(c, k + ".weight", &w, {N, K})) || (bias && (rc = need(c, k + ".bias", &b, {N})))) return rc;
+  *out = LinW{w->p, b ? b->p : nullptr, N, K};
   return D2T_OK;
 }
 // bf16 hi/lo planes of a Linear's weight for the bf16x3 GEMM kernel (K % 32 == 0)
@@ -515,22 +515,32 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
     AttnW& A = c->attn;
     A = AttnW{};
     A.taps = taps;
-    const RawW *emb, *lcw, *lcb, *lpw, *lpb, *qw, *qb, *sw, *sb, *wih, *whh, *bih, *bhh, *gw, *gb;
-    if ((rc = need(c, pp + "embedding.weight", &emb, {V, Hh})) ||
-        (rc = need(c, ac + "attn.loc_conv.weight", &lcw, {kd, 1, taps})) ||
-        (rc = need(c, ac + "attn.loc_conv.bias", &lcb, {kd})) ||
-        (rc = need(c, ac + "attn.loc_proj.weight", &lpw, {Hh, kd})) ||
-        (rc = need(c, ac + "attn.loc_proj.bias", &lpb, {Hh})) ||
-        (rc = need(c, ac + "attn.query_proj.weight", &qw, {Hh, Hh})) ||
-        (rc = need(c, ac + "attn.query_proj.bias", &qb, {Hh})) ||
-        (rc = get_lin(c, ac + "attn.key_proj", &A.key, Hh, Hh)) ||
-        (rc = need(c, ac + "attn.score.weight", &sw, {1, Hh})) || (rc = need(c, ac + "attn.score.bias", &sb, {1})) ||
-        (rc = need(c, ac + "rnn.weight_ih", &wih, {4 * Hh, 2 * Hh})) ||
+    const RawW *emb = nullptr, *lcw = nullptr, *lcb = nullptr, *lpw = nullptr, *lpb = nullptr, *qw, *qb, *sw, *sb = nullptr,
+               *wih, *whh, *bih, *bhh, *gw, *gb;
+    const bool bahdanau = g.attn_cell == D2T_ATTN_CELL_BAHDANAU, onehot = g.attn_onehot != 0;
+    const int Ein = onehot ? V : Hh;  // width of the decoder-input part of rnn.weight_ih
+    if (!onehot && (rc = need(c, pp + "embedding.weight", &emb, {V, Hh}))) return rc;
+    if (bahdanau) {  // BahdanauAttentionCell (attention1D.py:71-85): i2h without bias, h2h, score without bias
+      if ((rc = need(c, ac + "attn.h2h.weight", &qw, {Hh, Hh})) || (rc = need(c, ac + "attn.h2h.bias", &qb, {Hh})) ||
+          (rc = get_lin(c, ac + "attn.i2h", &A.key, Hh, Hh, /*bias=*/false)) ||
+          (rc = need(c, ac + "attn.score.weight", &sw, {1, Hh})))
+        return rc;
+    } else if ((rc = need(c, ac + "attn.loc_conv.weight", &lcw, {kd, 1, taps})) ||
+               (rc = need(c, ac + "attn.loc_conv.bias", &lcb, {kd})) ||
+               (rc = need(c, ac + "attn.loc_proj.weight", &lpw, {Hh, kd})) ||
+               (rc = need(c, ac + "attn.loc_proj.bias", &lpb, {Hh})) ||
+               (rc = need(c, ac + "attn.query_proj.weight", &qw, {Hh, Hh})) ||
+               (rc = need(c, ac + "attn.query_proj.bias", &qb, {Hh})) ||
+               (rc = get_lin(c, ac + "attn.key_proj", &A.key, Hh, Hh)) ||
+               (rc = need(c, ac + "attn.score.weight", &sw, {1, Hh})) || (rc = need(c, ac + "attn.score.bias", &sb, {1}))) {
+      return rc;
+    }
+    if ((rc = need(c, ac + "rnn.weight_ih", &wih, {4 * Hh, Hh + Ein})) ||
         (rc = need(c, ac + "rnn.weight_hh", &whh, {4 * Hh, Hh})) || (rc = need(c, ac + "rnn.bias_ih", &bih, {4 * Hh})) ||
         (rc = need(c, ac + "rnn.bias_hh", &bhh, {4 * Hh})) || (rc = need(c, ac + "generator.weight", &gw, {V, Hh})) ||
         (rc = need(c, ac + "generator.bias", &gb, {V})))
       return rc;
-    A.emb = emb->p; A.bq = qb->p; A.wscore = sw->p; A.bg = gb->p;
+    A.emb = emb ? emb->p : nullptr; A.bq = qb->p; A.wscore = sw->p; A.bg = gb->p;
     auto alloc = [&](float** dst, size_t n) -> int {
       void* q;
       int r2 = dev_alloc(c, &q, n * 4);
@@ -544,11 +554,26 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
         (rc = alloc(&A.wg_t, (size_t)Hh * V)))
       return rc;
     HIPCHK(c, launch_transpose_into(qw->p, Hh, Hh, A.wq_t, Hh, 0, s));
-    HIPCHK(c, launch_transpose_into(wih->p, 4 * Hh, 2 * Hh, A.wx_t, 4 * Hh, 0, s));       // rows [ctx ; emb]
+    if (!onehot) {
+      HIPCHK(c, launch_transpose_into(wih->p, 4 * Hh, 2 * Hh, A.wx_t, 4 * Hh, 0, s));       // rows [ctx ; emb]
+    } else {
+      // one-hot decoder input (seq2seq.py:72-78): W_ih . [ctx ; onehot(tok)] = W_ih[:, :H] . ctx + W_ih[:, H + tok]; the
+      // kernel keeps its [ctx ; emb ; h] layout with zero "emb" rows and adds row `tok` of the transposed tail of W_ih
+      float* full;  // W_ih^T [H + V][4H]
+      if ((rc = alloc(&full, (size_t)(Hh + V) * 4 * Hh))) return rc;
+      HIPCHK(c, launch_transpose_into(wih->p, 4 * Hh, Hh + V, full, 4 * Hh, 0, s));
+      HIPCHK(c, hipMemcpyAsync(A.wx_t, full, (size_t)Hh * 4 * Hh * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(c, hipMemsetAsync(A.wx_t + (size_t)Hh * 4 * Hh, 0, (size_t)Hh * 4 * Hh * 4, s));
+      A.tokgate = full + (size_t)Hh * 4 * Hh;
+    }
     HIPCHK(c, launch_transpose_into(whh->p, 4 * Hh, Hh, A.wx_t, 4 * Hh, 2 * Hh, s));      // rows h
     HIPCHK(c, launch_add_rows(bih->p, bhh->p, A.bx, 4 * Hh, s));
     HIPCHK(c, launch_transpose_into(gw->p, V, Hh, A.wg_t, V, 0, s));
-    {  // fold loc_proj o loc_conv (attention1D.py:150-152) into one [H][taps] filter on the host
+    if (bahdanau) {  // no location term, no score bias: a zero one-tap filter
+      HIPCHK(c, hipMemsetAsync(A.wloc, 0, (size_t)Hh * taps * 4, s));
+      HIPCHK(c, hipMemsetAsync(A.bloc, 0, (size_t)Hh * 4, s));
+      A.bscore = 0.f;
+    } else {  // fold loc_proj o loc_conv (attention1D.py:150-152) into one [H][taps] filter on the host
       std::vector<float> hcw((size_t)kd * taps), hcb(kd), hpw((size_t)Hh * kd), hpb(Hh), hsb(1);
       HIPCHK(c, hipStreamSynchronize(s));
       HIPCHK(c, hipMemcpy(hcw.data(), lcw->p, hcw.size() * 4, hipMemcpyDeviceToHost));
@@ -1123,7 +1148,7 @@ int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T
   p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
   p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
   p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
-  p.emb = c->attn.emb; p.probs = probs; p.tokens = tokens; p.end_step = end_step;
+  p.emb = c->attn.emb; p.tokgate = c->attn.tokgate; p.probs = probs; p.tokens = tokens; p.end_step = end_step;
   p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage; p.end_token = 1;  // attn_converter.py:8
   HIPCHK(c, launch_attn_decode(p, s));
   int steps = S;
@@ -1158,7 +1183,9 @@ int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t bea
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   const d2t_config& g = c->cfg;
   if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
-  if (!g.attn_coverage) return fail(c, D2T_ESTATE, "LSTM beam search is implemented for attn_type 'coverage' only");
+  if (!g.attn_coverage && g.attn_cell != D2T_ATTN_CELL_BAHDANAU)
+    return fail(c, D2T_ESTATE, "LSTM beam search is implemented for the coverage and Bahdanau cells (the reference's 'loc_aware' beam "
+                "hands the previous beam's un-reordered alignment to the next step, seq2seq.py:207)");
   if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
   const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = beam_size;
   const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
@@ -1214,7 +1241,7 @@ int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t bea
   p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
   p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
   p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
-  p.emb = c->attn.emb; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
+  p.emb = c->attn.emb; p.tokgate = c->attn.tokgate; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
   p.S = 1; p.V = V; p.H = Hh; p.E = Hh; p.coverage = 1; p.end_token = 1;
   p.step_mode = 1;
   p.st_h_in = st[0]; p.st_c_in = st[1]; p.st_mem_in = st[4];
@@ -1304,7 +1331,9 @@ int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   const d2t_config& g = c->cfg;
   if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
-  if (!g.attn_coverage) return fail(c, D2T_ESTATE, "LSTM beam search is implemented for attn_type 'coverage' only");
+  if (!g.attn_coverage && g.attn_cell != D2T_ATTN_CELL_BAHDANAU)
+    return fail(c, D2T_ESTATE, "LSTM beam search is implemented for the coverage and Bahdanau cells (the reference's 'loc_aware' beam "
+                "hands the previous beam's un-reordered alignment to the next step, seq2seq.py:207)");
   if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
   const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = N * beam_size;
   const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
@@ -1362,7 +1391,7 @@ int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32
   p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
   p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
   p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
-  p.emb = c->attn.emb; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
+  p.emb = c->attn.emb; p.tokgate = c->attn.tokgate; p.probs = d_logits; p.tokens = d_dummy; p.end_step = d_end;
   p.S = 1; p.V = V; p.H = Hh; p.E = Hh; p.coverage = 1; p.end_token = 1;
   p.step_mode = 1;
   p.st_h_in = st[0]; p.st_c_in = st[1]; p.st_mem_in = st[4];

@@ -110,7 +110,8 @@ struct AttnDecP {
   const float* wx_t; const float* bx;  // LSTMCell: [ctx(D) ; emb(E) ; h(H)] -> 4H, transposed [(D+E+H)][4H]; bias b_ih+b_hh
   const float* wg_t; const float* bg;  // generator^T [H][V], bias
   const float* wih_t; const float* bih; const float* wic_t; const float* bic;  // proj_init_h/c^T [D][H]
-  const float* emb;                    // [V][E]
+  const float* emb;                    // [V][E], or nullptr with one-hot targets: then ...
+  const float* tokgate;                // ... [V][4H] rows of W_ih^T behind the context columns are added to the gates
   float* probs; int64_t* tokens; int* end_step;  // [B][S][V], [B][S], [B] (-1 = never ended)
   int B, S, V, H, E, coverage, end_token;
   // Beam-search step mode (S == 1): every block is one hypothesis of sample 0 (shared keys); the recurrent state is

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
 #pragma unroll 8
       for (int k = 0; k < H; ++k) a = fmaf(h_s[k], p.wq_t[(size_t)k * H + tid], a);
       hq_s[tid] = a;
-      emb_s[tid] = p.emb[(size_t)tok_s * p.E + tid];
+      emb_s[tid] = p.emb ? p.emb[(size_t)tok_s * p.E + tid] : 0.f;  // one-hot targets: see tokgate below
       if (p.sv_hq) p.sv_hq[((size_t)b * p.S + step) * H + tid] = a;
     }
     __syncthreads();
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
     // (5) LSTMCell gates: thread = gate row, [ctx ; emb ; h] . W^T (coalesced transposed weights)
     {
       float a = p.bx[tid];
+      if (p.tokgate) a += p.tokgate[(size_t)tok_s * 4 * H + tid];  // W_ih . onehot(token) = one column of W_ih
       const float* w = p.wx_t + tid;
 #pragma unroll 8
       for (int k = 0; k < 3 * H; ++k) a = fmaf(x_s[k], w[(size_t)k * 4 * H], a);

@@ -965,6 +965,8 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (lstm && L != g.batch_max_length + 1) return fail(c, D2T_EINVAL, "the Attn head trains on batch_max_length + 1 = %d steps", g.batch_max_length + 1);
   if (!lstm && L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
   if (g.gcb) return fail(c, D2T_ESTATE, "the training step does not support GlobalContext blocks (gcb)");
+  if (lstm && (g.attn_cell != D2T_ATTN_CELL_LOCATION || g.attn_onehot))
+    return fail(c, D2T_ESTATE, "the Attn training step is implemented for the location-aware cells with embedded targets");
   if (!c->train) c->train = new d2t_train_state();
   d2t_train_state* st = c->train;
   st->tape.reset();

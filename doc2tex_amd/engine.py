@@ -66,7 +66,14 @@ def config_from_opt(opt):
         cfg.attn_hidden = int(pp["hidden_size"])
         cfg.attn_kernel_size, cfg.attn_kernel_dim = int(pp["kernel_size"]), int(pp["kernel_dim"])
         cfg.attn_enc_init = int(bool(pp.get("enc_init", False)))
-        cfg.attn_coverage = int(pp.get("attn_type", "coverage") == "coverage")
+        attn_type = pp.get("attn_type", "coverage")
+        if attn_type == "luong":  # constructs in the reference, but no forward can run (build_model raises before any engine exists)
+            raise AttributeError("'LuongAttention' object has no attribute 'reset_mem'")
+        cfg.attn_coverage = int(attn_type == "coverage")
+        cfg.attn_cell = _lib.ATTN_CELL_LOCATION if attn_type in ("coverage", "loc_aware") else _lib.ATTN_CELL_BAHDANAU
+        cfg.attn_onehot = int(not pp.get("embed_target", False))
+        if cfg.attn_cell == _lib.ATTN_CELL_BAHDANAU:
+            cfg.attn_kernel_size, cfg.attn_kernel_dim = 0, 1  # no location filter
         sm = pp.get("seqmodel", "ViT")
         if pred["name"] == "Attnv2":  # seq2seq_v2.py:182-199
             if sm in ("BiLSTM", "VIG"):

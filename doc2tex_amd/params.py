@@ -317,24 +317,73 @@ class _LocationAwareAttentionParams(_Holder):
         self.generator = nn.Linear(hidden_size, num_classes)
 
 
+class _BahdanauAttentionCellParams(_Holder):
+    """BahdanauAttentionCell, attention1D.py:71-77."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.i2h = nn.Linear(input_dim, hidden_dim, bias=False)
+        self.h2h = nn.Linear(hidden_dim, hidden_dim)
+        self.score = nn.Linear(hidden_dim, 1, bias=False)
+
+
+class _BahdanauAttentionParams(_Holder):
+    """BahdanauAttention, attention1D.py:88-97."""
+
+    def __init__(self, input_size, hidden_size, num_embeddings, num_classes):
+        super().__init__()
+        self.attn = _BahdanauAttentionCellParams(input_size, hidden_size)
+        self.rnn = nn.LSTMCell(input_size + num_embeddings, hidden_size)
+        self.generator = nn.Linear(hidden_size, num_classes)
+
+
+class _LuongAttentionCellParams(_Holder):
+    """LuongAttentionCell, attention1D.py:38-50."""
+
+    def __init__(self, hidden_size, method):
+        super().__init__()
+        if method in ("general", "concat"):
+            self.fc = nn.Linear(hidden_size, hidden_size, bias=False)
+        if method == "concat":
+            self.weight = nn.Parameter(torch.zeros(1, hidden_size))  # the reference leaves it uninitialised (:50)
+
+
+class _LuongAttentionParams(_Holder):
+    """LuongAttention, attention1D.py:8-16.  Holds the reference's parameters so that checkpoints load; the reference
+    cannot run this cell (Attention.forward_* call attention_cell.reset_mem(), which it does not define)."""
+
+    def __init__(self, input_size, hidden_size, num_embeddings, num_classes, method="dot"):
+        super().__init__()
+        self.attn = _LuongAttentionCellParams(hidden_size, method)
+        self.rnn = nn.LSTMCell(num_embeddings, hidden_size)
+        self.generator = nn.Linear(2 * hidden_size, num_classes)
+
+
 class AttentionParams(_Holder):
-    """Attention.__init__ / AttentionV2, prediction_head/seq2seq.py:11-82 (location-aware cells only)."""
+    """Attention.__init__ / AttentionV2, prediction_head/seq2seq.py:11-82: the attention cell is chosen by `attn_type`
+    ('luong' -> Luong, 'loc_aware' / 'coverage' -> location-aware, anything else -> Bahdanau, :44-53), the decoder input is
+    an nn.Embedding (embed_target) or the one-hot vector of the previous token (:72-78)."""
 
     def __init__(self, kernel_size, kernel_dim, input_size, hidden_size, num_classes, embed_dim=None,
                  attn_type="coverage", embed_target=False, enc_init=False, teacher_forcing=1.0, droprate=0.1,
                  method="concat", seqmodel="ViT", viz_attn=False, device="cuda"):
         super().__init__()
-        if attn_type not in ("coverage", "loc_aware"):
-            raise NotImplementedError(f"attn_type '{attn_type}' is not on the accelerated path")
-        if not embed_target:
-            raise NotImplementedError("embed_target=False (one-hot targets) is not on the accelerated path")
         if embed_dim is None:
             embed_dim = input_size
-        if input_size != 256 or hidden_size != 256 or embed_dim != 256:
+        if input_size != 256 or hidden_size != 256 or (embed_target and embed_dim != 256):
             raise NotImplementedError("the Attn kernel is built for input_size = hidden_size = embed_dim = 256")
-        self.embedding = nn.Embedding(num_classes, embed_dim, padding_idx=0)  # ATTN.START() = 0
-        self.attention_cell = _LocationAwareAttentionParams(kernel_size, kernel_dim, input_size, hidden_size,
-                                                            embed_dim, num_classes)
+        if not embed_target and num_classes > 1024:
+            raise NotImplementedError("one-hot targets: the Attn kernel handles up to 1024 classes")
+        if embed_target:
+            self.embedding = nn.Embedding(num_classes, embed_dim, padding_idx=0)  # ATTN.START() = 0
+        num_embeddings = embed_dim if embed_target else num_classes
+        if attn_type == "luong":
+            self.attention_cell = _LuongAttentionParams(input_size, hidden_size, num_embeddings, num_classes, method)
+        elif attn_type in ("loc_aware", "coverage"):
+            self.attention_cell = _LocationAwareAttentionParams(kernel_size, kernel_dim, input_size, hidden_size,
+                                                                num_embeddings, num_classes)
+        else:
+            self.attention_cell = _BahdanauAttentionParams(input_size, hidden_size, num_embeddings, num_classes)
         self.hidden_size, self.input_size, self.num_classes = hidden_size, input_size, num_classes
         self.kernel_size, self.kernel_dim = kernel_size, kernel_dim
         self.attn_type, self.enc_init, self.seqmodel, self.device = attn_type, enc_init, seqmodel, device

@@ -134,6 +134,16 @@ _CONFIGS["TS0"]["_crop"] = (48, 64)
 _CONFIGS["TS0D"] = copy.deepcopy(_CONFIGS["TS0"])
 _CONFIGS["TS0D"]["Prediction"]["params"]["droprate"] = 0.25
 _CONFIGS["TS0D"]["Prediction"]["params"]["teacher_forcing"] = 0.7
+# the other attention cells / decoder inputs of Attention.__init__ (seq2seq.py:11-68): Bahdanau cell (any attn_type that is
+# not luong / loc_aware / coverage), one-hot targets (embed_target False, the constructor's default), and Luong
+_CONFIGS["B0"] = copy.deepcopy(_CONFIGS["C0"])  # VGG + BiLSTM + Attn, Bahdanau cell, embedded targets
+_CONFIGS["B0"]["Prediction"]["params"]["attn_type"] = "bahdanau"
+_CONFIGS["TB0"] = copy.deepcopy(_CONFIGS["TS0"])  # tiny HybridViT + Attnv2, Bahdanau cell, one-hot targets, zero initial state
+_CONFIGS["TB0"]["Prediction"]["params"].update({"attn_type": "bahdanau", "embed_target": False, "enc_init": False})
+_CONFIGS["TO0"] = copy.deepcopy(_CONFIGS["TS0"])  # tiny HybridViT + Attnv2, coverage cell, one-hot targets
+_CONFIGS["TO0"]["Prediction"]["params"]["embed_target"] = False
+_CONFIGS["TL0"] = copy.deepcopy(_CONFIGS["TS0"])  # Luong cell: constructs, every forward raises (attention_cell.reset_mem)
+_CONFIGS["TL0"]["Prediction"]["params"].update({"attn_type": "luong", "method": "general"})
 _CONFIGS["C3"] = copy.deepcopy(_CONFIGS["C2"])
 _CONFIGS["C3"]["_batch"] = 32  # per GPU; 256 global over 8 GPUs
 

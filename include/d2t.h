@@ -83,6 +83,8 @@ enum {
 /* Activation codes of d2t_op_conv2d. */
 enum { D2T_ACT_NONE = 0, D2T_ACT_RELU = 1, D2T_ACT_GELU = 2 };
 
+enum { D2T_ATTN_CELL_LOCATION = 0, D2T_ATTN_CELL_BAHDANAU = 1 };
+
 typedef struct d2t_config {
   int32_t encoder;      /* D2T_ENC_*: Feat=ResNet+Seq=None  |  Seq=ViT (hybrid) */
   int32_t in_channels;  /* 1 (grey crops) */
@@ -104,6 +106,11 @@ typedef struct d2t_config {
   int32_t bilstm_hidden;    /* SequenceModeling.params.hidden_size of the BiLSTM, 256 */
   int32_t batch_max_length; /* Attn decoders run batch_max_length + 1 steps */
   int32_t gcb;              /* 1: GlobalContext blocks close the four ResNet stages (gcb: True) */
+  /* appended in v3: the other cells / inputs of Attention.__init__ (prediction_head/seq2seq.py:31-53) */
+  int32_t attn_cell;        /* D2T_ATTN_CELL_*: location-aware (attn_type 'coverage' | 'loc_aware') or Bahdanau
+                               (attention1D.py:71-118: keys "attn.i2h / attn.h2h / attn.score", no alignment memory) */
+  int32_t attn_onehot;      /* 1 = embed_target False: the decoder input is the one-hot vector of the previous token
+                               (seq2seq.py:72-78), rnn.weight_ih is [4H][H + num_class] and there is no embedding table */
 } d2t_config;
 
 /* ---- lifecycle ----------------------------------------------------------

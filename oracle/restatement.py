@@ -452,15 +452,57 @@ def bilstm(x, sd, p):
     return F.linear(torch.cat(outs, dim=2), sd[p + "linear.weight"], sd[p + "linear.bias"])
 
 
+class LuongResetMemError(AttributeError):
+    """attn_type 'luong': Attention.forward_greedy / forward_beam call `self.attention_cell.reset_mem()` unconditionally
+    (seq2seq.py:114,285; seq2seq_v2.py:65,247) and LuongAttention (addon_module/attention1D.py:8-35) defines no such
+    method -- the reference raises AttributeError before the first step.  The restatement raises the same type."""
+
+
+def _attn_keys_proj(keys, sd, a, attn_type):
+    """Projection of the encoder outputs inside the score: LocationAwareAttentionCell.key_proj (attention1D.py:132,145) or
+    BahdanauAttentionCell.i2h (bias-free, :75,80)."""
+    if attn_type in ("coverage", "loc_aware"):
+        return F.linear(keys, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
+    return F.linear(keys, sd[a + "attn.i2h.weight"])
+
+
+def _attn_alpha(kp, h, mem, sd, a, attn_type):
+    """Alignment of one step, [M,T,1].  Location-aware cell (attention1D.py:121-161,216-226): tanh(key_proj + query_proj +
+    loc_proj(loc_conv(last alignment))) -> score (with bias); Bahdanau cell (:71-85,104-106): tanh(i2h + h2h) -> score
+    (no bias), no memory."""
+    if attn_type in ("coverage", "loc_aware"):
+        hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
+        pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
+        last = torch.zeros(h.shape[0], kp.shape[-2], 1, dtype=kp.dtype) if mem is None else mem
+        loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
+        loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
+        e = F.linear(torch.tanh(kp + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])
+    else:
+        hq = F.linear(h, sd[a + "attn.h2h.weight"], sd[a + "attn.h2h.bias"]).unsqueeze(1)
+        e = F.linear(torch.tanh(kp + hq), sd[a + "attn.score.weight"])
+    return F.softmax(e, dim=1)
+
+
+def _attn_embed(targets, sd, p, V, embed_target, dtype):
+    """Decoder input of a step: nn.Embedding(padding_idx=[GO]) (seq2seq.py:33-35,69-70) or the one-hot vector of
+    _char_to_onehot (:72-78) when embed_target is False (the constructor's default)."""
+    if embed_target:
+        return F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)
+    return F.one_hot(targets, V).to(dtype)
+
+
 def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_init=True, is_test=False, teacher=None,
-                flags=None, drop=None):
+                flags=None, drop=None, embed_target=True):
     """Attention.forward_greedy (prediction_head/seq2seq.py:224-331) / AttentionV2.forward_greedy
-    (seq2seq_v2.py:176-293) in eval mode (is_train=False) with embed_target=True, on the
-    LocationAwareAttention cell (addon_module/attention1D.py:121-161,203-242).
+    (seq2seq_v2.py:176-293) in eval mode (is_train=False), on the LocationAwareAttention cell
+    (addon_module/attention1D.py:121-161,203-242; attn_type 'coverage' / 'loc_aware') or the BahdanauAttention cell
+    (:71-118; any other attn_type except 'luong', which raises), with embedded or one-hot targets.
 
     seqmodel: 'BiLSTM' (keys = all tokens, init from their mean), 'TFM' (AttentionV2: keys without the
     cls token, init from the cls token), 'first' (Attention v1 on a non-BiLSTM encoder: keys = all
     tokens, init from token 0)."""
+    if attn_type == "luong":
+        raise LuongResetMemError("'LuongAttention' object has no attribute 'reset_mem'")
     B = batch_H.shape[0]
     a = p + "attention_cell."
     keys = batch_H[:, 1:] if seqmodel == "TFM" else batch_H
@@ -478,16 +520,10 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
     mem = None  # attention memory: None on the first step (-> zeros, attention1D.py:147-148)
     alpha_cum = torch.zeros(B, T, 1, dtype=keys.dtype)
     end = torch.zeros(B, dtype=torch.bool)
-    kp = F.linear(keys, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
-    pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
+    kp = _attn_keys_proj(keys, sd, a, attn_type)
     for i in range(num_steps):
-        emb = F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)  # seq2seq.py:33-35
-        hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
-        last = torch.zeros(B, T, 1, dtype=keys.dtype) if mem is None else mem
-        loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
-        loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
-        e = F.linear(torch.tanh(kp + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])
-        alpha = F.softmax(e, dim=1)
+        emb = _attn_embed(targets, sd, p, V, embed_target, keys.dtype)
+        alpha = _attn_alpha(kp, h, mem, sd, a, attn_type)
         context = torch.bmm(alpha.permute(0, 2, 1), keys).squeeze(1)
         g = (F.linear(torch.cat([context, emb], 1), sd[a + "rnn.weight_ih"], sd[a + "rnn.bias_ih"])
              + F.linear(h, sd[a + "rnn.weight_hh"], sd[a + "rnn.bias_hh"]))
@@ -498,7 +534,7 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
         if attn_type == "coverage":
             alpha_cum = alpha_cum + alpha
             mem = alpha_cum
-        else:  # loc_aware
+        elif attn_type == "loc_aware":
             mem = alpha
         if teacher is not None:
             # is_train (seq2seq.py:298-316): dropout on the generator output, then the next input is the label
@@ -522,15 +558,20 @@ def attn_greedy(batch_H, sd, p, num_steps, seqmodel, attn_type="coverage", enc_i
     return probs.argmax(2), probs
 
 
-def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
+def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True, attn_type="coverage", embed_target=True):
     """Attention.forward_beam (prediction_head/seq2seq.py:83-222) / AttentionV2.forward_beam (seq2seq_v2.py:12-174)
-    for one sample, coverage attention, embed_target=True.  Quirks kept: all `beam_size` rows start identical and
+    for one sample; coverage attention or the memory-free Bahdanau cell, embedded or one-hot targets ('loc_aware' hands
+    the un-reordered alignment of the previous beam to the next step, :207, a shape error as soon as the beam shrinks:
+    not restated).  Quirks kept: all `beam_size` rows start identical and
     step 0 takes the top-k of row 0 only (:145-146); the hidden state is re-ordered by prev_word_inds[incomplete]
     but the coverage memory only by `incomplete` (:197-207); a hypothesis ends on [s] = 1 and is stored with its
     [GO]; when the LAST executed step completed nothing the first live sequence is returned even if earlier steps
     completed some (:209-216); otherwise the best score/len sequence is returned together with the MAXIMUM raw
     score (:218-224).  Returns (seq LongTensor [1, n], score float)."""
     assert batch_H.shape[0] == 1
+    if attn_type == "luong":
+        raise LuongResetMemError("'LuongAttention' object has no attribute 'reset_mem'")
+    assert attn_type != "loc_aware"
     a = p + "attention_cell."
     H1 = batch_H[0]
     keys1 = H1[1:] if seqmodel == "TFM" else H1
@@ -544,8 +585,8 @@ def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
         h, c = torch.zeros(k, Hd), torch.zeros(k, Hd)
     keys = keys1[None].repeat(k, 1, 1)
     T = keys.shape[1]
-    kp1 = F.linear(keys1, sd[a + "attn.key_proj.weight"], sd[a + "attn.key_proj.bias"])
-    pad = (sd[a + "attn.loc_conv.weight"].shape[2] - 1) // 2
+    kp1 = _attn_keys_proj(keys1, sd, a, attn_type)
+    Vv = sd[a + "generator.weight"].shape[0]
     alpha_cum = torch.zeros(k, T, 1)
     mem = None
     seqs = torch.zeros(k, 1, dtype=torch.long)  # [GO] = 0 (attn_converter.py:8)
@@ -554,13 +595,8 @@ def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
     complete, complete_scores, complete_inds = [], [], []
     for step in range(num_steps):
         M = h.shape[0]
-        emb = F.embedding(targets, sd[p + "embedding.weight"], padding_idx=ATTN_GO)  # seq2seq.py:33-35
-        hq = F.linear(h, sd[a + "attn.query_proj.weight"], sd[a + "attn.query_proj.bias"]).unsqueeze(1)
-        last = torch.zeros(M, T, 1) if mem is None else mem
-        loc = F.conv1d(last.permute(0, 2, 1), sd[a + "attn.loc_conv.weight"], sd[a + "attn.loc_conv.bias"], padding=pad)
-        loc = F.linear(loc.transpose(1, 2), sd[a + "attn.loc_proj.weight"], sd[a + "attn.loc_proj.bias"])
-        e = F.linear(torch.tanh(kp1[None] + hq + loc), sd[a + "attn.score.weight"], sd[a + "attn.score.bias"])
-        alpha = F.softmax(e, dim=1)
+        emb = _attn_embed(targets, sd, p, Vv, embed_target, keys.dtype)
+        alpha = _attn_alpha(kp1[None], h, mem, sd, a, attn_type)
         context = torch.bmm(alpha.permute(0, 2, 1), keys[:M]).squeeze(1)
         g = (F.linear(torch.cat([context, emb], 1), sd[a + "rnn.weight_ih"], sd[a + "rnn.bias_ih"])
              + F.linear(h, sd[a + "rnn.weight_hh"], sd[a + "rnn.bias_hh"]))
@@ -589,8 +625,9 @@ def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True):
         h, c = h[prev[incomplete]], c[prev[incomplete]]
         top_scores = top_v[incomplete].unsqueeze(1)
         targets = nxt[incomplete]
-        alpha_cum = (alpha_cum + alpha)[incomplete]
-        mem = alpha_cum
+        if attn_type == "coverage":
+            alpha_cum = (alpha_cum + alpha)[incomplete]
+            mem = alpha_cum
     if not complete_inds:
         return torch.tensor(seqs[0][1:].tolist(), dtype=torch.long)[None], float(top_scores[0])
     best = max(range(len(complete)), key=lambda i: complete_scores[i] / len(complete[i]))
@@ -639,10 +676,11 @@ def forward(cfg, sd, image, text, is_train=True, is_test=False, faithful=False, 
         if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
             sm = "first"  # seq2seq.py:229-238: keys = all tokens, init from token 0
         if cfg.get("beam_size", 1) > 1:  # Attention.forward (seq2seq.py:333-347): beam only when not is_train
-            seq, score = attn_beam(mem, sd, p, cfg["batch_max_length"] + 1, sm, cfg["beam_size"], pp.get("enc_init", False))
+            seq, score = attn_beam(mem, sd, p, cfg["batch_max_length"] + 1, sm, cfg["beam_size"], pp.get("enc_init", False),
+                                   pp.get("attn_type", "coverage"), pp.get("embed_target", False))
             return seq, score, {}
         preds, probs = attn_greedy(mem, sd, p, cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
-                                   pp.get("enc_init", False), is_test)
+                                   pp.get("enc_init", False), is_test, embed_target=pp.get("embed_target", False))
         return preds, probs, {}
     if training:
         logits = tfm_full_pass(text, mem, sd, p, pp["num_decoder_layers"], pp["nhead"], key_padding=True)
@@ -684,7 +722,8 @@ def train_forward(cfg, sd, image, text_in, bn_train, drop=None, flags=None):
         if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":
             sm = "first"
         return attn_greedy(mem, sd, "predicter.Prediction.", cfg["batch_max_length"] + 1, sm, pp.get("attn_type", "coverage"),
-                           pp.get("enc_init", False), teacher=text_in, flags=flags, drop=drop)[1]
+                           pp.get("enc_init", False), teacher=text_in, flags=flags, drop=drop,
+                           embed_target=pp.get("embed_target", False))[1]
     return tfm_full_pass(text_in, mem, sd, "predicter.Prediction.", pp["num_decoder_layers"], pp["nhead"],
                          key_padding=True, drop=drop)
 

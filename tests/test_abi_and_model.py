@@ -38,7 +38,7 @@ def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.D2TConfig) == 4 * len(names)
 
 
-@pytest.mark.parametrize("name", ["C2", "C1", "T2", "C0", "S0"])
+@pytest.mark.parametrize("name", ["C2", "C1", "T2", "C0", "S0", "B0", "TB0", "TO0", "TL0"])
 def test_state_dict_keys_and_shapes_match_reference_manifest(manifests, name):
     m = Model(synth.make_config(name))
     sd = m.state_dict()
@@ -91,14 +91,23 @@ def test_constructor_mutates_config_like_reference():
 
 
 def test_unsupported_configs_raise():
-    cfg = synth.make_config("C0")
-    cfg["Prediction"]["params"]["attn_type"] = "luong"
-    with pytest.raises(NotImplementedError):
-        Model(cfg)
     cfg = synth.make_config("C2")
     cfg["FeatureExtraction"]["name"] = "ResNet"
     with pytest.raises(AssertionError):  # build_model.py:18-19
         Model(cfg)
+
+
+def test_luong_model_constructs_and_every_forward_raises_like_the_reference(cases):
+    """The reference builds a LuongAttention cell for attn_type 'luong' (seq2seq.py:44-46) but cannot run it:
+    forward_greedy / forward_beam call attention_cell.reset_mem() (seq2seq.py:114,285), which that class lacks.  The fixture
+    holds the reference's own exception; the drop-in raises the same one, in train and eval mode, before any GPU work."""
+    c = next(r for r in cases["raises"] if r["case"] == "tl0_luong_greedy")
+    m = Model(synth.make_config("TL0"))
+    img = synth.synth_images(1, 48, 64)
+    for mode in (m.eval(), m.train()):
+        with pytest.raises(AttributeError) as e:
+            mode(img, torch.zeros(1, 7, dtype=torch.long), is_train=False)
+        assert str(e.value) == c["message"] and c["type"] == "AttributeError"
 
 
 def test_tables_equal_oracle_tables():

@@ -15,7 +15,9 @@ GREEDY = ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_sma
           "c0_greedy", "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy",
           # round 2: config C4's geometry (max_dimension [160, 640]); c4_greedy_160 / c1_greedy_full (151 steps, ~15 s each) are
           # re-checked by tools/make_golden.py at generation time and on the GPU box, not here
-          "c4_greedy_128", "c4_greedy_96"]
+          "c4_greedy_128", "c4_greedy_96",
+          # the other cells / inputs of the LSTM-attention head: Bahdanau, one-hot targets (seq2seq.py:31-53,72-78)
+          "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy"]
 
 
 def _case(cases, kind, name):
@@ -72,7 +74,8 @@ def test_beam_matches_reference_fixture(cases, manifests, name):
     assert abs(score - c["score"]) <= 1e-3
 
 
-@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish"])
+@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish",
+                                  "b0_beam3", "b0_beam3_end", "tb0_beam4", "to0_beam5", "to0_beam5_end"])
 def test_attn_beam_matches_reference_fixture(cases, manifests, name):
     """LSTM-attention beam search (seq2seq.py:83-222, seq2seq_v2.py:12-174) of the oracle against the reference."""
     c = _case(cases, "attn_beam", name)
@@ -180,3 +183,16 @@ def test_train_dropout_placement_matches_reference_fixture(cases, manifests, nam
     loss, logits, grads, _ = R.train_step_grads(cfg, sd, img, text, drop=drop, flags=c.get("flags"))
     assert abs(float(loss) - c["loss"]) <= 1e-5 * max(1.0, abs(c["loss"]))
     assert abs(float(logits.double().sum()) - c["logits_sum"]) <= 1e-3 * max(1.0, abs(c["logits_sum"]))
+
+
+@pytest.mark.parametrize("name", ["tl0_luong_greedy", "tl0_luong_beam"])
+def test_configurations_the_reference_cannot_run_raise_the_same_error(cases, manifests, name):
+    """attn_type 'luong': the reference's own forward ends in AttributeError (attention_cell.reset_mem does not exist on
+    LuongAttention); the fixture holds the exception the reference raised, the oracle must end in the same one."""
+    c = next(r for r in cases["raises"] if r["case"] == name)
+    cfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], 6)
+    cfg["beam_size"] = c["beam_size"]
+    img = synth.synth_images(1, c["H"], c["W"], seed=1)
+    with pytest.raises(AttributeError) as e:
+        R.forward(cfg, sd, img, torch.zeros(1, 7, dtype=torch.long), is_train=False, is_test=True)
+    assert c["type"] == "AttributeError" and str(e.value) == c["message"]

@@ -36,7 +36,9 @@ def _run_engine(c, B=None):
                                   "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy",
                                   # BASELINE configs[4] geometry (max_dimension [160, 640]: 9x161 grid, 406 memory tokens) at
                                   # each bucket of SURVEY 8d, and configs[1] at its full 151 steps
-                                  "c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full"])
+                                  "c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full",
+                                  # Bahdanau cell, one-hot targets (the remaining branches of Attention.__init__)
+                                  "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy"])
 def test_greedy_vs_reference_fixture(cases, name):
     c = _case(cases, "greedy", name)
     z = np.load(os.path.join(GOLD, name + ".npz"))
@@ -198,7 +200,8 @@ def test_beam_vs_oracle_other_seeds(cases, manifests):
         assert abs(score - oscore) <= 1e-3
 
 
-@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish"])
+@pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish",
+                                  "b0_beam3", "b0_beam3_end", "tb0_beam4", "to0_beam5", "to0_beam5_end"])
 def test_attn_beam_vs_reference_fixture(cases, name):
     """LSTM-attention beam search (Attention.forward_beam seq2seq.py:83-222, AttentionV2.forward_beam
     seq2seq_v2.py:12-174; what config/test.yaml runs): token ids exact, score within 1e-3."""
@@ -497,3 +500,41 @@ def test_error_paths_raise_instead_of_crashing():
         eng.train_backward(torch.zeros(1, 9, synth.VOCAB, device="cuda"))  # no preceding training forward
     with pytest.raises(RuntimeError):
         eng.read_weight("no.such.tensor", torch.zeros(4, device="cuda"))
+
+
+@pytest.mark.parametrize("name", ["tl0_luong_greedy", "tl0_luong_beam"])
+def test_luong_configuration_raises_what_the_reference_raises(cases, name):
+    """attn_type 'luong' constructs (checkpoints load: same state_dict keys) and every forward ends in the reference's own
+    AttributeError -- Attention.forward_* call attention_cell.reset_mem(), which LuongAttention does not define."""
+    c = next(r for r in cases["raises"] if r["case"] == name)
+    cfg, m = engine_model(c["config"], 6, beam_size=c["beam_size"])
+    img = synth.synth_images(1, c["H"], c["W"], seed=1).cuda()
+    with pytest.raises(AttributeError) as e:
+        m(img, torch.zeros(1, 7, dtype=torch.long, device="cuda"), is_train=False, is_test=True)
+    assert c["type"] == "AttributeError" and str(e.value) == c["message"]
+
+
+def test_other_attention_cells_vs_oracle_other_seeds(manifests):
+    """Bahdanau cell / one-hot targets on inputs the fixtures do not hold: greedy tokens exact, logits within 1e-3; beam
+    sequences exact; and the batched beam extension equals the per-sample call."""
+    for cname, beam in (("TB0", 4), ("TO0", 3), ("B0", 2)):
+        H, W = synth.crop_shape(cname)
+        for iseed, eb in ((611, 0.0), (612, 0.3)):
+            cfg, m = engine_model(cname, 10, 1234, eb)
+            ocfg, sd = oracle_state_dict(cname, manifests[cname], 10, 1234, eb)
+            img = synth.synth_images(2, H, W, seed=iseed)
+            text = torch.zeros(2, 11, dtype=torch.long)
+            with torch.no_grad():
+                p, l, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=False)
+                op, ol, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=False)
+            assert torch.equal(p.cpu(), op), (cname, iseed)
+            assert float((l.cpu() - ol).abs().max()) <= LOGIT_TOL
+            cfgb, mb = engine_model(cname, 10, 1234, eb, beam_size=beam)
+            ocfg["beam_size"] = beam
+            with torch.no_grad():
+                seq, score, _ = mb(img[:1].cuda(), text[:1].cuda(), is_train=False, is_test=True)
+                oseq, oscore, _ = R.forward(ocfg, sd, img[:1], text[:1], is_train=False, is_test=True)
+                both = mb.beam_search_batch(img.cuda(), beam_size=beam)
+            assert seq[0].tolist() == oseq[0].tolist(), (cname, iseed, eb)
+            assert abs(float(score) - oscore) <= 1e-3
+            assert both[0][0][0].tolist() == seq[0].tolist() and abs(float(both[0][1]) - float(score)) <= 1e-5

@@ -64,7 +64,15 @@ GREEDY_CASES = [
     ("c4_greedy_96", "C4", 2, 96, 384, 20, 1234, 1072, 0.0, False),
     # BASELINE configs[1] at its full decode length (the GPU test decodes B=32 and checks these first rows)
     ("c1_greedy_full", "C1", 2, 64, 256, 150, 1234, 1073, 0.0, False),
+    # round 2 -- the other attention cells / decoder inputs of Attention.__init__ (seq2seq.py:31-53): Bahdanau cell with
+    # embedded targets on the VGG + BiLSTM encoder; Bahdanau + one-hot targets + zero initial state and coverage + one-hot
+    # targets on the tiny HybridViT + Attnv2 stack
+    ("b0_greedy", "B0", 3, 32, 320, 20, 1234, 1080, 0.0, False),
+    ("b0_greedy_early", "B0", 3, 32, 320, 40, 1234, 1081, 0.0, True),
+    ("tb0_greedy", "TB0", 2, 48, 64, 12, 1234, 1082, 0.0, False),
+    ("to0_greedy", "TO0", 2, 48, 64, 12, 1234, 1083, 0.0, False),
 ]
+A15_GREEDY = ("b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy")
 ROUND2_GREEDY = ("c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full")
 BEAM_CASES = [
     ("t2_beam5", "T2", 48, 64, 16, 1234, 1010, 1.8, 5),
@@ -85,7 +93,16 @@ ATTN_BEAM_CASES = [
     ("s0_beam10", "S0", 96, 384, 10, 1234, 1052, 0.3, 10),
     ("s0_beam10_late", "S0", 96, 384, 10, 1234, 1052, 0.4, 10),  # completions early, none in the last step
     ("ts0_beam4_nofinish", "TS0", 48, 64, 6, 1234, 1053, 0.0, 4),
+    # round 2 -- beam search on the Bahdanau cell (no alignment memory) and with one-hot targets
+    ("b0_beam3", "B0", 32, 320, 12, 1234, 1084, 0.15, 3),
+    ("tb0_beam4", "TB0", 48, 64, 10, 1234, 1085, 0.3, 4),
+    ("to0_beam5", "TO0", 48, 64, 12, 1234, 1086, 0.3, 5),
+    ("to0_beam5_end", "TO0", 48, 64, 12, 1234, 1086, 0.38, 5),
+    ("b0_beam3_end", "B0", 32, 320, 12, 1234, 1084, 0.18, 3),
 ]
+A15_BEAM = ("b0_beam3", "tb0_beam4", "to0_beam5", "to0_beam5_end", "b0_beam3_end")
+# configurations whose every forward raises in the reference: name, config, H, W, beam_size
+RAISES_CASES = [("tl0_luong_greedy", "TL0", 48, 64, 1), ("tl0_luong_beam", "TL0", 48, 64, 3)]
 TRAIN_CASES = [("t2_train", "T2", 2, 48, 64, 20, 1234, 1020)]
 # full module.train() steps (BN batch statistics, teacher forcing, CE, backward): name, config, B, H, W, L, wseed, iseed
 TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_train_step", "T1", 2, 32, 64, 22, 1234, 1031),
@@ -252,6 +269,28 @@ def run_attn_beam(case):
     return {"case": name, "config": cname, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
             "end_bias": end_bias, "beam_size": beam, "seq": seq[0].tolist(), "score": float(score),
             "ended": bool(len(seq[0]) and int(seq[0][-1]) == 1), "torch": torch.__version__}
+
+
+def run_raises(case):
+    """Run the reference on a configuration it cannot run and record the exception it ends in (type and message), after
+    asserting that the restatement ends in the same one."""
+    name, cname, H, W, beam = case
+    cfg, m, sd = build_ref(cname, 6, beam_size=beam)
+    img = synth.synth_images(1, H, W, seed=1)
+    text = torch.zeros(1, 7, dtype=torch.long)
+    rep = {"case": name, "config": cname, "H": H, "W": W, "beam_size": beam, "torch": torch.__version__}
+    for who, fn in (("reference", lambda: m(img, text, is_train=False, is_test=True)),
+                    ("oracle", lambda: R.forward(cfg, sd, img, text, is_train=False, is_test=True))):
+        try:
+            with torch.no_grad():
+                fn()
+            raise SystemExit(f"{name}: the {who} did not raise")
+        except Exception as e:  # noqa: BLE001 -- the point is to record whatever it is
+            rep[who] = {"type": next(c.__name__ for c in type(e).__mro__ if c.__module__ == "builtins"), "message": str(e)}
+    assert rep["reference"] == rep["oracle"], rep
+    rep.update(rep.pop("reference"))
+    rep.pop("oracle")
+    return rep, manifest(sd), cname
 
 
 def run_train(case):
@@ -472,6 +511,36 @@ def main():
         with open(os.path.join(GOLD, "manifests.json"), "w") as f:
             json.dump(manifests, f)
         return
+    if os.environ.get("GOLDEN_ONLY") == "a15":  # add / refresh only the Bahdanau / one-hot / Luong fixtures
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        with open(os.path.join(GOLD, "manifests.json")) as f:
+            manifests = json.load(f)
+        for case in GREEDY_CASES:
+            if case[0] not in A15_GREEDY:
+                continue
+            rep, man, cname = run_greedy(case)
+            manifests[cname] = man
+            summary["greedy"] = [r for r in summary["greedy"] if r["case"] != rep["case"]] + [rep]
+            print("greedy", rep["case"], "steps", rep["steps"], "dmem", rep["diff_mem_folded"], "dlogit", rep["diff_logits_cached"],
+                  "gap", rep["min_top2_gap"], f'{rep["seconds"]}s', flush=True)
+        for case in ATTN_BEAM_CASES:
+            if case[0] not in A15_BEAM:
+                continue
+            rep = run_attn_beam(case)
+            summary["attn_beam"] = [r for r in summary["attn_beam"] if r["case"] != rep["case"]] + [rep]
+            print("attn_beam", rep["case"], rep["seq"], rep["score"], "ended", rep["ended"], flush=True)
+        summary["raises"] = []
+        for case in RAISES_CASES:
+            rep, man, cname = run_raises(case)
+            manifests[cname] = man
+            summary["raises"].append(rep)
+            print("raises", rep["case"], rep["type"], rep["message"], flush=True)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+            json.dump(manifests, f)
+        return
     if os.environ.get("GOLDEN_ONLY") == "gcb":  # add / refresh only the GlobalContext greedy fixtures
         with open(os.path.join(GOLD, "cases.json")) as f:
             summary = json.load(f)
@@ -534,6 +603,12 @@ def main():
         rep = run_train_step(case)
         summary["train_step"].append(rep)
         print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
+    summary["raises"] = []
+    for case in RAISES_CASES:
+        rep, man, cname = run_raises(case)
+        manifests[cname] = man
+        summary["raises"].append(rep)
+        print("raises", rep["case"], rep["type"], rep["message"], flush=True)
     summary["train_dropout"] = []
     for case in TRAIN_DROPOUT_CASES:
         rep = run_train_dropout(case)
