@@ -183,7 +183,14 @@ struct DmaIssuer {
 
 // block tile BM x BN, compute-wave grid WM x WN, NL dedicated loader waves (0: the compute waves issue the LDS-DMA themselves,
 // each its share, right after the K-step's barrier); ABL: ablation probes (1 no DMA, 2 no MFMA, 3 no ds_read / MFMA)
-template <int BM, int BN, int WM, int WN, int NL, int ABL = 0>
+// STG (stagger, MI355X_MICROARCH.md "Two waves per SIMD", item 9): all eight compute waves run the same program with one
+// barrier per K-step, so the two waves that share a SIMD (w and w + 4) reach their fragment reads, their MFMAs and the barrier
+// together -- both wait for LDS, then both want the matrix pipe.  With STG the second-dispatched half (waves 4-7) runs half
+// a K-step behind: it loads the fragments of a step's second half BEFORE the next barrier (the reads have returned when it
+// arrives there, so the stage may be overwritten as before) and issues those MFMAs right AFTER the barrier, while its SIMD
+// partner waits for its first fragments; later it reads while the partner multiplies.  Every accumulator still sees the
+// same MFMAs in the same order: results are bit-identical.
+template <int BM, int BN, int WM, int WN, int NL, int ABL = 0, bool STG = false>
 __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char* smem) {
   constexpr int NW = WM * WN, NT = (NW + NL) * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -268,48 +275,79 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
       }
     }
     int cur = 0, nxt2 = 2;  // stage of K-step kt / kt+2
-    for (int kt = 0; kt < KT; ++kt) {
-      if (NL == 0) {  // this wave's own pieces of K-step kt have landed (those of kt+1 may still be in flight)
-        if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
-      }
-      __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
-      if (NL == 0 && kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
-      __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the ds_reads / MFMAs
-      const unsigned char* ah = smem + cur * STAGE;
+    auto read_half = [&](const unsigned char* ah, int kk, bf16x8 (&fah)[MI], bf16x8 (&fal)[MI], bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
       const unsigned char* bh = ah + 2 * PLANE_A;
       const unsigned char* bl = bh + PLANE_B;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        if (ABL == 3) continue;
-        bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+      for (int i = 0; i < MI; ++i) {
+        fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[kk][i]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[kk][i]);
+      }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[kk][i]);
-          fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[kk][i]);
-        }
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[kk][j]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[kk][j]);
+      }
+    };
+    auto mma_half = [&](const bf16x8 (&fah)[MI], const bf16x8 (&fal)[MI], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+      if (ABL == 2) {  // keep the reads alive, drop the matrix work
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fbh[j]), "v"(fbl[j]));
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[kk][j]);
-          fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[kk][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
         }
-        if (ABL == 2) {  // keep the reads alive, drop the matrix work
-#pragma unroll
-          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(fbh[j]), "v"(fbl[j]));
-          continue;
+    };
+    const bool late = STG && wave >= NW / 2;  // wave-uniform: the half of the block that runs half a K-step behind
+    // two whole loops, not a branch inside one: an `if` around MFMAs that update the accumulators makes the compiler keep
+    // two copies of them (64 VGPRs each) and move them back and forth
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        if (NL == 0) {  // this wave's own pieces of K-step kt have landed (those of kt+1 may still be in flight)
+          if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
         }
+        __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
+        if (NL == 0 && kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
+        __builtin_amdgcn_sched_barrier(0);  // keep the DMA issue ahead of the ds_reads / MFMAs
+        const unsigned char* ah = smem + cur * STAGE;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-          }
+        for (int kk = 0; kk < 2; ++kk) {
+          if (ABL == 3) continue;
+          bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+          read_half(ah, kk, fah, fal, fbh, fbl);
+          mma_half(fah, fal, fbh, fbl);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
       }
-      cur = cur == 2 ? 0 : cur + 1;
-      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    } else {
+      bf16x8 gah[MI], gal[MI], gbh[NJ], gbl[NJ];  // second-half fragments carried across the barrier
+      auto step = [&](bool carried) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* ah = smem + cur * STAGE;
+        if (carried) mma_half(gah, gal, gbh, gbl);  // second half of the previous K-step, loaded before this barrier
+        __builtin_amdgcn_sched_barrier(0);          // (no reads of this step hoisted above: the carried fragments die first)
+        {
+          bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+          read_half(ah, 0, fah, fal, fbh, fbl);
+          mma_half(fah, fal, fbh, fbl);
+        }
+        read_half(ah, 1, gah, gal, gbh, gbl);
+        // the reads have returned before this wave arrives at the next barrier (after it the stage may be overwritten)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cur = cur == 2 ? 0 : cur + 1;
+      };
+      step(false);  // peeled: nothing carried into K-step 0 (a branch around accumulator updates would duplicate them)
+      for (int kt = 1; kt < KT; ++kt) step(true);
+      mma_half(gah, gal, gbh, gbl);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the last stages: the staging area becomes the epilogue's fp32 tile
@@ -347,6 +385,16 @@ __global__ __launch_bounds__(768, 3) __attribute__((amdgpu_num_vgpr(112))) void 
 __global__ __launch_bounds__(768, 3) __attribute__((amdgpu_num_vgpr(112))) void conv_bf16x3p_256x128_k4608(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
   conv_bf16x3p_body<256, 128, 4, 2, 4>(p, smem);
+}
+
+// waves 4-7 half a K-step behind their SIMD partners
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p_256x128_s(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4, 0, true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p_256x128_s_k4608(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p_body<256, 128, 4, 2, 4, 0, true>(p, smem);
 }
 
 // the same without dedicated loader waves: 8 waves (2 per SIMD), the compute waves issue the LDS-DMA themselves
@@ -415,10 +463,13 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   }
   if (grid > tiles) grid = tiles;
   const int abl = abl_probe();
+  static const int stagger = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
   static const int loaders = getenv("D2T_CONV_LOADERS") ? atoi(getenv("D2T_CONV_LOADERS")) : 4;
   if (abl == 1) hipLaunchKernelGGL(conv_bf16x3p_probe_no_dma, dim3(grid), dim3(768), 0, s, p2);
   else if (abl == 2) hipLaunchKernelGGL(conv_bf16x3p_probe_no_mfma, dim3(grid), dim3(768), 0, s, p2);
   else if (abl == 3) hipLaunchKernelGGL(conv_bf16x3p_probe_dma_only, dim3(grid), dim3(768), 0, s, p2);
+  else if (stagger && p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
+  else if (stagger) hipLaunchKernelGGL(conv_bf16x3p_256x128_s, dim3(grid), dim3(768), 0, s, p2);
   else if (loaders == 0 && p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_w8_k4608, dim3(grid), dim3(512), 0, s, p2);
   else if (loaders == 0) hipLaunchKernelGGL(conv_bf16x3p_256x128_w8, dim3(grid), dim3(512), 0, s, p2);
   else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p_256x128_k4608, dim3(grid), dim3(768), 0, s, p2);
