@@ -17,6 +17,7 @@ default for arrays / PIL images, "api" for paths, as in the reference.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -80,6 +81,7 @@ class Preprocessor:
             rc = self.lib.d2t_prep_create(C.byref(self.cfg), C.byref(h))
         self.h = h
         self._slot, self._stage = -1, [None] * 4  # rotating pinned staging blocks (_upload)
+        self.timing = None  # set to a dict to accumulate seconds per phase of batch()
         self._check(rc, "d2t_prep_create")
 
     def _check(self, rc, what):
@@ -114,16 +116,23 @@ class Preprocessor:
             # blocks is a copy queued three batches ago -- the host does not wait behind the encoder in flight.
             slot = self._slot = (self._slot + 1) % len(self._stage)
             stage = self._stage
+            t0 = time.perf_counter()
             if stage[slot] is None or stage[slot][0].numel() < total:
                 stage[slot] = (torch.empty(max(total, 1 << 20) * 5 // 4, dtype=torch.uint8).pin_memory(), torch.cuda.Event())
             else:
                 stage[slot][1].synchronize()
+            t1 = time.perf_counter()
             host, copied = stage[slot]
             hv = host.numpy()
             for a, o in zip(arrays, offs):
                 hv[o:o + a.size] = a.reshape(-1)
+            t2 = time.perf_counter()
             src = host[:total].to(self.device, non_blocking=True)
             copied.record()
+            if self.timing is not None:  # where a serving loop's host time goes (tools/serve_bench.py)
+                self.timing["stage_wait"] = self.timing.get("stage_wait", 0.0) + (t1 - t0)
+                self.timing["pack"] = self.timing.get("pack", 0.0) + (t2 - t1)
+                self.timing["h2d_enqueue"] = self.timing.get("h2d_enqueue", 0.0) + (time.perf_counter() - t2)
         return src, offs
 
     def _run(self, src, offs, plans, out_h, out_w):
@@ -212,10 +221,14 @@ class Preprocessor:
         """images: paths / PIL images / uint8 [h,w] arrays -> (tensors, errors): tensors[i] is image i's [1,1,H,W] result
         (a view into the [n,1,H,W] batch of its size bucket; `tensors[i]._base` is the bucket), errors[i] the exception
         instance the reference's resize() raises for image i (tensors[i] is None then)."""
+        t_in = time.perf_counter()
         arrays = [_as_gray_array(im) for im in images]
         n = len(arrays)
         tensors, errors = [None] * n, [None] * n
+        if self.timing is not None:
+            self.timing["to_gray"] = self.timing.get("to_gray", 0.0) + (time.perf_counter() - t_in)
         src, offs = self._upload(arrays)
+        t_up = time.perf_counter()
         # per image: which device buffer holds its current source, at which offset and size (pad() replaces the source)
         cur = [(src, int(offs[i]), arrays[i].shape) for i in range(n)]
         fallback = [False] * n
@@ -263,6 +276,8 @@ class Preprocessor:
             pending = redo
             if not pending:
                 break
+        if self.timing is not None:
+            self.timing["plan_and_launch"] = self.timing.get("plan_and_launch", 0.0) + (time.perf_counter() - t_up)
         return tensors, errors
 
     def __call__(self, img):

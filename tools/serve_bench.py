@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--group", type=int, default=3, help="decode groups (batches per decode step loop)")
+    ap.add_argument("--group", type=int, default=6, help="decode groups (batches per decode step loop)")
     ap.add_argument("--page-sets", type=int, default=4, help="distinct batches of pages cycled through")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -111,6 +111,7 @@ def main():
     consume(True)
     torch.cuda.synchronize(dev)
     done, t_pre, t_post = 0, 0.0, 0.0
+    pre.timing = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -121,7 +122,11 @@ def main():
     print(json.dumps({"metric": "formulas/s end to end (uint8 pages -> LaTeX strings)", "value": round(done / el, 1),
                       "unit": "formulas/s", "steps": args.steps, "batch": B, "ms_per_batch": round(el / args.steps * 1e3, 2),
                       "host_ms_per_batch": {"preprocess_call": round(t_pre / args.steps * 1e3, 2),
-                                            "postprocess_call": round(t_post / args.steps * 1e3, 2)},
+                                            "postprocess_call": round(t_post / args.steps * 1e3, 2),
+                                            # preprocess_call split up: `stage_wait` is the host waiting for the H2D copy it
+                                            # queued four batches ago (the GPU is the bottleneck and the host runs ahead of
+                                            # it until its staging ring is full: back-pressure, not work)
+                                            "preprocess_phases": {k: round(v / args.steps * 1e3, 2) for k, v in pre.timing.items()}},
                       "page": "310-395 x 1580-1620 uint8 -> 128x512", "sample_latex_chars": len(sample)}))
 
 
