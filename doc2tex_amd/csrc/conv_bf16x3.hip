@@ -514,8 +514,31 @@ __global__ void merge_act_kernel(const uint16_t* __restrict__ planes, float* __r
     x[i] = bf16_bits_to_f32(planes[o]) + bf16_bits_to_f32(planes[o + 32]);
   }
 }
+// the same, eight channels per thread: two 16-byte loads, one 16-byte store into each half of the record (C % 32 == 0)
+__global__ void split_act8_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint16_t hi[8], lo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split_f32(v[k], hi[k], lo[k]);
+    // element e = 8 i of the row-major [rows][C] tensor lies in record e / 32 at position e % 32 (C % 32 == 0)
+    const size_t rec = i >> 2, pos = (i & 3) * 8;
+    uint16_t* dst = planes + rec * 64 + pos;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0] | (uint32_t)hi[1] << 16, hi[2] | (uint32_t)hi[3] << 16,
+                                                hi[4] | (uint32_t)hi[5] << 16, hi[6] | (uint32_t)hi[7] << 16);
+    *reinterpret_cast<uint4*>(dst + 32) = make_uint4(lo[0] | (uint32_t)lo[1] << 16, lo[2] | (uint32_t)lo[3] << 16,
+                                                     lo[4] | (uint32_t)lo[5] << 16, lo[6] | (uint32_t)lo[7] << 16);
+  }
+}
 hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s) {
   const size_t n = rows * C;
+  if (C % 32 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const size_t n8 = n / 8;
+    hipLaunchKernelGGL(split_act8_kernel, dim3((unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192)), dim3(256), 0, s, x,
+                       planes, n8);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
                      s, x, planes, rows, C);
   return hipGetLastError();

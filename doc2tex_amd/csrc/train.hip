@@ -176,6 +176,22 @@ struct Tr {  // builder / runner bound to one context and stream
     TCHK(d2t_internal_conv_timed(c, p, s));
     return D2T_OK;
   }
+  // split-bf16 mode: hand the convolution its input as hi / lo records (a copy in the step's arena), which moves it from
+  // the kernel that splits fp32 activations inside its K loop to the LDS-DMA kernels (conv_bf16x3p.hip: ~25 % faster; the
+  // copy costs one pass over the input).  Same split, same three-MFMA products.
+  int split_input(ConvP* p, const float* x, long long rows, int C) {
+    static const bool off = getenv("D2T_TRAIN_SPLIT_INPUT") && atoi(getenv("D2T_TRAIN_SPLIT_INPUT")) == 0;
+    if (off || !c->conv_bf16x3 || !c->zero_page || C % 32 != 0 || rows * C * 2 > 0x7fffffffLL || p->KH * p->KW > 16) return D2T_OK;
+    float* planes;
+    RC(alloc(&planes, (size_t)rows * C));
+    TCHK(launch_split_act(x, reinterpret_cast<uint16_t*>(planes), (size_t)rows, C, s));
+    p->in = nullptr;
+    p->in_hi = reinterpret_cast<const uint16_t*>(planes);
+    p->zero16 = c->zero_page;
+    p->pipelined = c->conv_pipelined;
+    p->split_tail = 1;
+    return D2T_OK;
+  }
   // dst[c] (+)= column sums of a[R][C]
   int colsum(const float* a, long long R, int C, float* dst) {
     const int chunks = colreduce_chunks(R);
@@ -260,6 +276,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.in = x.p; p.w = wp; p.bias = bias; p.out = n.z;
     p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
+    RC(split_input(&p, x.p, x.rows, x.cols));
     TCHK(d2t_internal_conv_timed(c, p, s));
     if (bnkey.empty()) {
       RC(new_tensor(P, Cout, out, x.B, OH, OW, n.z));
@@ -867,6 +884,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.B = x.B; p.H = DH; p.W = DW; p.Cin = Cout; p.OH = x.H; p.OW = x.W; p.Cout = Cin;
     p.KH = n.KH; p.KW = n.KW; p.SH = p.SW = 1; p.PH = n.KH - 1 - n.PH; p.PW = n.KW - 1 - n.PW;
     p.M = (int)x.rows; p.K = Kd; p.act = ACT_NONE;
+    RC(split_input(&p, src, (long long)x.B * DH * DW, Cout));
     TCHK(d2t_internal_conv_timed(c, p, s));
     return add_grad(n.in, dx);
   }
@@ -1130,6 +1148,11 @@ struct OpCtx {
   OpCtx(int bf16x3, hipStream_t s) : tr{&c, &st, s} {
     c.conv_bf16x3 = bf16x3 != 0;
     hipGetDevice(&c.device);
+    if (hipMalloc(&c.zero_page, 256) == hipSuccess) hipMemset(c.zero_page, 0, 256);  // out-of-image taps of the LDS-DMA kernels
+  }
+  ~OpCtx() {
+    if (c.zero_page) hipFree(c.zero_page);
+    c.zero_page = nullptr;
   }
   void put(const char* key, const float* p, std::vector<int64_t> shape) {
     RawW r;
