@@ -345,4 +345,8 @@ hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, in
 hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int B, int H, int W, int Cout, int chunk,
                              int nchunks, hipStream_t s);
 
+// One launch for many device-to-device copies: block b copies chunk b = {src, dst, n floats} of the table.
+struct CopyChunk { const float* src; float* dst; long long n; };
+hipError_t launch_multi_copy(const CopyChunk* table, int chunks, hipStream_t s);
+
 }  // namespace d2t

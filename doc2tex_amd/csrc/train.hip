@@ -83,6 +83,10 @@ struct Node {
 }  // namespace
 
 struct d2t_train_state {
+  // d2t_train_gather: copy-table staging (pinned + device mirror), four sets in rotation so that the host waits for an
+  // upload queued four calls ago, never for the work just ahead of it
+  struct GatherStage { void *h = nullptr, *d = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; } gather[4];
+  unsigned gather_calls = 0;
   Arena tape;
   std::vector<TT> t;
   std::vector<Node> nodes;
@@ -105,6 +109,11 @@ struct d2t_train_state {
     tape.release();
     for (auto& kv : grads) hipFree(kv.second);
     for (auto& kv : ready) hipEventDestroy(kv.second);
+    for (auto& g : gather) {
+      if (g.h) hipHostFree(g.h);
+      if (g.d) hipFree(g.d);
+      if (g.ev) hipEventDestroy(g.ev);
+    }
     if (part) hipFree(part);
     if (scratch) hipFree(scratch);
   }
@@ -1039,6 +1048,55 @@ int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_
   // ordered after the backward kernels that produce this gradient, whichever stream `stream` is
   HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, st->ready[name], 0));
   HIPCHK(c, hipMemcpyAsync(dst, it->second, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return D2T_OK;
+}
+
+int d2t_train_gather(d2t_ctx* c, int32_t source, int32_t n, const char* const* names, const int64_t* offsets,
+                     const int64_t* numels, float* flat, d2t_stream stream) {
+  DevGuard dg_(c);
+  if (!c || n < 0 || (n && (!names || !offsets || !numels || !flat)) || (source != 0 && source != 1)) return fail(c, D2T_EINVAL, "bad argument");
+  d2t_train_state* st = c->train;
+  if (source == 0 && !st) return fail(c, D2T_ESTATE, "no training step has run");
+  if (!st) st = c->train = new d2t_train_state();
+  if (int rc = check_dev_ptr(c, flat, "flat")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr long long CHUNK = 1 << 16;  // floats per block
+  std::vector<CopyChunk> table;
+  for (int i = 0; i < n; ++i) {
+    const RawW* r = find(c, names[i]);
+    if (!r || (int64_t)r->numel != numels[i]) return fail(c, D2T_EINVAL, "tensor '%s': unknown or size mismatch", names[i]);
+    const float* src = r->p;
+    if (source == 0) {
+      auto it = st->grads.find(names[i]);
+      if (it == st->grads.end()) return fail(c, D2T_ESTATE, "no gradient for '%s'", names[i]);
+      src = it->second;
+      HIPCHK(c, hipStreamWaitEvent(s, st->ready[names[i]], 0));  // (the same stream as the backward: no-ops)
+    }
+    for (long long o = 0; o < numels[i]; o += CHUNK)
+      table.push_back(CopyChunk{src + o, flat + offsets[i] + o, std::min<long long>(CHUNK, numels[i] - o)});
+  }
+  if (table.empty()) return D2T_OK;
+  // the table travels through a pinned block
+  const size_t bytes = table.size() * sizeof(CopyChunk);
+  d2t_train_state::GatherStage& g = st->gather[st->gather_calls++ & 3];
+  if (g.pending) {
+    HIPCHK(c, hipEventSynchronize(g.ev));
+    g.pending = false;
+  }
+  if (bytes > g.cap) {
+    if (g.h) { HIPCHK(c, hipHostFree(g.h)); HIPCHK(c, hipFree(g.d)); }
+    g.h = g.d = nullptr;
+    g.cap = 0;
+    HIPCHK(c, hipHostMalloc(&g.h, bytes * 2, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(&g.d, bytes * 2));
+    g.cap = bytes * 2;
+    if (!g.ev) HIPCHK(c, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+  }
+  memcpy(g.h, table.data(), bytes);
+  HIPCHK(c, hipMemcpyAsync(g.d, g.h, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(g.ev, s));
+  g.pending = true;
+  HIPCHK(c, launch_multi_copy(reinterpret_cast<const CopyChunk*>(g.d), (int)table.size(), s));
   return D2T_OK;
 }
 

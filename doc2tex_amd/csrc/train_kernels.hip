@@ -734,14 +734,14 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, con
 // probs [B][heads][Lq][Lk] is written for the backward pass.
 // ---------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_train_fwd_kernel(const AttnTrainP p) {
+__global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;                          // [Lk][HD+1]
   float* Vs = Ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD]
-  float* Ps = Vs + (size_t)p.Lk * HD;        // [4 waves][Lk]
+  float* Ps = Vs + (size_t)p.Lk * HD;        // [waves][Lk]
   const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < p.Lk * HD; i += 256) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
+  for (int i = tid; i < p.Lk * HD; i += NT) {
     const int j = i / HD, c = i % HD;
     Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
     Vs[j * HD + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const AttnTrainP p)
   __syncthreads();
   const float scale = rsqrtf((float)HD);
   float* P = Ps + (size_t)wave * p.Lk;
-  for (int i = wave; i < p.Lq; i += 4) {
+  for (int i = wave; i < p.Lq; i += NW) {
     const float* qp = p.q + ((size_t)b * p.Lq + i) * p.ldq + hh * HD;
     float q[HD];
 #pragma unroll
@@ -797,15 +797,25 @@ static hipError_t attn_lds(const void* fn, size_t lds) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+// One block per (batch, head) leaves a CU with a single block; sixteen waves in it (four per SIMD) hide the latency of the
+// per-query loops that four could not (forward 382 -> ~130 us, backward 656 -> ~250 us at B = 32, 261 tokens).  Fewer when
+// the per-wave LDS rows do not fit.
+static int attn_waves(size_t base_bytes, int Lk) {
+  for (int nw = 16; nw > 4; nw -= 4)
+    if (base_bytes + (size_t)nw * Lk * 4 <= 160 * 1024) return nw;
+  return 4;
+}
 hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s) {
-  const size_t lds = ((size_t)p.Lk * (p.hd + 1) + (size_t)p.Lk * p.hd + 4 * (size_t)p.Lk) * 4;
+  const size_t base = ((size_t)p.Lk * (p.hd + 1) + (size_t)p.Lk * p.hd) * 4;
+  const int nw = attn_waves(base, p.Lk);
+  const size_t lds = base + (size_t)nw * p.Lk * 4;
   hipError_t e;
   if (p.hd == 32) {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<32>), lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_train_fwd_kernel<32>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(attn_train_fwd_kernel<32>, dim3(p.B * p.heads), dim3(nw * 64), lds, s, p);
   } else if (p.hd == 64) {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<64>), lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_train_fwd_kernel<64>, dim3(p.B * p.heads), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(attn_train_fwd_kernel<64>, dim3(p.B * p.heads), dim3(nw * 64), lds, s, p);
   } else {
     return hipErrorInvalidValue;
   }
@@ -889,21 +899,23 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
 // reductions (dV over queries with P, dK over queries with dS) run with lane = key (consecutive lanes read consecutive
 // probabilities of one query row) and wave = group of HD/4 channels.  Needs (2*Lk*(HD+1) + 2*Lq*HD + 4*Lk) floats of LDS.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrainP p) {
+__global__ __launch_bounds__(1024) void attn_train_bwd_fast_kernel(const AttnTrainP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;                             // [Lk][HD+1]
   float* Vs = Ks + (size_t)p.Lk * (HD + 1);   // [Lk][HD+1]
   float* dOs = Vs + (size_t)p.Lk * (HD + 1);  // [Lq][HD]
   float* Qs = dOs + (size_t)p.Lq * HD;        // [Lq][HD]
-  float* Ds = Qs + (size_t)p.Lq * HD;         // [4 waves][Lk]
+  float* Ds = Qs + (size_t)p.Lq * HD;         // [waves][Lk]
   const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < p.Lk * HD; i += 256) {
+  // a multiple of four waves: wave & 3 = channel group of the column reductions, wave >> 2 = which 64-key blocks it takes
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
+  const int cgrp = wave & 3, kgrp = wave >> 2, nkg = NW >> 2;
+  for (int i = tid; i < p.Lk * HD; i += NT) {
     const int j = i / HD, c = i % HD;
     Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
     Vs[j * (HD + 1) + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
   }
-  for (int i = tid; i < p.Lq * HD; i += 256) {
+  for (int i = tid; i < p.Lq * HD; i += NT) {
     const int r = i / HD, c = i % HD;
     dOs[i] = p.o[((size_t)b * p.Lq + r) * p.ldo + hh * HD + c];
     Qs[i] = p.q[((size_t)b * p.Lq + r) * p.ldq + hh * HD + c];
@@ -914,7 +926,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
   // column reduction out[j][c] = alpha * sum_i M[i][j] * R[i][c]
   const uint8_t* dmask = p.dropmask ? p.dropmask + ((size_t)b * p.heads + hh) * p.Lq * p.Lk : nullptr;
   auto colred = [&](const float* R, float* out, int ld, float alpha, const uint8_t* dm) {
-    for (int j0 = 0; j0 < p.Lk; j0 += 64) {
+    for (int j0 = kgrp * 64; j0 < p.Lk; j0 += 64 * nkg) {
       const int j = j0 + lane;
       float acc[CG];
 #pragma unroll
@@ -923,11 +935,11 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
         for (int i = 0; i < p.Lq; ++i) {
           float m = probs[(size_t)i * p.Lk + j];
           if (dm) m *= dm[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
-          const float* r = R + i * HD + wave * CG;
+          const float* r = R + i * HD + cgrp * CG;
 #pragma unroll
           for (int c = 0; c < CG; ++c) acc[c] = fmaf(m, r[c], acc[c]);
         }
-        float* o = out + ((size_t)b * p.Lk + j) * ld + hh * HD + wave * CG;
+        float* o = out + ((size_t)b * p.Lk + j) * ld + hh * HD + cgrp * CG;
 #pragma unroll
         for (int c = 0; c < CG; ++c) o[c] = acc[c] * alpha;
       }
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
   const float scale = rsqrtf((float)HD);
   constexpr int PH = 64 / HD;
   const int c = lane % HD, ph = lane / HD;
-  for (int i = wave; i < p.Lq; i += 4) {  // phase 2: dS (in place) and dQ, one wave per query row
+  for (int i = wave; i < p.Lq; i += NW) {  // phase 2: dS (in place) and dQ, one wave per query row
     const float* d_o = dOs + i * HD;
     float* prow = probs + (size_t)i * p.Lk;
     float dsum = 0.f;
@@ -967,15 +979,17 @@ __global__ __launch_bounds__(256) void attn_train_bwd_fast_kernel(const AttnTrai
 
 hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s) {
   const size_t lds = ((size_t)2 * p.Lk * (p.hd + 1) + 4 * (size_t)p.Lk) * 4;
-  const size_t lds_fast = lds + (size_t)2 * p.Lq * p.hd * 4;
+  const size_t base_fast = ((size_t)2 * p.Lk * (p.hd + 1) + (size_t)2 * p.Lq * p.hd) * 4;
+  const int nw = attn_waves(base_fast, p.Lk);
+  const size_t lds_fast = base_fast + (size_t)nw * p.Lk * 4;
   hipError_t e;
   if (lds_fast <= 160 * 1024 && (p.hd == 32 || p.hd == 64)) {
     if (p.hd == 32) {
       if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_fast_kernel<32>), lds_fast)) != hipSuccess) return e;
-      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<32>, dim3(p.B * p.heads), dim3(256), lds_fast, s, p);
+      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<32>, dim3(p.B * p.heads), dim3(nw * 64), lds_fast, s, p);
     } else {
       if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_fast_kernel<64>), lds_fast)) != hipSuccess) return e;
-      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<64>, dim3(p.B * p.heads), dim3(256), lds_fast, s, p);
+      hipLaunchKernelGGL(attn_train_bwd_fast_kernel<64>, dim3(p.B * p.heads), dim3(nw * 64), lds_fast, s, p);
     }
     return hipGetLastError();
   }
@@ -1229,6 +1243,27 @@ hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int
                              int nchunks, hipStream_t s) {
   if (Cout != 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, Cout, chunk);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// many small device-to-device copies in one launch (d2t_train_gather)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyChunk* __restrict__ table) {
+  const CopyChunk c = table[blockIdx.x];
+  const bool vec = ((reinterpret_cast<uintptr_t>(c.src) | reinterpret_cast<uintptr_t>(c.dst)) & 15) == 0;
+  long long i = threadIdx.x;
+  if (vec) {
+    const long long n4 = c.n >> 2;
+    for (; i < n4; i += 256) reinterpret_cast<float4*>(c.dst)[i] = reinterpret_cast<const float4*>(c.src)[i];
+    for (i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+  } else {
+    for (; i < c.n; i += 256) c.dst[i] = c.src[i];
+  }
+}
+hipError_t launch_multi_copy(const CopyChunk* table, int chunks, hipStream_t s) {
+  if (chunks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(chunks), dim3(256), 0, s, table);
   return hipGetLastError();
 }
 

@@ -215,6 +215,25 @@ class Engine:
                     f"train_grad({name})")
         return g
 
+    def train_gather(self, names, likes, source="grad"):
+        """All gradients (source "grad") or the engine's copies of loaded tensors (source "weight": the BatchNorm running
+        statistics after a training forward) in ONE kernel: returns fp32 tensors shaped like `likes`, views of one flat
+        buffer (as DistributedDataParallel's gradient_as_bucket_view hands them out)."""
+        n = len(names)
+        numels = [int(t.numel()) for t in likes]
+        offs, total = [], 0
+        for m in numels:  # 16-byte aligned starts: the copy kernel moves float4s
+            offs.append(total)
+            total += (m + 3) & ~3
+        if n == 0:
+            return []
+        flat = torch.empty(max(total, 1), dtype=torch.float32, device=likes[0].device)
+        arr = (C.c_char_p * n)(*[s.encode() for s in names])
+        self._check(self.lib.d2t_train_gather(self.ctx, 0 if source == "grad" else 1, n, arr, (C.c_int64 * n)(*offs),
+                                              (C.c_int64 * n)(*numels), _lib.ptr(flat), _lib.stream_of(flat)),
+                    "train_gather")
+        return [flat[o:o + m].view(t.shape) for o, m, t in zip(offs, numels, likes)]
+
     def train_grad_into(self, name, dst):
         """Copy the gradient of `name` into the flat fp32 view `dst` on the current stream (ordered after the
         kernels that produce it, whichever stream that is)."""

@@ -31,10 +31,12 @@ class _TrainStep(torch.autograd.Function):
         logits = eng.train_forward(image, text)
         # BatchNorm side effects of module.train(): running statistics and the batch counter
         with torch.no_grad():
+            stats = [(name, buf) for name, buf in model.named_buffers() if name.endswith(("running_mean", "running_var"))]
+            if stats:  # one gather kernel + one multi-tensor copy instead of a device copy per buffer
+                got = eng.train_gather([n for n, _ in stats], [b for _, b in stats], source="weight")
+                torch._foreach_copy_([b for _, b in stats], got)
             for name, buf in model.named_buffers():
-                if name.endswith(("running_mean", "running_var")):
-                    eng.read_weight(name, buf)
-                elif name.endswith("num_batches_tracked"):
+                if name.endswith("num_batches_tracked"):
                     buf += 1
         eng._sig = None  # the buffers above changed: re-upload before the next eval forward
         ctx.model, ctx.names, ctx.params = model, names, params
@@ -46,7 +48,7 @@ class _TrainStep(torch.autograd.Function):
         eng.train_backward(dlogits)  # enqueues the whole backward on the current stream and returns
         sync = getattr(ctx.model, "grad_sync", None)
         if sync is None:
-            grads = tuple(eng.train_grad(n, p) for n, p in zip(ctx.names, ctx.params))
+            grads = tuple(eng.train_gather(ctx.names, ctx.params))  # views of one flat buffer, filled by one kernel
         else:  # data-parallel: bucketed all-reduce-mean overlapped with the rest of the backward (dist.GradSync)
             grads = tuple(sync.collect(eng.train_grad_into, ctx.names, ctx.params))
         return (None, None, None, None) + grads

@@ -272,6 +272,12 @@ int d2t_train_forward(d2t_ctx* ctx, const float* image, int32_t B, int32_t H, in
                       float* logits, d2t_stream stream);
 int d2t_train_backward(d2t_ctx* ctx, const float* dlogits, d2t_stream stream);
 int d2t_train_grad(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
+/* All of them at once (the single-process step: what loss.backward() leaves in .grad): gradient `names[i]` is written to
+ * flat[offsets[i] .. offsets[i] + numels[i]) by ONE kernel ordered after the whole backward, instead of one device copy per
+ * parameter (378 of them for the headline model: ~3 ms of 4-us copies).  source = 0: gradients; 1: the engine's current
+ * copy of loaded tensors (the BatchNorm running statistics after a training forward, as d2t_read_weight). */
+int d2t_train_gather(d2t_ctx* ctx, int32_t source, int32_t n, const char* const* names, const int64_t* offsets,
+                     const int64_t* numels, float* flat, d2t_stream stream);
 /* copy the engine's current copy of a loaded tensor (e.g. BatchNorm running statistics after a training forward) */
 int d2t_read_weight(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
 /* Dropout of nn.TransformerDecoderLayer(dropout=p) in the training step: on the attention probabilities of both
