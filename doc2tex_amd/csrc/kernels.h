@@ -295,10 +295,10 @@ hipError_t launch_colreduce_final(const float* part, int chunks, int C, float* o
 hipError_t launch_bn_finalize(const float* part, int chunks, int C, long long R, float eps, float momentum, float* mean,
                               float* rstd, float* run_mean, float* run_var, hipStream_t s);
 hipError_t launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* g, const float* b,
-                           const float* res, float* y, long long R, int C, int relu, hipStream_t s);
+                           const float* res, float* y, long long R, int C, int relu, hipStream_t s, uint16_t* planes = nullptr);
 hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                                const float* gamma, const float* s0, const float* s1, float* dz, float* gout, long long R,
-                               int C, hipStream_t s);
+                               int C, hipStream_t s, uint16_t* planes = nullptr);
 enum { EW_COPY = 0, EW_ADD = 1, EW_RELU_BWD = 2, EW_GELU = 3, EW_GELU_BWD = 4 };
 hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int op, hipStream_t s);
 hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,

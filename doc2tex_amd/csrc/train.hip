@@ -49,6 +49,7 @@ struct TT {  // tensor on the tape
   int cols = 0;
   int B = 0, H = 0, W = 0;  // NHWC maps: rows = B*H*W
   float* grad = nullptr;
+  const uint16_t* planes = nullptr;  // split-bf16 records of p, when the producing kernel wrote them alongside (bf16x3 mode)
 };
 
 enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD, N_LSTM };
@@ -188,14 +189,29 @@ struct Tr {  // builder / runner bound to one context and stream
   // split-bf16 mode: hand the convolution its input as hi / lo records (a copy in the step's arena), which moves it from
   // the kernel that splits fp32 activations inside its K loop to the LDS-DMA kernels (conv_bf16x3p.hip: ~25 % faster; the
   // copy costs one pass over the input).  Same split, same three-MFMA products.
-  int split_input(ConvP* p, const float* x, long long rows, int C) {
+  bool want_planes(long long rows, int C) const {
     static const bool off = getenv("D2T_TRAIN_SPLIT_INPUT") && atoi(getenv("D2T_TRAIN_SPLIT_INPUT")) == 0;
-    if (off || !c->conv_bf16x3 || !c->zero_page || C % 32 != 0 || rows * C * 2 > 0x7fffffffLL || p->KH * p->KW > 16) return D2T_OK;
-    float* planes;
-    RC(alloc(&planes, (size_t)rows * C));
-    TCHK(launch_split_act(x, reinterpret_cast<uint16_t*>(planes), (size_t)rows, C, s));
+    return !off && c->conv_bf16x3 && c->zero_page && C % 32 == 0 && rows * C * 2 <= 0x7fffffffLL;
+  }
+  // records written by the producer of a tensor (BatchNorm apply kernels), or nullptr
+  int new_planes(long long rows, int C, uint16_t** out) {
+    *out = nullptr;
+    if (!want_planes(rows, C)) return D2T_OK;
+    float* pl;
+    RC(alloc(&pl, (size_t)rows * C));
+    *out = reinterpret_cast<uint16_t*>(pl);
+    return D2T_OK;
+  }
+  int split_input(ConvP* p, const float* x, long long rows, int C, const uint16_t* ready = nullptr) {
+    if (!want_planes(rows, C) || p->KH * p->KW > 16) return D2T_OK;
+    if (!ready) {
+      float* planes;
+      RC(alloc(&planes, (size_t)rows * C));
+      TCHK(launch_split_act(x, reinterpret_cast<uint16_t*>(planes), (size_t)rows, C, s));
+      ready = reinterpret_cast<const uint16_t*>(planes);
+    }
     p->in = nullptr;
-    p->in_hi = reinterpret_cast<const uint16_t*>(planes);
+    p->in_hi = ready;
     p->zero16 = c->zero_page;
     p->pipelined = c->conv_pipelined;
     p->split_tail = 1;
@@ -285,7 +301,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.in = x.p; p.w = wp; p.bias = bias; p.out = n.z;
     p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
-    RC(split_input(&p, x.p, x.rows, x.cols));
+    RC(split_input(&p, x.p, x.rows, x.cols, x.planes));
     TCHK(d2t_internal_conv_timed(c, p, s));
     if (bnkey.empty()) {
       RC(new_tensor(P, Cout, out, x.B, OH, OW, n.z));
@@ -295,7 +311,10 @@ struct Tr {  // builder / runner bound to one context and stream
       const float *g, *b;
       RC(raw(bnkey + ".weight", &g, Cout));
       RC(raw(bnkey + ".bias", &b, Cout));
-      TCHK(launch_bn_apply(n.z, n.mean, n.rstd, g, b, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, P, Cout, relu, s));
+      uint16_t* pl;  // the next convolution's operand records, written by the same pass
+      RC(new_planes(P, Cout, &pl));
+      TCHK(launch_bn_apply(n.z, n.mean, n.rstd, g, b, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, P, Cout, relu, s, pl));
+      st->t[*out].planes = pl;
     }
     n.out = *out;
     st->nodes.push_back(n);
@@ -826,6 +845,7 @@ struct Tr {  // builder / runner bound to one context and stream
     const long long P = y.rows;
     const int Cout = n.N;
     const float* dz = y.grad;
+    uint16_t* dz_planes = nullptr;
     float *dW;
     RC(grad_buf(n.wkey + ".weight", &dW));
     if (!n.bnkey.empty()) {
@@ -844,7 +864,8 @@ struct Tr {  // builder / runner bound to one context and stream
       s0 = dbet; s1 = dgam;
       RC(alloc(&dzb, (size_t)P * Cout));
       if (n.in2 >= 0) RC(alloc(&gres, (size_t)P * Cout));
-      TCHK(launch_bn_bwd_apply(y.grad, n.relu ? y.p : nullptr, n.z, n.mean, n.rstd, gamma, s0, s1, dzb, gres, P, Cout, s));
+      if (!n.stem) RC(new_planes(P, Cout, &dz_planes));  // the data-gradient convolution's operand records
+      TCHK(launch_bn_bwd_apply(y.grad, n.relu ? y.p : nullptr, n.z, n.mean, n.rstd, gamma, s0, s1, dzb, gres, P, Cout, s, dz_planes));
       if (n.in2 >= 0) RC(add_grad(n.in2, gres));
       dz = dzb;
     } else {
@@ -893,7 +914,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.B = x.B; p.H = DH; p.W = DW; p.Cin = Cout; p.OH = x.H; p.OW = x.W; p.Cout = Cin;
     p.KH = n.KH; p.KW = n.KW; p.SH = p.SW = 1; p.PH = n.KH - 1 - n.PH; p.PW = n.KW - 1 - n.PW;
     p.M = (int)x.rows; p.K = Kd; p.act = ACT_NONE;
-    RC(split_input(&p, src, (long long)x.B * DH * DW, Cout));
+    RC(split_input(&p, src, (long long)x.B * DH * DW, Cout, src == dz ? dz_planes : nullptr));
     TCHK(d2t_internal_conv_timed(c, p, s));
     return add_grad(n.in, dx);
   }

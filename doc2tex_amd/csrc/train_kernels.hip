@@ -431,9 +431,20 @@ hipError_t launch_bn_finalize(const float* part, int chunks, int C, long long R,
 // ---------------------------------------------------------------------------
 // BatchNorm apply (train forward) and backward apply, float4 over [R][C]
 // ---------------------------------------------------------------------------
+// the four values of flat float4 index i4 of a row-major [rows][C] tensor (C % 32 == 0) as split-bf16 record entries
+// (conv_common.h plane_idx): what the LDS-DMA convolution kernels read
+__device__ __forceinline__ void store_split4(uint16_t* planes, size_t i4, const float (&v)[4]) {
+  uint16_t hi[4], lo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) split_f32(v[k], hi[k], lo[k]);
+  const size_t e = i4 * 4;
+  uint16_t* dst = planes + (e >> 5) * 64 + (e & 31);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(hi[0] | (uint32_t)hi[1] << 16, hi[2] | (uint32_t)hi[3] << 16);
+  *reinterpret_cast<uint2*>(dst + 32) = make_uint2(lo[0] | (uint32_t)lo[1] << 16, lo[2] | (uint32_t)lo[3] << 16);
+}
 __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                 const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ res,
-                                float* __restrict__ y, size_t n4, int C, int relu) {
+                                float* __restrict__ y, size_t n4, int C, int relu, uint16_t* __restrict__ planes) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)((i * 4) % C);
     const float4 v = reinterpret_cast<const float4*>(z)[i];
@@ -446,12 +457,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __rest
       o[k] = relu ? fmaxf(t, 0.f) : t;
     }
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (planes) store_split4(planes, i, o);
   }
 }
 hipError_t launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* g, const float* b,
-                           const float* res, float* y, long long R, int C, int relu, hipStream_t s) {
+                           const float* res, float* y, long long R, int C, int relu, hipStream_t s, uint16_t* planes) {
   const size_t n4 = (size_t)R * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, z, mean, rstd, g, b, res, y, n4, C, relu);
+  if (planes && C % 32 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, z, mean, rstd, g, b, res, y, n4, C, relu, planes);
   return hipGetLastError();
 }
 // dz = gamma*rstd * (g - s0/R - xhat * s1/R),  g = dy * (y > 0) (y nullable = no ReLU);  gout (nullable) receives g
@@ -460,7 +473,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ s0,
                                     const float* __restrict__ s1, float invR, float* __restrict__ dz,
-                                    float* __restrict__ gout, size_t n4, int C) {
+                                    float* __restrict__ gout, size_t n4, int C, uint16_t* __restrict__ planes) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)((i * 4) % C);
     const float4 d4 = reinterpret_cast<const float4*>(dy)[i];
@@ -480,15 +493,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
       o[k] = gamma[c + k] * rstd[c + k] * (g[k] - s0[c + k] * invR - xh * s1[c + k] * invR);
     }
     reinterpret_cast<float4*>(dz)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (planes) store_split4(planes, i, o);
     if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
 }
 hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                                const float* gamma, const float* s0, const float* s1, float* dz, float* gout, long long R,
-                               int C, hipStream_t s) {
+                               int C, hipStream_t s, uint16_t* planes) {
   const size_t n4 = (size_t)R * C / 4;
+  if (planes && C % 32 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, dy, y, z, mean, rstd, gamma, s0, s1,
-                     1.f / (float)R, dz, gout, n4, C);
+                     1.f / (float)R, dz, gout, n4, C, planes);
   return hipGetLastError();
 }
 
