@@ -54,45 +54,56 @@ __device__ __forceinline__ void wait_vm() {
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned char* smem, int m0, int n0, int tid) {
   const float* tile = reinterpret_cast<const float*>(smem);
-  constexpr int QPR = BN / 4;  // 4-channel quads per tile row
+  constexpr int OPR = BN / 8;  // 8-channel octets per tile row: 16-byte accesses to each half of a record
+  const uint16_t* __restrict__ res_hi = p.res_hi;
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ bias = p.bias;
+  uint16_t* __restrict__ out_hi = p.out_hi;
+  float* __restrict__ out = p.out;
 #pragma unroll 2
-  for (int idx = tid; idx < BM * QPR; idx += NT) {
-    const int row = idx / QPR, q = idx % QPR;
-    const int m = m0 + row, n = n0 + q * 4;
+  for (int idx = tid; idx < BM * OPR; idx += NT) {
+    const int row = idx / OPR, o = idx % OPR;
+    const int m = m0 + row, n = n0 + o * 8;
     if (m >= p.M || n >= p.Cout) continue;
-    const int col = (q * 4) ^ (((row >> 2) & 1) << 5);
-    const float4 a = *reinterpret_cast<const float4*>(tile + row * BN + col);
-    float v[4] = {a.x, a.y, a.z, a.w};
-    if (p.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-      v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+    const int col = (o * 8) ^ (((row >> 2) & 1) << 5);
+    const float4 a0 = *reinterpret_cast<const float4*>(tile + row * BN + col);
+    const float4 a1 = *reinterpret_cast<const float4*>(tile + row * BN + col + 4);
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if (bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+      v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w, v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
     }
     const size_t off = (size_t)m * p.Cout + n;
     const size_t pi = plane_idx((size_t)m, n, p.Cout);
-    if (p.res) {
-      const float4 rr = *reinterpret_cast<const float4*>(p.res + off);
-      v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+    if (res) {
+      const float4 r0 = *reinterpret_cast<const float4*>(res + off), r1 = *reinterpret_cast<const float4*>(res + off + 4);
+      v[0] += r0.x, v[1] += r0.y, v[2] += r0.z, v[3] += r0.w, v[4] += r1.x, v[5] += r1.y, v[6] += r1.z, v[7] += r1.w;
     }
-    if (p.res_hi) {
-      const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
-      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
-      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
-      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
-      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+    if (res_hi) {
+      const uint4 rh = *reinterpret_cast<const uint4*>(res_hi + pi), rl = *reinterpret_cast<const uint4*>(res_hi + pi + 32);
+      const unsigned h[4] = {rh.x, rh.y, rh.z, rh.w}, l[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+        v[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-    if (p.out_hi) {
-      uint16_t hi[4], lo[4];
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+    if (out_hi) {
+      uint16_t hi[8], lo[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
-      uint2 oh, ol;
+      for (int e = 0; e < 8; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint4 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      oh.z = (unsigned)hi[4] | ((unsigned)hi[5] << 16), oh.w = (unsigned)hi[6] | ((unsigned)hi[7] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
-      *reinterpret_cast<uint2*>(p.out_hi + pi) = oh;
-      *reinterpret_cast<uint2*>(p.out_hi + pi + 32) = ol;
+      ol.z = (unsigned)lo[4] | ((unsigned)lo[5] << 16), ol.w = (unsigned)lo[6] | ((unsigned)lo[7] << 16);
+      *reinterpret_cast<uint4*>(out_hi + pi) = oh;
+      *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;
     } else {
-      *reinterpret_cast<float4*>(p.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
   }
 }
