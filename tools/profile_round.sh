@@ -8,7 +8,12 @@ tag=$1; shift
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 $R/bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-secondary "$@" > $out/trace.log 2>&1
+# The driver's own command (20 timed steps after 5 warm-up steps).  Most forward passes of the process are the graph-priming
+# ones before the warm-up, during which no decode loop is in flight and the convolution would hand its last round of tiles
+# to the small kernel; D2T_CONV_TAIL=0 pins the serving form of the kernel (what the timed region runs) for every launch,
+# so that the per-kernel average is comparable with bench.py's live timing.
+export D2T_CONV_TAIL=0
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary "$@" > $out/trace.log 2>&1
 grep '^{' $out/trace.log > $out/bench_line_profiled.json || true
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o pmc --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $out/pmc_fetch.log 2>&1
