@@ -27,6 +27,9 @@ def manifests():
         return json.load(f)
 
 
+_SYNTH_CACHE = {}  # (key, shape, dtype, seed, end_bias of the two biases that carry it) -> seeded tensor, read-only
+
+
 def oracle_state_dict(cfg_name, manifest, max_seq_len, wseed=1234, end_bias=0.0):
     """Seeded state_dict for the oracle, built from the committed key manifest
     (names + shapes of the reference's state_dict) -- no reference needed."""
@@ -39,7 +42,11 @@ def oracle_state_dict(cfg_name, manifest, max_seq_len, wseed=1234, end_bias=0.0)
         if k.endswith("image_positional_encoder.pe"):
             continue  # 8 GB table in the reference; the oracle builds the crop it needs
         dt = torch.long if k.endswith("num_batches_tracked") else torch.float32
-        t = synth.synth_tensor(k, shape, dt, seed=wseed, end_bias=end_bias)
+        eb = end_bias if k.endswith(("Prediction.proj.bias", "attention_cell.generator.bias")) else 0.0
+        key = (k, tuple(shape), dt, wseed, eb)
+        if key not in _SYNTH_CACHE:  # shared with engine_model: the same seeded tensor for the oracle and the engine
+            _SYNTH_CACHE[key] = synth.synth_tensor(k, shape, dt, seed=wseed, end_bias=eb)
+        t = _SYNTH_CACHE[key]
         if t is None:
             if k.endswith("pos_embed"):
                 gh, gw = R.resnet_out_hw(*cfg["max_dimension"])
@@ -51,6 +58,23 @@ def oracle_state_dict(cfg_name, manifest, max_seq_len, wseed=1234, end_bias=0.0)
     return cfg, sd
 
 
+def _cached_synth_state_dict(tmpl, seed, end_bias):
+    """synth.synth_state_dict with the seeded tensors kept across tests (a tensor depends only on its key, shape, dtype, the
+    seed and -- for the two biases that carry it -- end_bias): most of the ~200 engine models the GPU suite builds share a
+    backbone, and generating 50 M Philox normals per model was a third of the suite's wall time.  The cached tensors are
+    only ever copied from (load_state_dict)."""
+    from doc2tex_amd import synth
+    out = {}
+    for k, t in tmpl.items():
+        eb = end_bias if k.endswith(("Prediction.proj.bias", "attention_cell.generator.bias")) else 0.0
+        key = (k, tuple(t.shape), t.dtype, seed, eb)
+        if key not in _SYNTH_CACHE:
+            _SYNTH_CACHE[key] = synth.synth_tensor(k, t.shape, t.dtype, seed=seed, end_bias=eb)
+        v = _SYNTH_CACHE[key]
+        out[k] = t.detach().clone() if v is None else v  # None: a constructed table (depends on more than its shape)
+    return out
+
+
 def engine_model(cfg_name, max_seq_len, wseed=1234, end_bias=0.0, beam_size=None, device="cuda"):
     """doc2tex_amd.Model on the GPU with the same seeded weights."""
     from doc2tex_amd import Model, synth
@@ -60,7 +84,7 @@ def engine_model(cfg_name, max_seq_len, wseed=1234, end_bias=0.0, beam_size=None
     tmpl = {k: v for k, v in m.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     for k in tmpl:
         assert tmpl[k].dtype in (torch.float32, torch.int64), k
-    sd = synth.synth_state_dict(tmpl, seed=wseed, end_bias=end_bias)
+    sd = _cached_synth_state_dict(tmpl, wseed, end_bias)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.endswith("image_positional_encoder.pe") for k in missing), (missing, unexpected)
     m.eval()

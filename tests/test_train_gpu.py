@@ -315,6 +315,11 @@ def test_config_c3_crop_size_matches_reference_fixture(cases, manifests, precisi
         if k.endswith(("running_mean", "running_var")):
             ref = z["bn:" + k]
             assert np.abs(bufs[k].cpu().numpy() - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    if precision == "fp32":
+        # exact-fp32 mode: the reference's own float32 numbers below; the float64 replay (35 s of host autograd at this size)
+        # runs in the default arithmetic only -- the fp32 kernels are replayed on the toy fixtures and tested op by op
+        _check_c3_fixture_samples(m, c, z)
+        return
     with _ReplayDecisions(m._engine) as rep:
         oloss, ologits, ograds, _ = R.train_step_grads(cfg, sd64, img.double(), text)
     assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
@@ -325,11 +330,12 @@ def test_config_c3_crop_size_matches_reference_fixture(cases, manifests, precisi
              sum(g.double().norm() ** 2 for g in ograds.values())) ** 0.5
     print(f"[c3 {precision}, decisions replayed] whole-gradient rel. L2 {float(whole):.2e}; worst tensors {order[:4]}; "
           f"median {np.median(list(l2.values())):.2e}")
-    tol = 2e-4 if precision == "fp32" else 1e-3  # measured: 3.5e-5 / 5.8e-4 (worst tensor), 2.1e-5 / 3.4e-4 (whole gradient)
+    tol = 1e-3  # measured: 5.8e-4 (worst tensor), 3.4e-4 (whole gradient); the exact-fp32 mode measured 3.5e-5 / 2.1e-5
     assert order[0][1] <= tol, order[:4]
     assert float(whole) <= tol
-    if precision != "fp32":
-        return
+
+
+def _check_c3_fixture_samples(m, c, z):
     # the reference's own float32 numbers (no replay possible: decisions within rounding of a tie may differ, measured
     # <= 1.4 % on the BatchNorm vectors of the high-resolution layers, whose sums over 4.2 M pixels cancel to 1/2000)
     params = dict(m.named_parameters())
@@ -429,8 +435,10 @@ class _ReplayDecisions:
             assert self.i == self.n, f"the oracle replayed {self.i} of the engine's {self.n} decisions"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step"])
+# (each case costs ~20 s of float64 autograd on the host; the exact-fp32 mode is replayed on the HybridViT + TFM stack, the
+# default split-bf16 mode on all three, and every backward kernel has its own fp32 / bf16x3 test in test_train_ops_gpu.py)
+@pytest.mark.parametrize("name,precision", [("t2_train_step", "fp32"), ("t2_train_step", "bf16x3"),
+                                            ("t1_train_step", "bf16x3"), ("ts0_train_step", "bf16x3")])
 def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, name, precision):
     """ADVICE r1 / VERDICT r1 item 1d.  The loose end-to-end gradient bounds exist because a ReLU / max-pool decision whose
     operands differ by rounding may fall differently in two correct implementations.  Here the oracle (float64) replays the
