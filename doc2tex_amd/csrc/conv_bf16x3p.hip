@@ -51,7 +51,7 @@ __device__ __forceinline__ void wait_vm() {
 // included: the fp32 [BM][BN] tile is in LDS (32-float column blocks XOR-ed with bit 2 of the row); a thread owns four
 // consecutive channels of one output row.  Same arithmetic per element in the same order as conv_epilogue:
 // v = acc + bias; v += res | (res_hi + res_lo); activation; split.
-template <int BM, int BN, int NT>
+template <int BM, int BN, int NT, int ROWS = BM>  // ROWS < BM: only the first ROWS rows of the tile are real output rows
 __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned char* smem, int m0, int n0, int tid) {
   const float* tile = reinterpret_cast<const float*>(smem);
   constexpr int OPR = BN / 8;  // 8-channel octets per tile row: 16-byte accesses to each half of a record
@@ -61,7 +61,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
   uint16_t* __restrict__ out_hi = p.out_hi;
   float* __restrict__ out = p.out;
 #pragma unroll 2
-  for (int idx = tid; idx < BM * OPR; idx += NT) {
+  for (int idx = tid; idx < ROWS * OPR; idx += NT) {
     const int row = idx / OPR, o = idx % OPR;
     const int m = m0 + row, n = n0 + o * 8;
     if (m >= p.M || n >= p.Cout) continue;
@@ -386,6 +386,259 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions on narrow maps (W <= 131): the INPUT PATCH of a tile stays in LDS for all nine taps.
+//
+// The kernels above fetch, for every K-step (tap, 32 channels), the tile's 256 input records again -- the same pixels under
+// another tap: 9 x 32 KB per channel chunk, two thirds of everything a CU moves through its vector-memory path, which is
+// what the loaders, the decode kernels that share a CU, and the power budget feel.  With output tiles that are linear in
+// the pixel index m = (b*H + oh)*W + ow, tap (dy, dx) of output pixel m is input pixel m + dy*W + dx whenever it is inside
+// the image, so all nine taps of 248 consecutive output pixels read from ONE run of 248 + 2*(W+1) <= 512 input records:
+//   * LDS: two patch buffers of 512 records (64 KB each: the channel chunk in use and the next one, loaded 1/9 per K-step
+//     while the taps of the current chunk run) + two 16 KB stages of weights = 163,840 B, all of a CU's LDS;
+//   * a tile computes 256 rows (the wave grid of the kernels above) of which the first 248 are output rows -- the patch
+//     buffer holds 512 records, and 256 + 2*130 = 516 would not fit; rows 248..255 read whatever follows and are dropped;
+//   * fragment reads: record (row + (W+1) + dy*W + dx) of the patch, chunk XOR-swizzled by the record index as above; a tap
+//     that falls outside the image (or into the neighbouring image row / image) is zeroed per lane from a 9-bit mask;
+//   * LDS-DMA per (tap, 32 channels): 7 KB of patch (amortised) + 16 KB of weights instead of 32 + 16 KB.
+// Same K order (channel chunk, tap, channel) and the same three-MFMA products: bit-identical to the other kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int QROWS = 248, QREC = 512, QPATCH = QREC * 128, QBST = 2 * 128 * PROW;  // real rows, patch records, bytes
+static_assert(2 * QPATCH + 2 * QBST == 160 * 1024, "the patch kernel uses all of a CU's LDS");
+
+template <bool STG>
+__device__ __forceinline__ void conv3x3_patch_body(const ConvP& p, unsigned char* smem) {
+  constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, NL = 4, NT = (NW + NL) * 64, MI = 2, NJ = 2;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + QROWS - 1) / QROWS);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool loader = wave >= NW;
+  const int nchunks = p.Cin / 32, KT = 9 * nchunks;
+  const int W1 = p.W + 1;
+  unsigned char* const bst = smem + 2 * QPATCH;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * QROWS;
+    const int n0 = (tile % nt) * BN;
+
+    if (loader) {
+      const int lw = wave - NW;
+      // patch pieces of this loader: q = lw, lw + 4, ... (16 of 64); a piece = 8 records, lane -> (record, 16-byte position)
+      int a_off[16];
+      unsigned a_ok = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int rec = (lw + 4 * j) * 8 + (lane >> 3);
+        const int g = m0 - W1 + rec;  // input pixel (linear index) held by patch record `rec`
+        const int c = (lane & 7) ^ ((rec >> 1) & 7);
+        a_off[j] = g * p.Cin * 2 + c * 8;
+        if (g >= 0 && g < p.M) a_ok |= 1u << j;  // stride 1, pad 1: as many input as output pixels
+      }
+      const uint16_t* b_hi[2];
+      const uint16_t* b_lo[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (lw * 2 + j) * 16 + (lane >> 2);
+        const int n = n0 + row;
+        const int c = pswz(row, lane & 3);
+        b_hi[j] = n < p.Cout ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
+        b_lo[j] = n < p.Cout ? p.w_lo + (size_t)n * p.K + c * 8 : nullptr;
+      }
+      auto issue_b = [&](int kt) {
+        unsigned char* bh = bst + (kt & 1) * QBST;
+        unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int piece = (lw * 2 + j) * 1024;
+          __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bh + piece), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bl + piece), 16, 0, 0);
+        }
+      };
+      auto issue_a = [&](int chunk, int j) {  // piece j (0..15) of this loader, channel chunk `chunk`
+        unsigned char* dst = smem + (chunk & 1) * QPATCH + (lw + 4 * j) * 1024;
+        const uint16_t* src = ((a_ok >> j) & 1u) ? p.in_hi + (a_off[j] + chunk * 64) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+      };
+      // prologue: the whole patch of chunk 0 and the weights of K-step 0
+#pragma unroll
+      for (int j = 0; j < 16; ++j) issue_a(0, j);
+      issue_b(0);
+      wait_vm<0>();
+      int chunk = 0, tap = 0;
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();  // K-step kt may start: its weights (and at tap 0 its patch) are in LDS; kt-1 is read
+        int na = 0;
+        if (kt + 1 < KT) issue_b(kt + 1);
+        if (chunk + 1 < nchunks && tap < 8) {  // two of this loader's sixteen pieces of the next chunk's patch per K-step
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j == 2 * tap || j == 2 * tap + 1) issue_a(chunk + 1, j);
+          na = 2;
+        }
+        // before the next barrier: the weights of kt+1 have landed (the patch pieces issued after them may still fly);
+        // before the first tap of a chunk: all of its patch
+        if (tap == 7 || na == 0) wait_vm<0>(); else wait_vm<2>();
+        if (++tap == 9) { tap = 0; ++chunk; }
+      }
+      __builtin_amdgcn_s_barrier();  // (compute waves: done with the last stage)
+      __builtin_amdgcn_s_barrier();  // (compute waves: accumulators are in the LDS tile)
+      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT, QROWS>(p, smem, m0, n0, tid);
+      __builtin_amdgcn_s_barrier();  // the tile is staging memory again
+      continue;
+    }
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // this lane's two output rows: which of the nine taps lie inside the image
+    unsigned tmask[MI];
+    int rbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * 64 + i * 32 + r;
+      rbase[i] = row + W1;
+      const int m = m0 + row;
+      tmask[i] = 0;
+      if (row < QROWS && m < p.M) {
+        const int rem = m % (p.H * p.W), oh = rem / p.W, ow = rem - oh * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y = oh + t / 3 - 1, x = ow + t % 3 - 1;
+          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tmask[i] |= 1u << t;
+        }
+      }
+    }
+    int offb[2][NJ];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn * 64 + j * 32 + r;
+        offb[kk][j] = row * PROW + pswz(row, 2 * kk + h) * 16;
+      }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto read_half = [&](const unsigned char* patch, const unsigned char* bh, int shift, int tap, int kk, bf16x8 (&fah)[MI],
+                         bf16x8 (&fal)[MI], bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
+      const unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rec = rbase[i] + shift;
+        const int off = rec * 128 + (((2 * kk + h) ^ ((rec >> 1) & 7)) << 4);
+        const unsigned keep = ((tmask[i] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
+        u4 a = *reinterpret_cast<const u4*>(patch + off), b = *reinterpret_cast<const u4*>(patch + (off ^ 64));
+        a &= keep;
+        b &= keep;
+        fah[i] = __builtin_bit_cast(bf16x8, a);
+        fal[i] = __builtin_bit_cast(bf16x8, b);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[kk][j]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[kk][j]);
+      }
+    };
+    auto mma_half = [&](const bf16x8 (&fah)[MI], const bf16x8 (&fal)[MI], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const bool late = STG && wave >= NW / 2;
+    int chunk = 0, tap = 0;
+    auto step_refs = [&](const unsigned char*& patch, const unsigned char*& bh, int& shift, int kt) {
+      patch = smem + (chunk & 1) * QPATCH;
+      bh = bst + (kt & 1) * QBST;
+      shift = (tap / 3 - 1) * p.W + (tap % 3 - 1);
+    };
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *patch, *bh;
+        int shift;
+        step_refs(patch, bh, shift, kt);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+          read_half(patch, bh, shift, tap, kk, fah, fal, fbh, fbl);
+          mma_half(fah, fal, fbh, fbl);
+        }
+        if (++tap == 9) { tap = 0; ++chunk; }
+      }
+    } else {
+      bf16x8 gah[MI], gal[MI], gbh[NJ], gbl[NJ];  // second-half fragments carried across the barrier
+      auto step = [&](bool carried, int kt) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *patch, *bh;
+        int shift;
+        step_refs(patch, bh, shift, kt);
+        if (carried) mma_half(gah, gal, gbh, gbl);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          bf16x8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+          read_half(patch, bh, shift, tap, 0, fah, fal, fbh, fbl);
+          mma_half(fah, fal, fbh, fbl);
+        }
+        read_half(patch, bh, shift, tap, 1, gah, gal, gbh, gbl);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the next barrier
+        if (++tap == 9) { tap = 0; ++chunk; }
+      };
+      step(false, 0);
+      for (int kt = 1; kt < KT; ++kt) step(true, kt);
+      mma_half(gah, gal, gbh, gbl);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the patches: they become the epilogue's fp32 tile
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int col = (wn * 64 + j * 32 + r) ^ (((row >> 2) & 1) << 5);
+            tile_f[row * BN + col] = acc[i][j][reg];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      epilogue_rows<BM, BN, NT, QROWS>(p, smem, m0, n0, tid);
+    } else {
+      __builtin_amdgcn_s_barrier();
+      // (the narrow epilogue writes whole wave tiles: mask the eight surplus rows by shrinking M for the last row block)
+      ConvP q = p;
+      if (m0 + QROWS < q.M) q.M = m0 + QROWS;
+      conv_epilogue<MI, NJ>(q, acc, m0 + wm * 64, n0 + wn * 64, r, h);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+__global__ __launch_bounds__(768, 3) void conv_bf16x3q_3x3_patch(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
+  conv3x3_patch_body<true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3q_3x3_patch_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
+  conv3x3_patch_body<true>(p, smem);
+}
+
 // non-template entry points (the host-side stub of a __global__ template using the LDS-DMA builtin is not emitted)
 __global__ __launch_bounds__(768, 3) __attribute__((amdgpu_num_vgpr(112))) void conv_bf16x3p_256x128(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
@@ -454,6 +707,18 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   int tiles = ((p.M + 255) / 256) * nt;
   int grid = cus - (p.reserved_cus > 0 ? p.reserved_cus : 0);
   if (grid < 8) grid = 8;
+  // 3x3 / stride 1 / pad 1 on a narrow map: the kernel that keeps a tile's input patch in LDS for all nine taps
+  // (p.pipelined == 2 or D2T_CONV_PATCH=1; not the default: in the bench's sustained, power-bound state it runs the dominant
+  // layer in 1.67 ms like the kernel below, cold it is 5 % slower -- DESIGN.md 5.1)
+  static const int patch_env = getenv("D2T_CONV_PATCH") ? atoi(getenv("D2T_CONV_PATCH")) : 0;
+  if ((patch_env || p.pipelined == 2) && !abl_probe() && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PH == 1 && p.PW == 1 && p.OH == p.H &&
+      p.OW == p.W && p.W + 1 <= (QREC - QROWS) / 2 && p.Cin % 32 == 0 && p.M >= QROWS) {
+    const int qtiles = ((p.M + QROWS - 1) / QROWS) * nt;
+    if (grid > qtiles) grid = qtiles;
+    if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3q_3x3_patch_k4608, dim3(grid), dim3(768), 0, s, p2);
+    else hipLaunchKernelGGL(conv_bf16x3q_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
+    return hipGetLastError();
+  }
   // Whole rounds only.  The dominant layer has 2064 tiles: eight rounds on 256 CUs and then sixteen tiles that keep 16 CUs
   // busy for a ninth of the kernel's duration while 240 idle.  When the last round is less than `tail_frac` full, the pipelined
   // kernel stops after the whole rounds (cut back to whole rows of tiles) and the remaining rows go to the 128-row kernel,

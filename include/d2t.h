@@ -249,7 +249,9 @@ int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
  * holding three LDS stages, LDS-DMA two K-steps ahead behind counted waits; its persistent grid spans (CUs - reserved)
  * compute units, d2t_set_reserved_cus leaving the rest to the decode streams of the previous batches (pipelined serving;
  * also the place where the tile count of the dominant layer comes out in whole rounds).  kind 0: the 128x128 kernel with
- * two blocks per CU (d2t_set_reserved_blocks applies to that one).  Results are bit-identical between the two. */
+ * two blocks per CU (d2t_set_reserved_blocks applies to that one).  kind 2: as 1, but 3x3 / stride 1 / pad 1 layers on
+ * maps at most 131 pixels wide take the patch-resident kernel (a tile's input records stay in LDS for all nine taps: half
+ * the LDS-DMA; measured equal to kind 1 in sustained runs).  Results are bit-identical between all three. */
 int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
 int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
 /* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has

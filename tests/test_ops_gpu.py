@@ -250,6 +250,8 @@ def test_conv_bf16x3_large_tiles():
     (3, 7, 37, 128, 384, (3, 3), (1, 1), (1, 1), True),      # ragged rows and a partial last row tile
     (1, 16, 129, 256, 512, (2, 2), (2, 1), (0, 1), False),   # conv4_1's strided, asymmetrically padded window
     (1, 5, 9, 64, 128, (2, 2), (2, 2), (0, 0), False),       # 8 output rows
+    (3, 9, 131, 64, 256, (3, 3), (1, 1), (1, 1), True),      # the widest map the patch-resident kernel takes (W = 131)
+    (5, 13, 50, 96, 128, (3, 3), (1, 1), (1, 1), False),     # three channel chunks, tiles that straddle images and rows
 ])
 def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     """The pipelined 256x128 kernel (default) and the 128x128 LDS-DMA kernel stage the same records and run the same three-MFMA
@@ -269,7 +271,7 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
     outs = []
     try:
-        for kind in (0, 1):
+        for kind in (0, 1, 2):  # 128-row two-stage kernel, pipelined 256x128, patch-resident 3x3 (where the layer qualifies)
             assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
             y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
             assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
@@ -280,6 +282,6 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     finally:
         lib.d2t_op_set_conv_kernel(1, 0)
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = _ref_conv(x, w, b, res, st, pd, 1)
     assert float((outs[1].permute(0, 3, 1, 2) - ref).abs().max()) <= 4e-4
