@@ -1,0 +1,19 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from doc2tex_amd import _lib
+lib = _lib.require_device()
+B, H, W, Cin, Cout = 64, 16, 129, 512, 512
+g = torch.Generator().manual_seed(0)
+for name, make in (("random", lambda *s: torch.randn(*s, generator=g)), ("zeros", lambda *s: torch.zeros(*s))):
+    x = make(B, H, W, Cin).cuda(); w = (make(Cout, 3, 3, Cin) * 0.02).cuda(); b = make(Cout).cuda()
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    assert lib.d2t_op_set_conv_kernel(1, 0) == 0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    # the op entry point repacks weights each call; time 40 back-to-back calls and report the mean of the last 20
+    ts = []
+    for i in range(40):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), B, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1, 1, _lib.stream_of(x))
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(name, "mean of last 20 calls (incl. split/repack) ms:", sum(ts[20:]) / 20 * 1e3, flush=True)
