@@ -341,8 +341,6 @@ class Model(nn.Module):
                 if pp.get("attn_type", "coverage") not in ("coverage", "loc_aware") or not pp.get("embed_target", False):
                     raise NotImplementedError("training the LSTM-attention head is implemented for the location-aware cells "
                                               "(attn_type 'coverage' / 'loc_aware') with embed_target: True")
-            if self.engine(finalize=False).cfg.gcb:
-                raise NotImplementedError("training with GlobalContext blocks (gcb: True) is not implemented in the HIP engine")
             logits = train_forward(self, input, text)
             return logits.argmax(dim=2), logits, {}
         contextual_feature, output_shape, feat_pad = self.forward_encoder(input)

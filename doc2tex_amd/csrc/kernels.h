@@ -261,6 +261,24 @@ struct GCParams { const float *wg, *bg, *w1, *b1, *ln_g, *ln_b, *w2, *b2; };
 hipError_t launch_global_context(float* x, const GCParams& w, float* logits, float* ctx, float* y, int B, int HW, int C,
                                  hipStream_t s);
 
+// GlobalContext in the training step (the forward uses the two kernels of the inference path, out of place):
+hipError_t launch_gc_logits(const float* x, const float* wg, const float* bg, float* logits, long long rows, int C, hipStream_t s);
+hipError_t launch_gc_pool(const float* x, const float* logits, float* ctx, int B, int HW, int C, hipStream_t s);
+// out[b][c] = sum_p (wts ? wts[b][p] : 1) * x[b][p][c]: per-image (weighted) column sums; part >= B * GC_CHUNKS * C floats
+constexpr int GC_CHUNKS = 16;
+hipError_t launch_gc_wpool(const float* x, const float* wts, float* part, float* out, int B, int HW, int C, hipStream_t s);
+// out[b][p][c] = x[b][p][c] + y[b][c]
+hipError_t launch_gc_bcast_add(const float* x, const float* y, float* out, int B, int HW, int C, hipStream_t s);
+// backward of ctx[b] = sum_p softmax_p(logits[b]) x[b][p]: a[b][p] (the softmax), da[b][p] = dctx[b] . (x[b][p] - ctx[b]), then
+// dl = a (da - sum_p a da) in place of da, sum_dl[b] = sum_p dl
+hipError_t launch_gc_pool_bwd_weights(const float* x, const float* logits, const float* dctx, const float* ctx, float* a,
+                                      float* dl, float* sum_dl, int B, int HW, int C, hipStream_t s);
+// dx[b][p][c] = a[b][p] dctx[b][c] + dl[b][p] wg[c]
+hipError_t launch_gc_pool_bwd_dx(const float* a, const float* dl, const float* dctx, const float* wg, float* dx, int B, int HW,
+                                 int C, hipStream_t s);
+
+hipError_t launch_sum_small(const float* a, int n, float* dst, hipStream_t s);  // dst[0] = sum of n (few) floats
+
 // ---- training step (train_kernels.hip) --------------------------------------
 // Weight gradient ("TN" GEMM, optional filter taps): part[z][tap][m][n] = sum_{p in chunk z} a[p][m] * x[src(p,tap)][n]
 struct WgradP {
@@ -299,7 +317,7 @@ hipError_t launch_bn_apply(const float* z, const float* mean, const float* rstd,
 hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean, const float* rstd,
                                const float* gamma, const float* s0, const float* s1, float* dz, float* gout, long long R,
                                int C, hipStream_t s, uint16_t* planes = nullptr);
-enum { EW_COPY = 0, EW_ADD = 1, EW_RELU_BWD = 2, EW_GELU = 3, EW_GELU_BWD = 4 };
+enum { EW_COPY = 0, EW_ADD = 1, EW_RELU_BWD = 2, EW_GELU = 3, EW_GELU_BWD = 4, EW_RELU = 5 };
 hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int op, hipStream_t s);
 hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
                               int PW, hipStream_t s);

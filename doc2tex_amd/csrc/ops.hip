@@ -631,6 +631,15 @@ __global__ void gc_add_kernel(float* __restrict__ x, const float* __restrict__ y
     reinterpret_cast<float4*>(x)[i] = v;
   }
 }
+hipError_t launch_gc_logits(const float* x, const float* wg, const float* bg, float* logits, long long rows, int C, hipStream_t s) {
+  hipLaunchKernelGGL(gc_logits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, wg, bg, logits, rows, C);
+  return hipGetLastError();
+}
+hipError_t launch_gc_pool(const float* x, const float* logits, float* ctx, int B, int HW, int C, hipStream_t s) {
+  if (C > 512) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_pool_kernel, dim3(B), dim3(512), 0, s, x, logits, ctx, HW, C);
+  return hipGetLastError();
+}
 hipError_t launch_global_context(float* x, const GCParams& w, float* logits, float* ctx, float* y, int B, int HW, int C,
                                  hipStream_t s) {
   if (C > 512 || C % 4) return hipErrorInvalidValue;

@@ -52,7 +52,8 @@ struct TT {  // tensor on the tape
   const uint16_t* planes = nullptr;  // split-bf16 records of p, when the producing kernel wrote them alongside (bf16x3 mode)
 };
 
-enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD, N_LSTM };
+enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD, N_LSTM, N_RELU,
+            N_GCPOOL, N_BCAST };
 
 struct Node {
   Kind kind;
@@ -379,6 +380,8 @@ struct Tr {  // builder / runner bound to one context and stream
           RC(conv_bn(x, bp + ".downsample.0", bp + ".downsample.1", chans[li], 1, 1, 1, 1, 0, 0, false, -1, &r));
         RC(conv_bn(t, bp + ".conv2", bp + ".bn2", chans[li], 3, 3, 1, 1, 1, 1, true, r, &x));
       }
+      if (c->cfg.gcb)  // a GlobalContext block closes the stage (resnet.py:200-201): Sequential index = number of blocks
+        RC(global_context(x, p + "layer" + std::to_string(li + 1) + "." + std::to_string(RESNET_BLOCKS[li]), &x));
       return D2T_OK;
     };
     RC(stage(0));
@@ -447,25 +450,27 @@ struct Tr {  // builder / runner bound to one context and stream
     return D2T_OK;
   }
   // a fresh keep mask of n elements (nullptr when dropout is off)
-  int new_mask(size_t n, const uint8_t** m) {
+  int new_mask(size_t n, const uint8_t** m, float p = -1.f) {
     *m = nullptr;
-    if (st->drop_p <= 0.f) return D2T_OK;
+    if (p < 0.f) p = st->drop_p;
+    if (p <= 0.f) return D2T_OK;
     float* raw;
     RC(alloc(&raw, n / 4 + 2));
     uint8_t* mk = reinterpret_cast<uint8_t*>(raw);
-    TCHK(launch_dropout_mask(mk, n, st->drop_p, st->drop_seed, (st->drop_calls << 16) | st->drop_site, s));
+    TCHK(launch_dropout_mask(mk, n, p, st->drop_seed, (st->drop_calls << 16) | st->drop_site, s));
     ++st->drop_site;
     st->masks.push_back({mk, n});
     *m = mk;
     return D2T_OK;
   }
   // nn.Dropout(p): out = in * mask / (1 - p); identity (no node) when p == 0
-  int dropout(int in, int* out) {
-    if (st->drop_p <= 0.f) { *out = in; return D2T_OK; }
+  int dropout(int in, int* out, float p = -1.f) {  // p < 0: the decoder's configured rate (d2t_train_set_dropout)
+    if (p < 0.f) p = st->drop_p;
+    if (p <= 0.f) { *out = in; return D2T_OK; }
     const TT x = st->t[in];
     Node n;
-    n.kind = N_DROPOUT; n.in = in; n.mscale = 1.f / (1.f - st->drop_p);
-    RC(new_mask((size_t)x.rows * x.cols, &n.mask));
+    n.kind = N_DROPOUT; n.in = in; n.mscale = 1.f / (1.f - p);
+    RC(new_mask((size_t)x.rows * x.cols, &n.mask, p));
     RC(new_tensor(x.rows, x.cols, out));
     TCHK(launch_apply_mask(x.p, n.mask, n.mscale, st->t[*out].p, (size_t)x.rows * x.cols, s));
     n.out = *out;
@@ -488,6 +493,48 @@ struct Tr {  // builder / runner bound to one context and stream
     Node n;
     n.kind = N_GELU; n.in = in; n.out = *out;
     st->nodes.push_back(n);
+    return D2T_OK;
+  }
+
+  int relu(int in, int* out) {
+    const TT x = st->t[in];
+    RC(new_tensor(x.rows, x.cols, out));
+    TCHK(launch_ew(x.p, nullptr, st->t[*out].p, (size_t)x.rows * x.cols, EW_RELU, s));
+    Node n;
+    n.kind = N_RELU; n.in = in; n.out = *out; n.relu = true;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  // GlobalContext.forward (addon_module/visual_attention.py:147-165, use_attn + fuse_add): a 1x1-conv attention map over the
+  // H*W positions, softmax, the attention-pooled channel vector, ConvMLP (fc1 -> LayerNorm2d -> ReLU -> fc2) on it, added to
+  // every position.  Three tape nodes of its own (pooling, ReLU, broadcast add) around the ordinary linear / LayerNorm ones.
+  int global_context(int in, const std::string& key, int* out) {
+    const TT x = st->t[in];
+    const int B = x.B, HW = x.H * x.W, C = x.cols;
+    const float *wg, *bg;
+    RC(raw(key + ".global_cxt.weight", &wg, C));
+    RC(raw(key + ".global_cxt.bias", &bg, 1));
+    Node n;
+    n.kind = N_GCPOOL; n.in = in; n.wkey = key + ".global_cxt";
+    RC(alloc(&n.z, (size_t)B * HW));  // the attention logits, kept for the backward pass
+    TCHK(launch_gc_logits(x.p, wg, bg, n.z, (long long)B * HW, C, s));
+    int ctx;
+    RC(new_tensor(B, C, &ctx));
+    TCHK(launch_gc_pool(x.p, n.z, st->t[ctx].p, B, HW, C, s));
+    n.out = ctx;
+    st->nodes.push_back(n);
+    int h, y;
+    const std::string m = key + ".bottleneck_add.";
+    RC(linear(ctx, m + "fc1", C, C, 0, ACT_NONE, -1, &h));
+    RC(layernorm(h, m + "norm", 1e-5f, &h));
+    RC(relu(h, &h));
+    RC(dropout(h, &h, 0.25f));  // ConvMLP's nn.Dropout(drop=0.25), hard-wired (visual_attention.py:86,94,100)
+    RC(linear(h, m + "fc2", C, C, 0, ACT_NONE, -1, &y));
+    RC(new_tensor(x.rows, C, out, x.B, x.H, x.W));
+    TCHK(launch_gc_bcast_add(x.p, st->t[y].p, st->t[*out].p, B, HW, C, s));
+    Node a;
+    a.kind = N_BCAST; a.in = in; a.in2 = y; a.out = *out;
+    st->nodes.push_back(a);
     return D2T_OK;
   }
 
@@ -970,6 +1017,52 @@ struct Tr {  // builder / runner bound to one context and stream
           RC(add_grad(n.in2, g));
           break;
         }
+        case N_RELU: {
+          const TT& x = st->t[n.in];
+          float* dx;
+          RC(alloc(&dx, (size_t)x.rows * x.cols));
+          TCHK(launch_ew(st->t[n.out].grad, st->t[n.out].p, dx, (size_t)x.rows * x.cols, EW_RELU_BWD, s));
+          RC(add_grad(n.in, dx));
+          break;
+        }
+        case N_BCAST: {  // out = x + y[b]: dx = dout; dy[b][c] = sum over the image's positions
+          const TT& x = st->t[n.in];
+          const TT& o = st->t[n.out];
+          const int B = x.B, HW = x.H * x.W, C = x.cols;
+          float *dy, *dx;
+          RC(alloc(&dy, (size_t)B * C));
+          RC(ensure_part((size_t)B * GC_CHUNKS * C));
+          TCHK(launch_gc_wpool(o.grad, nullptr, st->part, dy, B, HW, C, s));
+          RC(add_grad(n.in2, dy));
+          RC(alloc(&dx, (size_t)x.rows * C));
+          TCHK(hipMemcpyAsync(dx, o.grad, (size_t)x.rows * C * 4, hipMemcpyDeviceToDevice, s));
+          RC(add_grad(n.in, dx));
+          break;
+        }
+        case N_GCPOOL: {  // ctx[b] = sum_p a[b][p] x[b][p], a = softmax_p(x . wg + bg)
+          const TT& x = st->t[n.in];
+          const int B = x.B, HW = x.H * x.W, C = x.cols;
+          const float* dctx = st->t[n.out].grad;
+          const float* wg;
+          RC(raw(n.wkey + ".weight", &wg, C));
+          float *a, *dl, *sdl, *dx, *dwg_b, *dwg, *dbg;
+          RC(alloc(&a, (size_t)B * HW));
+          RC(alloc(&dl, (size_t)B * HW));
+          RC(alloc(&sdl, B));
+          TCHK(launch_gc_pool_bwd_weights(x.p, n.z, dctx, st->t[n.out].p, a, dl, sdl, B, HW, C, s));
+          RC(alloc(&dx, (size_t)x.rows * C));
+          TCHK(launch_gc_pool_bwd_dx(a, dl, dctx, wg, dx, B, HW, C, s));
+          RC(add_grad(n.in, dx));
+          // d wg[c] = sum_b sum_p dl[b][p] x[b][p][c]; d bg = sum dl (zero up to rounding: a softmax ignores a shift)
+          RC(alloc(&dwg_b, (size_t)B * C));
+          RC(ensure_part((size_t)B * GC_CHUNKS * C));
+          TCHK(launch_gc_wpool(x.p, dl, st->part, dwg_b, B, HW, C, s));
+          RC(grad_buf(n.wkey + ".weight", &dwg));
+          RC(colsum(dwg_b, B, C, dwg));
+          RC(grad_buf(n.wkey + ".bias", &dbg));
+          TCHK(launch_sum_small(sdl, B, dbg, s));
+          break;
+        }
         case N_GELU: {
           const TT& x = st->t[n.in];
           float* dx;
@@ -1012,7 +1105,6 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (lstm && g.encoder != D2T_ENC_HYBRID_VIT) return fail(c, D2T_ESTATE, "the Attn training step needs the HybridViT encoder");
   if (lstm && L != g.batch_max_length + 1) return fail(c, D2T_EINVAL, "the Attn head trains on batch_max_length + 1 = %d steps", g.batch_max_length + 1);
   if (!lstm && L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
-  if (g.gcb) return fail(c, D2T_ESTATE, "the training step does not support GlobalContext blocks (gcb)");
   if (lstm && (g.attn_cell != D2T_ATTN_CELL_LOCATION || g.attn_onehot))
     return fail(c, D2T_ESTATE, "the Attn training step is implemented for the location-aware cells with embedded targets");
   if (!c->train) c->train = new d2t_train_state();
@@ -1165,7 +1257,9 @@ int d2t_train_mask_count(d2t_ctx* c) { return c && c->train ? (int)c->train->mas
 // [+ residual] + ReLU nodes, decoder linear1) and per max-pool.  A test replays them in the oracle (ReLU -> multiply by the
 // keep mask, max-pool -> gather of the recorded window element), which makes oracle and engine evaluate the SAME smooth
 // function: gradients then agree to rounding everywhere, with no "a tie may have flipped" allowance.
-static bool is_decision(const Node& n) { return n.kind == N_POOL || ((n.kind == N_CONV || n.kind == N_LINEAR) && n.relu); }
+static bool is_decision(const Node& n) {
+  return n.kind == N_POOL || n.kind == N_RELU || ((n.kind == N_CONV || n.kind == N_LINEAR) && n.relu);
+}
 
 int d2t_train_decision_count(d2t_ctx* c) {
   if (!c || !c->train) return 0;

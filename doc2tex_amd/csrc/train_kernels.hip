@@ -521,6 +521,7 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
       switch (op) {
         case EW_ADD: o[k] = x[k] + y[k]; break;
         case EW_RELU_BWD: o[k] = y[k] > 0.f ? x[k] : 0.f; break;  // a = dy, b = forward output
+        case EW_RELU: o[k] = fmaxf(x[k], 0.f); break;
         case EW_GELU: o[k] = 0.5f * x[k] * (1.f + erff(x[k] * 0.70710678118654752440f)); break;
         case EW_GELU_BWD: {  // a = dy, b = pre-activation u: d/du [u * Phi(u)] = Phi(u) + u * phi(u)
           const float u = y[k];
@@ -673,7 +674,7 @@ hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, i
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm with saved statistics / backward.  One wave per row, D = 256 or 512.
+// LayerNorm with saved statistics / backward.  One wave per row, D = 128, 256 or 512.
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void ln_train_kernel(const float* __restrict__ x, const float* __restrict__ g,
@@ -700,7 +701,8 @@ __global__ __launch_bounds__(256) void ln_train_kernel(const float* __restrict__
 }
 hipError_t launch_ln_train(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
                            int D, float eps, hipStream_t s) {
-  if (D == 256) hipLaunchKernelGGL(ln_train_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
+  if (D == 128) hipLaunchKernelGGL(ln_train_kernel<128>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
+  else if (D == 256) hipLaunchKernelGGL(ln_train_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
   else if (D == 512) hipLaunchKernelGGL(ln_train_kernel<512>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, mean, rstd, rows, eps);
   else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -736,7 +738,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
                          const float* add, float* dx, int rows, int D, hipStream_t s) {
-  if (D == 256) hipLaunchKernelGGL(ln_bwd_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
+  if (D == 128) hipLaunchKernelGGL(ln_bwd_kernel<128>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
+  else if (D == 256) hipLaunchKernelGGL(ln_bwd_kernel<256>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
   else if (D == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, dim3((rows + 3) / 4), dim3(256), 0, s, dy, x, mean, rstd, g, add, dx, rows);
   else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -1258,6 +1261,165 @@ hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int
                              int nchunks, hipStream_t s) {
   if (Cout != 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, Cout, chunk);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// GlobalContext block in the training step (addon_module/visual_attention.py:147-165): x [B][HW][C]
+// ---------------------------------------------------------------------------
+// partial[b][z][c] = sum over the z-th pixel chunk of (w[b][p]) x[b][p][c];  grid (B, GC_CHUNKS), thread = 4 channels x
+// pixel phase
+__global__ __launch_bounds__(256) void gc_wpool_kernel(const float* __restrict__ x, const float* __restrict__ wts,
+                                                       float* __restrict__ part, int HW, int C) {
+  __shared__ float4 red[256];
+  const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x;
+  const int q4 = C / 4;                  // float4 per pixel row
+  const int cq = tid % q4, ph = tid / q4, nph = 256 / q4;  // C <= 512 -> q4 <= 128 -> at least two pixel phases
+  const int per = (HW + GC_CHUNKS - 1) / GC_CHUNKS, p0 = z * per, p1 = min(HW, p0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ph < nph)
+    for (int p = p0 + ph; p < p1; p += nph) {
+      const float w = wts ? wts[(size_t)b * HW + p] : 1.f;
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * C + cq * 4);
+      acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < q4) {  // fixed order over the phases: deterministic
+    float4 t = red[tid];
+    for (int k = 1; k < nph; ++k) {
+      const float4 u = red[k * q4 + tid];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + ((size_t)b * GC_CHUNKS + z) * C + tid * 4) = t;
+  }
+}
+__global__ void gc_wpool_final_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  float t = 0.f;
+  for (int z = 0; z < GC_CHUNKS; ++z) t += part[((size_t)b * GC_CHUNKS + z) * C + c];
+  out[i] = t;
+}
+hipError_t launch_gc_wpool(const float* x, const float* wts, float* part, float* out, int B, int HW, int C, hipStream_t s) {
+  if (C % 4 || C > 512 || 256 / (C / 4) < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_wpool_kernel, dim3(B, GC_CHUNKS), dim3(256), 0, s, x, wts, part, HW, C);
+  hipLaunchKernelGGL(gc_wpool_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, out, B, C);
+  return hipGetLastError();
+}
+__global__ void gc_bcast_add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n4,
+                                    int HW, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int c = (int)(e % C);
+    const size_t b = e / ((size_t)HW * C);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(y + b * C + c);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+hipError_t launch_gc_bcast_add(const float* x, const float* y, float* out, int B, int HW, int C, hipStream_t s) {
+  const size_t n4 = (size_t)B * HW * C / 4;
+  hipLaunchKernelGGL(gc_bcast_add_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, x, y, out, n4, HW, C);
+  return hipGetLastError();
+}
+// one block per image: softmax statistics of the logits, then per pixel a = softmax, da = dctx . x; then dl = a (da - s)
+// (da is taken against the pooled vector, dctx . (x[p] - ctx): dl = a (da - sum a da) cancels dctx . ctx, which is three
+// orders of magnitude larger than what is left when the positions of a map resemble each other)
+__global__ __launch_bounds__(512) void gc_pool_bwd_weights_kernel(const float* __restrict__ x, const float* __restrict__ logits,
+                                                                  const float* __restrict__ dctx, const float* __restrict__ ctx,
+                                                                  float* __restrict__ a_out, float* __restrict__ dl,
+                                                                  float* __restrict__ sum_dl, int HW, int C) {
+  __shared__ float red[24], dc[512], cx[512];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* l = logits + (size_t)b * HW;
+  float* av = a_out + (size_t)b * HW;
+  float* dv = dl + (size_t)b * HW;
+  if (tid < C) { dc[tid] = dctx[(size_t)b * C + tid]; cx[tid] = ctx[(size_t)b * C + tid]; }
+  float m = -INFINITY;
+  for (int p = tid; p < HW; p += 512) m = fmaxf(m, l[p]);
+  m = wmax(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+  float sum = 0.f;
+  for (int p = tid; p < HW; p += 512) sum += expf(l[p] - m);
+  sum = wsum(sum);
+  if (lane == 0) red[8 + wave] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tot += red[8 + w];
+  const float inv = 1.f / tot;
+  // da per pixel: one wave per pixel, lanes over channels
+  float sacc = 0.f;
+  for (int p = wave; p < HW; p += 8) {
+    const float* xr = x + ((size_t)b * HW + p) * C;
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d = fmaf(dc[c], xr[c] - cx[c], d);
+    d = wsum(d);
+    const float a = expf(l[p] - m) * inv;
+    if (lane == 0) { av[p] = a; dv[p] = d; }
+    sacc = fmaf(a, d, sacc);  // identical in every lane of the wave
+  }
+  if (lane == 0) red[16 + wave] = sacc;
+  __syncthreads();
+  float sdot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) sdot += red[16 + w];
+  __syncthreads();
+  float sd = 0.f;
+  for (int p = tid; p < HW; p += 512) {
+    const float v = av[p] * (dv[p] - sdot);
+    dv[p] = v;
+    sd += v;
+  }
+  sd = wsum(sd);
+  if (lane == 0) red[wave] = sd;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 8; ++w) t += red[w];
+    sum_dl[b] = t;
+  }
+}
+hipError_t launch_gc_pool_bwd_weights(const float* x, const float* logits, const float* dctx, const float* ctx, float* a,
+                                      float* dl, float* sum_dl, int B, int HW, int C, hipStream_t s) {
+  if (C > 512) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_pool_bwd_weights_kernel, dim3(B), dim3(512), 0, s, x, logits, dctx, ctx, a, dl, sum_dl, HW, C);
+  return hipGetLastError();
+}
+__global__ void gc_pool_bwd_dx_kernel(const float* __restrict__ a, const float* __restrict__ dl, const float* __restrict__ dctx,
+                                      const float* __restrict__ wg, float* __restrict__ dx, size_t n4, int HW, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int c = (int)(e % C);
+    const size_t row = e / C, b = row / HW;
+    const float av = a[row], dv = dl[row];
+    const float4 d = *reinterpret_cast<const float4*>(dctx + b * C + c);
+    const float4 w = *reinterpret_cast<const float4*>(wg + c);
+    reinterpret_cast<float4*>(dx)[i] = make_float4(fmaf(av, d.x, dv * w.x), fmaf(av, d.y, dv * w.y), fmaf(av, d.z, dv * w.z),
+                                                   fmaf(av, d.w, dv * w.w));
+  }
+}
+__global__ __launch_bounds__(64) void sum_small_kernel(const float* __restrict__ a, int n, float* __restrict__ dst) {
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) t += a[i];
+  t = wsum(t);
+  if (threadIdx.x == 0) dst[0] = t;
+}
+hipError_t launch_sum_small(const float* a, int n, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, s, a, n, dst);
+  return hipGetLastError();
+}
+hipError_t launch_gc_pool_bwd_dx(const float* a, const float* dl, const float* dctx, const float* wg, float* dx, int B, int HW,
+                                 int C, hipStream_t s) {
+  const size_t n4 = (size_t)B * HW * C / 4;
+  hipLaunchKernelGGL(gc_pool_bwd_dx_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, a, dl, dctx, wg, dx, n4, HW, C);
   return hipGetLastError();
 }
 

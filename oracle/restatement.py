@@ -72,10 +72,14 @@ def _basic_block(x, sd, p, faithful, bn_train=None):
     return F.relu(out + x)
 
 
-def _global_context(x, sd, p):
+GC_DROP = 0.25  # ConvMLP's nn.Dropout(drop=0.25), visual_attention.py:86,94: hard-wired, active under module.train()
+
+
+def _global_context(x, sd, p, drop=None):
     """GlobalContext.forward with use_attn / fuse_add (addon_module/visual_attention.py:147-165): 1x1 conv -> softmax
-    over H*W -> attention-pooled channel vector -> ConvMLP (fc1, LayerNorm2d, ReLU, dropout (eval: off), fc2; the hidden
-    width equals the channel count, :88-89) -> added to every position."""
+    over H*W -> attention-pooled channel vector -> ConvMLP (fc1, LayerNorm2d, ReLU, dropout p = 0.25 (eval: off), fc2; the
+    hidden width equals the channel count, :88-89) -> added to every position.  `drop(shape, "gc")` returns the scaled keep
+    mask of the training-mode dropout (None: evaluation)."""
     B, C, H, W = x.shape
     attn = F.conv2d(x, sd[p + "global_cxt.weight"], sd[p + "global_cxt.bias"]).reshape(B, H * W)
     attn = F.softmax(attn, dim=-1).unsqueeze(-1)
@@ -83,11 +87,14 @@ def _global_context(x, sd, p):
     m = p + "bottleneck_add."
     h = F.conv2d(ctx, sd[m + "fc1.weight"], sd[m + "fc1.bias"])
     h = F.layer_norm(h.permute(0, 2, 3, 1), (h.shape[1],), sd[m + "norm.weight"], sd[m + "norm.bias"], 1e-5).permute(0, 3, 1, 2)
-    h = F.conv2d(F.relu(h), sd[m + "fc2.weight"], sd[m + "fc2.bias"])
+    h = F.relu(h)
+    if drop is not None:
+        h = h * drop(h.shape, "gc").to(h.dtype)
+    h = F.conv2d(h, sd[m + "fc2.weight"], sd[m + "fc2.bias"])
     return x + h
 
 
-def resnet(x, sd, p, faithful=True, bn_train=None):
+def resnet(x, sd, p, faithful=True, bn_train=None, drop=None):
     """ResNet.forward, resnet.py:205-245.  x [B,1,H,W] -> [B,512,H',W'] (NCHW)."""
     cb = lambda x, c, b, s=1, pd=1: F.relu(_conv_bn(x, sd, p + c, p + b, s, pd, faithful, bn_train))
     x = cb(x, "conv0_1", "bn0_1")
@@ -96,24 +103,24 @@ def resnet(x, sd, p, faithful=True, bn_train=None):
     for i in range(RESNET_LAYERS[0]):
         x = _basic_block(x, sd, f"{p}layer1.{i}", faithful, bn_train)
     if f"{p}layer1.{RESNET_LAYERS[0]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
-        x = _global_context(x, sd, f"{p}layer1.{RESNET_LAYERS[0]}.")
+        x = _global_context(x, sd, f"{p}layer1.{RESNET_LAYERS[0]}.", drop)
     x = cb(x, "conv1", "bn1")
     x = F.max_pool2d(x, 2, 2, 0)  # :106
     for i in range(RESNET_LAYERS[1]):
         x = _basic_block(x, sd, f"{p}layer2.{i}", faithful, bn_train)
     if f"{p}layer2.{RESNET_LAYERS[1]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
-        x = _global_context(x, sd, f"{p}layer2.{RESNET_LAYERS[1]}.")
+        x = _global_context(x, sd, f"{p}layer2.{RESNET_LAYERS[1]}.", drop)
     x = cb(x, "conv2", "bn2")
     x = F.max_pool2d(x, 2, (2, 1), (0, 1))  # :120, implicit -inf padding
     for i in range(RESNET_LAYERS[2]):
         x = _basic_block(x, sd, f"{p}layer3.{i}", faithful, bn_train)
     if f"{p}layer3.{RESNET_LAYERS[2]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
-        x = _global_context(x, sd, f"{p}layer3.{RESNET_LAYERS[2]}.")
+        x = _global_context(x, sd, f"{p}layer3.{RESNET_LAYERS[2]}.", drop)
     x = cb(x, "conv3", "bn3")
     for i in range(RESNET_LAYERS[3]):
         x = _basic_block(x, sd, f"{p}layer4.{i}", faithful, bn_train)
     if f"{p}layer4.{RESNET_LAYERS[3]}.global_cxt.weight" in sd:  # gcb: GlobalContext closes the stage (resnet.py:200-201)
-        x = _global_context(x, sd, f"{p}layer4.{RESNET_LAYERS[3]}.")
+        x = _global_context(x, sd, f"{p}layer4.{RESNET_LAYERS[3]}.", drop)
     x = cb(x, "conv4_1", "bn4_1", (2, 1), (0, 1))  # :139-147
     x = cb(x, "conv4_2", "bn4_2", 1, 0)  # :149-157
     return x
@@ -187,9 +194,9 @@ def posenc2d_crop(d_model, h, w):
 # ---------------------------------------------------------------------------
 # HybridViT encoder
 # ---------------------------------------------------------------------------
-def hybrid_embed(x, sd, p, patch=(2, 2), faithful=True, bn_train=None):
+def hybrid_embed(x, sd, p, patch=(2, 2), faithful=True, bn_train=None, drop=None):
     """HybridEmbed.forward, seq_modeling/addon_module/patchembed.py:115-141."""
-    x = resnet(x, sd, p + "backbone.ConvNet.", faithful, bn_train)
+    x = resnet(x, sd, p + "backbone.ConvNet.", faithful, bn_train, drop)
     fh, fw = x.shape[2:]
     pad_h = (-fh) % patch[0]
     pad_w = (-fw) % patch[1]
@@ -214,9 +221,9 @@ def _vit_block(x, sd, p, heads):
     return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
 
 
-def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None, bn_train=None):
+def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None, bn_train=None, drop=None):
     """ViTEncoderV3.forward, seq_modeling/vit_encoder.py:249-268."""
-    x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful, bn_train)
+    x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful, bn_train, drop)
     if taps is not None:
         taps["patch"] = x
     B, n, C = x.shape
@@ -637,13 +644,13 @@ def attn_beam(batch_H, sd, p, num_steps, seqmodel, beam_size, enc_init=True, att
 # ---------------------------------------------------------------------------
 # Model.forward  (modules/build_model.py:36-79)
 # ---------------------------------------------------------------------------
-def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None):
+def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None, drop=None):
     """Model.forward_encoder: returns (contextual_feature [B,T,d], output_shape, feat_pad)."""
     seq = cfg["SequenceModeling"]
     if seq["name"] == "ViT":
         sp = seq["params"]
         x, pad_info, size = vit_encoder_v3(image, sd, "seqmodeler.SequenceModeling.", sp["depth"],
-                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps, bn_train)
+                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps, bn_train, drop)
         shape = (size["height"] // sp["patch_size"][0], size["width"] // sp["patch_size"][1])
         return x, shape, pad_info
     if seq["name"] == "BiLSTM":
@@ -658,7 +665,7 @@ def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None):
         return x, None, None
     # Feat=ResNet, Seq=None, Pred=TFM: PositionalEncoding2D add then B,C,H,W -> B,HW,C
     # (recognizers/build_seq.py:69-76)
-    f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful, bn_train)
+    f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful, bn_train, drop)
     if taps is not None:
         taps["backbone"] = f
     f = f + posenc2d_crop(f.shape[1], f.shape[2], f.shape[3])
@@ -716,7 +723,7 @@ def train_forward(cfg, sd, image, text_in, bn_train, drop=None, flags=None):
     Attn / Attnv2 heads: the LSTM-attention loop fed with the label tokens (teacher_forcing = 1.0,
     seq2seq.py:311-316; droprate 0).  Returns logits [B,L,V]."""
     pp = cfg["Prediction"]["params"]
-    mem, _, _ = forward_encoder(cfg, sd, image, faithful=True, bn_train=bn_train)
+    mem, _, _ = forward_encoder(cfg, sd, image, faithful=True, bn_train=bn_train, drop=drop)
     if cfg["Prediction"]["name"] in ("Attn", "Attnv2"):
         sm = pp.get("seqmodel", "ViT")
         if cfg["Prediction"]["name"] == "Attn" and sm != "BiLSTM":

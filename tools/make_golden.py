@@ -110,9 +110,12 @@ TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_tra
                     ("ts0_train_step", "TS0", 3, 48, 64, 24, 1234, 1032),
                     # round 2 -- BASELINE configs[3] at its own crop size and label length (four rows of the per-GPU shard:
                     # 8256 pixels per BatchNorm channel in the deepest stage instead of ~100 in the toys above)
-                    ("c3_train_step", "C3", 4, 128, 512, 150, 1234, 1033)]
+                    ("c3_train_step", "C3", 4, 128, 512, 150, 1234, 1033),
+                    # GlobalContext blocks on (gcb: True): the two TFM stacks
+                    ("t2g_train_step", "T2G", 3, 48, 64, 24, 1234, 1034), ("t1g_train_step", "T1G", 2, 32, 64, 22, 1234, 1035)]
 LOGIT_STRIDE = {"c3_train_step": 8}  # store every 8th position of the [B, 151, V] logits (fixture size)
 GRAD_SAMPLES = 48
+GC_MASK_SEED = 99  # seeded keep masks of the GlobalContext blocks' dropout in the *g_train_step fixtures
 # dropout placement (p = 0.1 in the decoder layers): name, config, B, H, W, L, wseed, iseed, mask seed
 TRAIN_DROPOUT_CASES = [("t2d_train_dropout", "T2D", 3, 48, 64, 24, 1234, 1060, 77),
                        # LSTM head: droprate 0.25 on the generator output + scheduled sampling (teacher_forcing 0.7)
@@ -354,7 +357,23 @@ def run_train_step(case):
     img = synth.synth_images(B, H, W, seed=iseed)
     text = train_labels(cfg, B, L, iseed)
     t0 = time.time()
-    _, preds, _ = m(img, text[:, :-1])  # is_train defaults to True (training.py:88)
+    # GlobalContext blocks carry an nn.Dropout(0.25) that module.train() switches on (visual_attention.py:86-101): the
+    # reference runs with torch.nn.functional.dropout replaced by a seeded mask source and the oracle gets the same masks
+    gc_seed = GC_MASK_SEED if cname.endswith("G") else None
+    src = SeqFirstMasks(R.GC_DROP, gc_seed) if gc_seed is not None else None
+    real = torch.nn.functional.dropout
+
+    def fake(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        assert src is not None and p == R.GC_DROP, p
+        return input * src.draw(input.shape)
+
+    torch.nn.functional.dropout = fake
+    try:
+        _, preds, _ = m(img, text[:, :-1])  # is_train defaults to True (training.py:88)
+    finally:
+        torch.nn.functional.dropout = real
     cost = torch.nn.functional.cross_entropy(preds.view(-1, preds.shape[-1]), text[:, 1:].contiguous().view(-1),
                                              ignore_index=0, reduction="none")
     loss = cost.mean()
@@ -362,14 +381,22 @@ def run_train_step(case):
     ref_grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     ref_frozen = [k for k, p in m.named_parameters() if p.grad is None]
     after = {k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
-    oloss, ologits, ograds, obn = R.train_step_grads(cfg, slim_sd(sd), img, text)
+    osrc = SeqFirstMasks(R.GC_DROP, gc_seed) if gc_seed is not None else None
+    oloss, ologits, ograds, obn = R.train_step_grads(cfg, slim_sd(sd), img, text,
+                                                     drop=(lambda shape, kind: osrc.draw(shape) if kind == "gc"
+                                                           else torch.ones(tuple(shape))) if osrc else None)
     assert abs(float(oloss) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (float(oloss), float(loss))
     assert maxdiff(ologits, preds.detach()) <= TOL
     assert sorted(ograds) == sorted(ref_grads), (set(ograds) ^ set(ref_grads), ref_frozen)
-    worst = 0.0
+    worst, worst_key = 0.0, None
     for k, g in ref_grads.items():
-        worst = max(worst, float((ograds[k].double() - g.double()).abs().max() / max(1e-6, float(g.double().abs().max()))))
-    assert worst <= 5e-4, worst
+        if k.endswith("global_cxt.bias"):  # a softmax ignores a shift of its logits: this gradient is rounding noise (1e-9)
+            assert float(g.abs().max()) <= 1e-7 and float(ograds[k].abs().max()) <= 1e-7, k
+            continue
+        e = float((ograds[k].double() - g.double()).abs().max() / max(1e-6, float(g.double().abs().max())))
+        if e > worst:
+            worst, worst_key = e, k
+    assert worst <= 5e-4, (worst, worst_key, float(ref_grads[worst_key].abs().max()))
     for k, v in after.items():
         assert maxdiff(obn[k], v) <= 1e-5, k
     arrays = {"logits": preds.detach()[:, ::LOGIT_STRIDE.get(name, 1)].numpy(), "text": text.numpy()}
@@ -383,7 +410,7 @@ def run_train_step(case):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
     return {"case": name, "config": cname, "B": B, "H": H, "W": W, "max_seq_len": L, "wseed": wseed, "iseed": iseed,
             "loss": float(loss), "oracle_worst_rel_grad_diff": worst, "n_grads": len(ref_grads), "frozen": ref_frozen,
-            "logit_stride": LOGIT_STRIDE.get(name, 1),
+            "logit_stride": LOGIT_STRIDE.get(name, 1), "gc_mask_seed": gc_seed,
             "grad_norms": norms, "seconds": round(time.time() - t0, 1), "torch": torch.__version__}
 
 
@@ -566,6 +593,18 @@ def main():
             rep = run_attn_beam(case)
             summary["attn_beam"].append(rep)
             print("attn_beam", rep["case"], rep["seq"], rep["score"], "ended", rep["ended"], flush=True)
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "gcb_train":  # add / refresh only the GlobalContext training fixtures
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        for case in TRAIN_STEP_CASES:
+            if case[0] not in ("t2g_train_step", "t1g_train_step"):
+                continue
+            rep = run_train_step(case)
+            summary["train_step"] = [r for r in summary["train_step"] if r["case"] != rep["case"]] + [rep]
+            print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
         with open(os.path.join(GOLD, "cases.json"), "w") as f:
             json.dump(summary, f, indent=1)
         return
