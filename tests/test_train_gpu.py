@@ -31,10 +31,8 @@ def _rel(a, b):
 
 
 def _train_model(*a, precision="fp32", **k):
-    """engine_model for the gradient tests.  They run in exact-fp32 arithmetic: on these tiny batches (a hundred
-    pixels per BatchNorm in the deep layers) the split-bf16 rounding (2^-16 per product instead of 2^-24) flips enough
-    ReLU / max-pool ties to move the early-backbone gradients by several per cent, which is the instance's
-    conditioning, not the kernels'; test_train_step_in_split_bf16 covers that mode with bounds that reflect it."""
+    """engine_model for the gradient tests, in the arithmetic mode the test names (default here: exact fp32; `Model` itself
+    defaults to split-bf16, which the decision-replay tests cover with their own bound)."""
     cfg, m = engine_model(*a, **k)
     m.conv_precision = precision
     return cfg, m
