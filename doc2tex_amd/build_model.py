@@ -335,8 +335,8 @@ class Model(nn.Module):
                 if self.stages["Seq"] not in ("ViT", "None"):
                     raise NotImplementedError("the training step is implemented for the HybridViT + TFM and ResNet + TFM stacks")
             else:  # Attn / Attnv2
-                if self.stages["Seq"] != "ViT":
-                    raise NotImplementedError("training the LSTM-attention head is implemented on the HybridViT encoder only")
+                if self.stages["Seq"] not in ("ViT", "BiLSTM"):
+                    raise NotImplementedError("training the LSTM-attention head is implemented on the HybridViT and BiLSTM encoders")
                 pp = self.opt["Prediction"]["params"]
                 if pp.get("attn_type", "coverage") not in ("coverage", "loc_aware") or not pp.get("embed_target", False):
                     raise NotImplementedError("training the LSTM-attention head is implemented for the location-aware cells "

@@ -278,6 +278,20 @@ hipError_t launch_gc_pool_bwd_dx(const float* a, const float* dl, const float* d
                                  int C, hipStream_t s);
 
 hipError_t launch_sum_small(const float* a, int n, float* dst, hipStream_t s);  // dst[0] = sum of n (few) floats
+hipError_t launch_bias_add(float* z, const float* bias, long long rows, int C, hipStream_t s);  // z[r][c] += bias[c]
+hipError_t launch_scale(const float* a, float* out, size_t n, float alpha, hipStream_t s);      // out = alpha * a
+// dx[b][h][w][c] = dy[b][w][c] / H  (backward of the mean over the height, build_feat.py:50-55)
+hipError_t launch_mean_h_bwd(const float* dy, float* dx, int B, int H, int W, int C, hipStream_t s);
+// Bidirectional LSTM recurrence of the training step (seq_modeling/bilstm.py:14-24).  gates [B*T][8H]: pre-activations
+// x W_ih^T + b_ih + b_hh, direction d in columns [4H d, 4H d + 4H); whh_t [2][H][4H]; out [B*T][2H] (forward | reverse);
+// saved for the backward pass: sv_gates [B*T][8H] (i, f, g, o after their nonlinearities), sv_c [B*T][2H].
+hipError_t launch_bilstm_train_fwd(const float* gates, const float* whh_t, float* out, float* sv_gates, float* sv_c, int B, int T,
+                                   int H, hipStream_t s);
+// Backward through time: dout [B*T][2H] -> dgates [B*T][8H] (w.r.t. the pre-activations); whh [2][4H][H] raw weights
+hipError_t launch_bilstm_train_bwd(const float* dout, const float* sv_gates, const float* sv_c, const float* whh_fwd,
+                                   const float* whh_rev, float* dgates, int B, int T, int H, hipStream_t s);
+// hprev[d][b*T + t][H] = h of direction d at the step processed before t (zero at its first step), from out [B*T][2H]
+hipError_t launch_bilstm_hprev(const float* out, float* hprev_fwd, float* hprev_rev, int B, int T, int H, hipStream_t s);
 
 // ---- training step (train_kernels.hip) --------------------------------------
 // Weight gradient ("TN" GEMM, optional filter taps): part[z][tap][m][n] = sum_{p in chunk z} a[p][m] * x[src(p,tap)][n]
@@ -320,7 +334,7 @@ hipError_t launch_bn_bwd_apply(const float* dy, const float* y, const float* z, 
 enum { EW_COPY = 0, EW_ADD = 1, EW_RELU_BWD = 2, EW_GELU = 3, EW_GELU_BWD = 4, EW_RELU = 5 };
 hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int op, hipStream_t s);
 hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
-                              int PW, hipStream_t s);
+                              int PW, hipStream_t s, int KW = 2);
 hipError_t launch_ln_train(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
                            int D, float eps, hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
@@ -352,7 +366,7 @@ hipError_t launch_ce_bwd(const float* x, const int64_t* tgt, const float* lse, c
                          long long ignore, hipStream_t s);
 hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s);
 hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
-                              hipStream_t s);
+                              hipStream_t s, int KW = 2);
 hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s);
 hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
                          int offw, hipStream_t s);

@@ -53,7 +53,7 @@ struct TT {  // tensor on the tape
 };
 
 enum Kind { N_CONV, N_POOL, N_LINEAR, N_LN, N_ATTN, N_GELU, N_EMBED, N_TOKENS, N_ADDCONST, N_DROPOUT, N_ADD, N_LSTM, N_RELU,
-            N_GCPOOL, N_BCAST };
+            N_GCPOOL, N_BCAST, N_MEANH, N_BILSTM };
 
 struct Node {
   Kind kind;
@@ -355,13 +355,14 @@ struct Tr {  // builder / runner bound to one context and stream
     st->nodes.push_back(n);
     return D2T_OK;
   }
-  int pool(int in, int SH, int SW, int PH, int PW, int* out) {
+  int pool(int in, int SH, int SW, int PH, int PW, int* out, int KW = 2) {  // window 2 x KW
     const TT x = st->t[in];
-    const int OH = (x.H + 2 * PH - 2) / SH + 1, OW = (x.W + 2 * PW - 2) / SW + 1;
+    const int OH = (x.H + 2 * PH - 2) / SH + 1, OW = (x.W + 2 * PW - KW) / SW + 1;
     RC(new_tensor((long long)x.B * OH * OW, x.cols, out, x.B, OH, OW));
-    TCHK(launch_maxpool(x.p, st->t[*out].p, x.B, x.H, x.W, x.cols, SH, SW, PH, PW, s));
+    if (KW == 2) TCHK(launch_maxpool(x.p, st->t[*out].p, x.B, x.H, x.W, x.cols, SH, SW, PH, PW, s));
+    else TCHK(launch_maxpool_k(x.p, st->t[*out].p, x.B, x.H, x.W, x.cols, 2, KW, SH, SW, PH, PW, s));
     Node n;
-    n.kind = N_POOL; n.in = in; n.out = *out; n.SH = SH; n.SW = SW; n.PH = PH; n.PW = PW;
+    n.kind = N_POOL; n.in = in; n.out = *out; n.SH = SH; n.SW = SW; n.PH = PH; n.PW = PW; n.KW = KW;
     st->nodes.push_back(n);
     return D2T_OK;
   }
@@ -397,6 +398,112 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(conv_bn(x, p + "conv4_2", p + "bn4_2", 512, 2, 2, 1, 1, 0, 0, true, -1, &x));
     *out = x;
     return D2T_OK;
+  }
+
+  // VGG_FeatureExtractor.forward (feature_extractor/vgg.py:16-44): Conv2d(1, 64) + ReLU, pool, Conv2d(64, 128) + ReLU, pool,
+  // two convolutions + ReLU, (2,1) pool, two bias-free convolutions with BatchNorm + ReLU, (2,1) pool, a 2x2 convolution + ReLU
+  int vgg(const float* img, int B, int H, int W, const std::string& p, int* out) {
+    int x;
+    {  // first layer: one input channel, the stem kernels (weight gradient included) with a bias instead of a BatchNorm
+      const float *w, *b;
+      RC(raw(p + "0.weight", &w, (size_t)64 * 9));
+      RC(raw(p + "0.bias", &b, 64));
+      const long long P = (long long)B * H * W;
+      Node n;
+      n.kind = N_CONV; n.wkey = p + "0"; n.KH = n.KW = 3; n.PH = n.PW = 1; n.N = 64; n.K = 9; n.stem = true;
+      RC(new_tensor(P, 64, &x, B, H, W));
+      n.z = st->t[x].p;
+      TCHK(launch_stem_raw(img, w, n.z, B, H, W, 64, s));
+      TCHK(launch_bias_add(n.z, b, P, 64, s));
+      n.out = x;
+      st->nodes.push_back(n);
+      RC(relu(x, &x));
+    }
+    auto cr = [&](const char* key, const char* bn, int Cout, int k, int pad) -> int {
+      RC(conv_bn(x, p + key, bn ? p + bn : std::string(), Cout, k, k, 1, 1, pad, pad, bn != nullptr, -1, &x));
+      if (!bn) RC(relu(x, &x));
+      return D2T_OK;
+    };
+    RC(pool(x, 2, 2, 0, 0, &x));
+    RC(cr("3", nullptr, 128, 3, 1));
+    RC(pool(x, 2, 2, 0, 0, &x));
+    RC(cr("6", nullptr, 256, 3, 1));
+    RC(cr("8", nullptr, 256, 3, 1));
+    RC(pool(x, 2, 1, 0, 0, &x, 1));
+    RC(cr("11", "12", 512, 3, 1));
+    RC(cr("14", "15", 512, 3, 1));
+    RC(pool(x, 2, 1, 0, 0, &x, 1));
+    RC(cr("18", nullptr, 512, 2, 0));
+    *out = x;
+    return D2T_OK;
+  }
+  // AdaptiveAvgPool2d((None, 1)) over the height of the permuted map (recognizers/build_feat.py:50-55): [B,H,W,C] -> [B,W,C]
+  int mean_h(int in, int* out) {
+    const TT x = st->t[in];
+    RC(new_tensor((long long)x.B * x.W, x.cols, out, x.B, 1, x.W));
+    TCHK(launch_mean_h(x.p, st->t[*out].p, x.B, x.H, x.W, x.cols, s));
+    Node n;
+    n.kind = N_MEANH; n.in = in; n.out = *out;
+    st->nodes.push_back(n);
+    return D2T_OK;
+  }
+  // BidirectionalLSTM (seq_modeling/bilstm.py:14-24): nn.LSTM(bidirectional, batch_first) + Linear(2H -> H).  The input
+  // projection of both directions is one GEMM on the engine's packed copies (c->lstm[i]: finalized weights).
+  int bilstm(int in, int layer, const std::string& key, int B, int T, int* out) {
+    const TT x = st->t[in];
+    const int Hh = c->cfg.bilstm_hidden;
+    const BiLstmW& L = c->lstm[layer];
+    if (!c->finalized || !L.wih_cat || x.cols != L.in) return fail(c, D2T_ESTATE, "BiLSTM weights are not finalized");
+    Node n;
+    n.kind = N_BILSTM; n.in = in; n.wkey = key + "rnn."; n.nb = B; n.Lq = T; n.K = L.in; n.woff = layer;
+    float* gates;
+    RC(alloc(&gates, (size_t)B * T * 8 * Hh));
+    RC(gemm_nt(x.p, L.wih_cat, L.bias_cat, nullptr, gates, (long long)B * T, 8 * Hh, L.in, ACT_NONE));
+    RC(alloc(&n.aux[0], (size_t)B * T * 8 * Hh));  // gates after their nonlinearities
+    RC(alloc(&n.aux[1], (size_t)B * T * 2 * Hh));  // cell states
+    int rec;
+    RC(new_tensor((long long)B * T, 2 * Hh, &rec));
+    TCHK(launch_bilstm_train_fwd(gates, L.whh_t, st->t[rec].p, n.aux[0], n.aux[1], B, T, Hh, s));
+    n.out = rec;
+    st->nodes.push_back(n);
+    return linear(rec, key + "linear", Hh, 2 * Hh, 0, ACT_NONE, -1, out);
+  }
+  int bwd_bilstm(const Node& n) {
+    const int B = n.nb, T = n.Lq, Hh = c->cfg.bilstm_hidden, in = n.K;
+    const long long R = (long long)B * T;
+    const TT& x = st->t[n.in];
+    const TT& rec = st->t[n.out];
+    const float *whh_f, *whh_r;
+    RC(raw(n.wkey + "weight_hh_l0", &whh_f, (size_t)4 * Hh * Hh));
+    RC(raw(n.wkey + "weight_hh_l0_reverse", &whh_r, (size_t)4 * Hh * Hh));
+    float *dgates, *hpf, *hpr;
+    RC(alloc(&dgates, (size_t)R * 8 * Hh));
+    TCHK(launch_bilstm_train_bwd(rec.grad, n.aux[0], n.aux[1], whh_f, whh_r, dgates, B, T, Hh, s));
+    RC(alloc(&hpf, (size_t)R * Hh));
+    RC(alloc(&hpr, (size_t)R * Hh));
+    TCHK(launch_bilstm_hprev(rec.p, hpf, hpr, B, T, Hh, s));
+    float *bsum, *g;
+    RC(alloc(&bsum, (size_t)8 * Hh));
+    RC(colsum(dgates, R, 8 * Hh, bsum));
+    const char* sfx[2] = {"", "_reverse"};
+    for (int d = 0; d < 2; ++d) {
+      const float* dg = dgates + (size_t)d * 4 * Hh;
+      RC(grad_buf(n.wkey + "weight_ih_l0" + sfx[d], &g));
+      RC(wgrad(dg, 8 * Hh, x.p, in, R, 4 * Hh, in, 1, nullptr, nullptr, nullptr, g, 0));
+      RC(grad_buf(n.wkey + "weight_hh_l0" + sfx[d], &g));
+      RC(wgrad(dg, 8 * Hh, d == 0 ? hpf : hpr, Hh, R, 4 * Hh, Hh, 1, nullptr, nullptr, nullptr, g, 0));
+      RC(grad_buf(n.wkey + "bias_ih_l0" + sfx[d], &g));
+      TCHK(launch_copy(bsum + (size_t)d * 4 * Hh, g, (size_t)4 * Hh, s));
+      RC(grad_buf(n.wkey + "bias_hh_l0" + sfx[d], &g));
+      TCHK(launch_copy(bsum + (size_t)d * 4 * Hh, g, (size_t)4 * Hh, s));
+    }
+    // dx = dgates @ [W_ih ; W_ih_reverse]  ([R][8H] x [8H][in]): the packed matrix transposed is the "weight" of an NT GEMM
+    float *wt, *dx;
+    RC(alloc(&wt, (size_t)8 * Hh * in));
+    TCHK(launch_transpose(c->lstm[n.woff].wih_cat, wt, 8 * Hh, in, s));
+    RC(alloc(&dx, (size_t)R * in));
+    RC(gemm_nt(dgates, wt, nullptr, nullptr, dx, R, in, 8 * Hh, ACT_NONE));
+    return add_grad(n.in, dx);
   }
 
   // out = act(in @ W[woff:woff+N]^T + b[woff:woff+N]) + res;  `into`: write the result into caller memory
@@ -498,7 +605,7 @@ struct Tr {  // builder / runner bound to one context and stream
 
   int relu(int in, int* out) {
     const TT x = st->t[in];
-    RC(new_tensor(x.rows, x.cols, out));
+    RC(new_tensor(x.rows, x.cols, out, x.B, x.H, x.W));
     TCHK(launch_ew(x.p, nullptr, st->t[*out].p, (size_t)x.rows * x.cols, EW_RELU, s));
     Node n;
     n.kind = N_RELU; n.in = in; n.out = *out; n.relu = true;
@@ -658,8 +765,6 @@ struct Tr {  // builder / runner bound to one context and stream
     const d2t_config& g = c->cfg;
     const int Hh = g.attn_hidden, V = g.vocab, T = (int)(st->t[mem].rows / B);
     const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0, Tk = T - key_off;
-    if (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN)
-      return fail(c, D2T_ESTATE, "training the Attn head on a BiLSTM encoder is not implemented");
     if (!c->finalized) return fail(c, D2T_ESTATE, "the Attn training step needs finalized weights");
     int kp;
     RC(linear(mem, "predicter.Prediction.attention_cell.attn.key_proj", Hh, Hh, 0, ACT_NONE, -1, &kp));
@@ -694,7 +799,8 @@ struct Tr {  // builder / runner bound to one context and stream
     }
     AttnDecP p{};
     p.mem = st->t[mem].p; p.T = T; p.D = Hh; p.key_off = key_off;
-    p.init_mode = !g.attn_enc_init ? 0 : 2;
+    p.init_mode = !g.attn_enc_init ? 0 : (g.attn_keys == D2T_ATTN_KEYS_ALL_INIT_MEAN ? 1 : 2);
+    n.causal = p.init_mode;  // (the field is free in this node kind) how the initial state was formed, for the backward pass
     p.kp = st->t[kp].p; p.wq_t = c->attn.wq_t; p.bq = c->attn.bq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
     p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
     p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
@@ -789,22 +895,44 @@ struct Tr {  // builder / runner bound to one context and stream
     TCHK(launch_loc_unfold_bwd(dwloc, dbloc, B, cw, cb, pw, Hh, kd, taps, gcw, gcb, gpw, gpb, s));
     RC(grad_buf(pp + "embedding.weight", &gW));
     TCHK(launch_embed_bwd(demb, n.keytok, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
-    if (g.attn_enc_init) {  // h0 / c0 = proj_init_{h,c}(memory[:, 0])
+    if (g.attn_enc_init) {  // h0 / c0 = proj_init_{h,c}(memory[:, 0]) or, on a BiLSTM encoder, of the mean over the tokens
+      const bool mean = n.causal == 1;
+      const float* initv = mem.p;  // row b = memory[b][0] with a row stride of T * Hh
+      int ldi = T * Hh;
+      if (mean) {
+        float *sums, *mv;
+        RC(alloc(&sums, (size_t)B * Hh));
+        RC(alloc(&mv, (size_t)B * Hh));
+        RC(ensure_part((size_t)B * GC_CHUNKS * Hh));
+        TCHK(launch_gc_wpool(mem.p, nullptr, st->part, sums, B, T, Hh, s));
+        TCHK(launch_scale(sums, mv, (size_t)B * Hh, 1.f / T, s));
+        initv = mv;
+        ldi = Hh;
+      }
       RC(grad_buf(pp + "proj_init_h.weight", &gW));
       RC(grad_buf(pp + "proj_init_h.bias", &gB));
-      RC(wgrad(dh0, Hh, mem.p, T * Hh, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+      RC(wgrad(dh0, Hh, initv, ldi, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
       RC(colsum(dh0, B, Hh, gB));
       RC(grad_buf(pp + "proj_init_c.weight", &gW));
       RC(grad_buf(pp + "proj_init_c.bias", &gB));
-      RC(wgrad(dc0, Hh, mem.p, T * Hh, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+      RC(wgrad(dc0, Hh, initv, ldi, B, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
       RC(colsum(dc0, B, Hh, gB));
       float *t1, *dinit;
       RC(alloc(&t1, (size_t)B * Hh));
       RC(alloc(&dinit, (size_t)B * Hh));
       RC(gemm_nt(dh0, c->attn.wih_t, nullptr, nullptr, t1, B, Hh, Hh, ACT_NONE));
       RC(gemm_nt(dc0, c->attn.wic_t, nullptr, t1, dinit, B, Hh, Hh, ACT_NONE));
-      for (int b = 0; b < B; ++b)
-        TCHK(launch_add_rows(dmem + (size_t)b * T * Hh, dinit + (size_t)b * Hh, dmem + (size_t)b * T * Hh, Hh, s));
+      if (mean) {  // every token carries 1 / T of the initial state's gradient
+        float *dsc, *dmem2;
+        RC(alloc(&dsc, (size_t)B * Hh));
+        TCHK(launch_scale(dinit, dsc, (size_t)B * Hh, 1.f / T, s));
+        RC(alloc(&dmem2, (size_t)mem.rows * mem.cols));
+        TCHK(launch_gc_bcast_add(dmem, dsc, dmem2, B, T, Hh, s));
+        dmem = dmem2;
+      } else {
+        for (int b = 0; b < B; ++b)
+          TCHK(launch_add_rows(dmem + (size_t)b * T * Hh, dinit + (size_t)b * Hh, dmem + (size_t)b * T * Hh, Hh, s));
+      }
     }
     RC(add_grad(n.in, dmem));
     RC(add_grad(n.in2, dkp));
@@ -969,7 +1097,7 @@ struct Tr {  // builder / runner bound to one context and stream
     const TT& x = st->t[n.in];
     float* dx;
     RC(alloc(&dx, (size_t)x.rows * x.cols));
-    TCHK(launch_maxpool_bwd(x.p, st->t[n.out].grad, dx, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, s));
+    TCHK(launch_maxpool_bwd(x.p, st->t[n.out].grad, dx, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, s, n.KW));
     return add_grad(n.in, dx);
   }
   int bwd_tokens(const Node& n) {
@@ -1015,6 +1143,15 @@ struct Tr {  // builder / runner bound to one context and stream
             g = cp;
           }
           RC(add_grad(n.in2, g));
+          break;
+        }
+        case N_BILSTM: RC(bwd_bilstm(n)); break;
+        case N_MEANH: {
+          const TT& x = st->t[n.in];
+          float* dx;
+          RC(alloc(&dx, (size_t)x.rows * x.cols));
+          TCHK(launch_mean_h_bwd(st->t[n.out].grad, dx, x.B, x.H, x.W, x.cols, s));
+          RC(add_grad(n.in, dx));
           break;
         }
         case N_RELU: {
@@ -1100,9 +1237,9 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
   const d2t_config& g = c->cfg;
   const bool lstm = g.decoder == D2T_DEC_ATTN;
-  if (g.encoder != D2T_ENC_HYBRID_VIT && g.encoder != D2T_ENC_RESNET)
-    return fail(c, D2T_ESTATE, "the training step is implemented for the HybridViT and ResNet+None encoders");
-  if (lstm && g.encoder != D2T_ENC_HYBRID_VIT) return fail(c, D2T_ESTATE, "the Attn training step needs the HybridViT encoder");
+  const bool lstm_enc = g.encoder == D2T_ENC_VGG_BILSTM || g.encoder == D2T_ENC_RESNET_BILSTM;
+  if (lstm && g.encoder == D2T_ENC_RESNET) return fail(c, D2T_ESTATE, "the Attn training step needs the HybridViT or a BiLSTM encoder");
+  if (!lstm && lstm_enc) return fail(c, D2T_ESTATE, "the BiLSTM encoders train with the Attn / Attnv2 heads");
   if (lstm && L != g.batch_max_length + 1) return fail(c, D2T_EINVAL, "the Attn head trains on batch_max_length + 1 = %d steps", g.batch_max_length + 1);
   if (!lstm && L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
   if (lstm && (g.attn_cell != D2T_ATTN_CELL_LOCATION || g.attn_onehot))
@@ -1123,6 +1260,15 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
     const std::string sp = "seqmodeler.SequenceModeling.";
     RC(tr.backbone(image, B, H, W, sp + "patch_embed.backbone.ConvNet.", &feat));
     RC(tr.vit(feat, sp, &mem, nullptr));
+  } else if (lstm_enc) {  // VGG | ResNet -> mean over the height -> 2 x BidirectionalLSTM (build_feat.py:50-55, build_seq.py)
+    const std::string fp = "featextractor.FeatureExtraction.ConvNet.";
+    if (g.encoder == D2T_ENC_VGG_BILSTM) RC(tr.vgg(image, B, H, W, fp, &feat));
+    else RC(tr.backbone(image, B, H, W, fp, &feat));
+    int seq;
+    RC(tr.mean_h(feat, &seq));
+    const int T = st->t[feat].W;
+    RC(tr.bilstm(seq, 0, "seqmodeler.SequenceModeling.0.", B, T, &seq));
+    RC(tr.bilstm(seq, 1, "seqmodeler.SequenceModeling.1.", B, T, &mem));
   } else {  // Feat=ResNet, Seq=None: + PositionalEncoding2D, [B,C,H,W] -> [B,HW,C] (already the NHWC row layout)
     RC(tr.backbone(image, B, H, W, "featextractor.FeatureExtraction.ConvNet.", &feat));
     const TT f = st->t[feat];
@@ -1287,7 +1433,7 @@ int d2t_train_read_decision(d2t_ctx* c, int32_t index, uint8_t* dst, int64_t num
     if (numel != ne) return fail(c, D2T_EINVAL, "decision %d has %lld elements", index, (long long)ne);
     if (n.kind == N_POOL) {
       const TT& x = st->t[n.in];
-      HIPCHK(c, launch_pool_argmax(x.p, dst, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, (hipStream_t)stream));
+      HIPCHK(c, launch_pool_argmax(x.p, dst, x.B, x.H, x.W, x.cols, n.SH, n.SW, n.PH, n.PW, (hipStream_t)stream, n.KW));
     } else {
       HIPCHK(c, launch_relu_mask(y.p, dst, (size_t)ne, (hipStream_t)stream));
     }

@@ -548,7 +548,7 @@ hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int o
 // FIRST maximum (scan order kh, kw; padding = -inf) it is -- the rule of torch's max_pool2d_with_indices.
 // ---------------------------------------------------------------------------
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B,
-                                   int H, int W, int C, int OH, int OW, int SH, int SW, int PH, int PW) {
+                                   int H, int W, int C, int OH, int OW, int SH, int SW, int PH, int PW, int KW) {
   const size_t total = (size_t)B * H * W * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -556,13 +556,13 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     float acc = 0.f;
     // windows (oh, ow) that contain (h, w): oh*SH - PH <= h <= oh*SH - PH + 1
     const int oh_lo = h + PH - 1 > 0 ? (h + PH - 1 + SH - 1) / SH : 0, oh_hi = min((h + PH) / SH, OH - 1);
-    const int ow_lo = w + PW - 1 > 0 ? (w + PW - 1 + SW - 1) / SW : 0, ow_hi = min((w + PW) / SW, OW - 1);
+    const int ow_lo = w + PW - (KW - 1) > 0 ? (w + PW - (KW - 1) + SW - 1) / SW : 0, ow_hi = min((w + PW) / SW, OW - 1);
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         float best = -INFINITY;
         int bh = -1, bw = -1;
         for (int kh = 0; kh < 2; ++kh)
-          for (int kw = 0; kw < 2; ++kw) {
+          for (int kw = 0; kw < KW; ++kw) {
             const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
             if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
             const float v = x[(((size_t)b * H + ih) * W + iw) * C + c];
@@ -574,11 +574,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
   }
 }
 hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
-                              int PW, hipStream_t s) {
-  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+                              int PW, hipStream_t s, int KW) {  // window 2 x KW (KW = 1: VGG's (2,1) pools)
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
   const size_t total = (size_t)B * H * W * C;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, x,
-                     dy, dx, B, H, W, C, OH, OW, SH, SW, PH, PW);
+                     dy, dx, B, H, W, C, OH, OW, SH, SW, PH, PW, KW);
   return hipGetLastError();
 }
 
@@ -647,7 +647,7 @@ hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s)
   return hipGetLastError();
 }
 __global__ void pool_argmax_kernel(const float* __restrict__ x, uint8_t* __restrict__ k, int B, int H, int W, int C, int OH,
-                                   int OW, int SH, int SW, int PH, int PW) {
+                                   int OW, int SH, int SW, int PH, int PW, int KW) {
   const size_t total = (size_t)B * OH * OW * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -655,21 +655,21 @@ __global__ void pool_argmax_kernel(const float* __restrict__ x, uint8_t* __restr
     float best = -INFINITY;
     int bk = -1;
     for (int kh = 0; kh < 2; ++kh)
-      for (int kw = 0; kw < 2; ++kw) {
+      for (int kw = 0; kw < KW; ++kw) {
         const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
         if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
         const float v = x[(((size_t)b * H + ih) * W + iw) * C + c];
-        if (v > best || bk < 0) { best = v; bk = kh * 2 + kw; }
+        if (v > best || bk < 0) { best = v; bk = kh * KW + kw; }
       }
     k[i] = (uint8_t)bk;
   }
 }
 hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
-                              hipStream_t s) {
-  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
+                              hipStream_t s, int KW) {
+  const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
   const size_t total = (size_t)B * OH * OW * C;
   hipLaunchKernelGGL(pool_argmax_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, x, k,
-                     B, H, W, C, OH, OW, SH, SW, PH, PW);
+                     B, H, W, C, OH, OW, SH, SW, PH, PW, KW);
   return hipGetLastError();
 }
 
@@ -1224,19 +1224,20 @@ hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, in
   return hipGetLastError();
 }
 // part[chunk][tap][co]: chunked over pixels; reduced by launch_wgrad_reduce with M = Cout, N = 1 ... (taps = 9)
+template <int CO>  // output channels: 32 (ResNet conv0_1) or 64 (VGG's first convolution)
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ dz,
-                                                         float* __restrict__ part, int B, int H, int W, int Cout,
-                                                         int chunk) {
-  // thread -> (co = tid % Cout, pixel lane = tid / Cout); Cout == 32 -> 8 pixel lanes
-  __shared__ float red[8][9][32];
-  const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+                                                         float* __restrict__ part, int B, int H, int W, int chunk) {
+  // thread -> (co = tid % CO, pixel lane = tid / CO)
+  constexpr int NPL = 256 / CO;
+  __shared__ float red[NPL][9][CO];
+  const int co = threadIdx.x % CO, pl = threadIdx.x / CO;
   const long long P = (long long)B * H * W;
   const long long r0 = (long long)blockIdx.x * chunk, r1 = r0 + chunk < P ? r0 + chunk : P;
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (long long r = r0 + pl; r < r1; r += 8) {
+  for (long long r = r0 + pl; r < r1; r += NPL) {
     const int x = (int)(r % W), y = (int)((r / W) % H);
     const long long b = r / ((long long)W * H);
-    const float g = dz[(size_t)r * Cout + co];
+    const float g = dz[(size_t)r * CO + co];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -1249,18 +1250,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < 9; ++t) red[pl][t][co] = acc[t];
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * 32; i += 256) {
-    const int t = i / 32, c = i % 32;
+  for (int i = threadIdx.x; i < 9 * CO; i += 256) {
+    const int t = i / CO, c = i % CO;
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += red[k][t][c];
-    part[((size_t)blockIdx.x * 9 + t) * Cout + c] = v;  // [chunk][tap][co] == wgrad partial layout with M = Cout, N = 1
+    for (int k = 0; k < NPL; ++k) v += red[k][t][c];
+    part[((size_t)blockIdx.x * 9 + t) * CO + c] = v;  // [chunk][tap][co] == wgrad partial layout with M = Cout, N = 1
   }
 }
 hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int B, int H, int W, int Cout, int chunk,
                              int nchunks, hipStream_t s) {
-  if (Cout != 32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, Cout, chunk);
+  if (Cout == 32) hipLaunchKernelGGL(stem_wgrad_kernel<32>, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, chunk);
+  else if (Cout == 64) hipLaunchKernelGGL(stem_wgrad_kernel<64>, dim3(nchunks), dim3(256), 0, s, img, dz, part, B, H, W, chunk);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -1420,6 +1422,183 @@ hipError_t launch_gc_pool_bwd_dx(const float* a, const float* dl, const float* d
                                  int C, hipStream_t s) {
   const size_t n4 = (size_t)B * HW * C / 4;
   hipLaunchKernelGGL(gc_pool_bwd_dx_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, a, dl, dctx, wg, dx, n4, HW, C);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// VGG + BidirectionalLSTM encoder in the training step
+// ---------------------------------------------------------------------------
+__global__ void bias_add_kernel(float* __restrict__ z, const float* __restrict__ bias, size_t n4, int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    float4 v = reinterpret_cast<float4*>(z)[i];
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    reinterpret_cast<float4*>(z)[i] = v;
+  }
+}
+hipError_t launch_bias_add(float* z, const float* bias, long long rows, int C, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)rows * C / 4;
+  hipLaunchKernelGGL(bias_add_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, s, z, bias, n4, C);
+  return hipGetLastError();
+}
+__global__ void scale_kernel(const float* __restrict__ a, float* __restrict__ out, size_t n, float alpha) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = alpha * a[i];
+}
+hipError_t launch_scale(const float* a, float* out, size_t n, float alpha, hipStream_t s) {
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid((n + 3) / 4)), dim3(EW_THREADS), 0, s, a, out, n, alpha);
+  return hipGetLastError();
+}
+__global__ void mean_h_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t total, int H, int W, int C, float inv) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C), w = (int)((i / C) % W);
+    const size_t b = i / ((size_t)C * W * H);
+    dx[i] = dy[(b * W + w) * C + c] * inv;
+  }
+}
+hipError_t launch_mean_h_bwd(const float* dy, float* dx, int B, int H, int W, int C, hipStream_t s) {
+  const size_t total = (size_t)B * H * W * C;
+  hipLaunchKernelGGL(mean_h_bwd_kernel, dim3(ew_grid((total + 3) / 4)), dim3(EW_THREADS), 0, s, dy, dx, total, H, W, C, 1.f / H);
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+constexpr int BL_RB = 4;  // batch rows per block, as the inference kernel (recurrent.hip)
+
+// grid (2 directions, ceil(B / 4)); 1024 threads = the 4H gate rows (H = 256); the same arithmetic as bilstm_kernel
+__global__ __launch_bounds__(1024) void bilstm_train_fwd_kernel(const float* __restrict__ g, const float* __restrict__ whh_t,
+                                                                float* __restrict__ out, float* __restrict__ sv_gates,
+                                                                float* __restrict__ sv_c, int B, int T, int H) {
+  __shared__ float h_s[BL_RB][256], c_s[BL_RB][256], gate_s[BL_RB][1024];
+  const int dir = blockIdx.x, b0 = blockIdx.y * BL_RB, r = threadIdx.x;
+  const int G4 = 4 * H;
+  const float* Wt = whh_t + (size_t)dir * H * G4;
+  for (int i = r; i < BL_RB * H; i += 1024) { (&h_s[0][0])[i] = 0.f; (&c_s[0][0])[i] = 0.f; }
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    float acc[BL_RB];
+#pragma unroll
+    for (int b = 0; b < BL_RB; ++b) acc[b] = (b0 + b < B) ? g[((size_t)(b0 + b) * T + t) * (2 * G4) + dir * G4 + r] : 0.f;
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) {
+      const float w = Wt[(size_t)k * G4 + r];
+#pragma unroll
+      for (int b = 0; b < BL_RB; ++b) acc[b] = fmaf(h_s[b][k], w, acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < BL_RB; ++b) gate_s[b][r] = acc[b];
+    __syncthreads();
+    {
+      const int b = r >> 8, j = r & 255;
+      if (b0 + b < B) {
+        const float ig = sigm(gate_s[b][j]), fg = sigm(gate_s[b][H + j]);
+        const float gg = tanhf(gate_s[b][2 * H + j]), og = sigm(gate_s[b][3 * H + j]);
+        const float cc = fg * c_s[b][j] + ig * gg;
+        const float hh = og * tanhf(cc);
+        c_s[b][j] = cc;
+        h_s[b][j] = hh;
+        const size_t row = (size_t)(b0 + b) * T + t;
+        out[row * (2 * H) + dir * H + j] = hh;
+        float* sg = sv_gates + row * (2 * G4) + dir * G4;
+        sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gg; sg[3 * H + j] = og;
+        sv_c[row * (2 * H) + dir * H + j] = cc;
+      }
+    }
+    __syncthreads();
+  }
+}
+hipError_t launch_bilstm_train_fwd(const float* gates, const float* whh_t, float* out, float* sv_gates, float* sv_c, int B, int T,
+                                   int H, hipStream_t s) {
+  if (H != 256 || B < 1 || T < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bilstm_train_fwd_kernel, dim3(2, (B + BL_RB - 1) / BL_RB), dim3(1024), 0, s, gates, whh_t, out, sv_gates, sv_c,
+                     B, T, H);
+  return hipGetLastError();
+}
+
+// Backward through time, same grid.  Per step (reverse processing order): phase 1, thread = (row, hidden unit): the cell's
+// gradients and the pre-activation gate gradients (kept in LDS and written out); phase 2, thread = (quarter of the 4H gate
+// rows, hidden unit k): dh_prev[b][k] = sum_r dgate[b][r] W_hh[r][k] for the block's four rows, each weight read once.
+__global__ __launch_bounds__(1024) void bilstm_train_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ sv_gates,
+                                                                const float* __restrict__ sv_c, const float* __restrict__ whh_fwd,
+                                                                const float* __restrict__ whh_rev, float* __restrict__ dgates,
+                                                                int B, int T, int H) {
+  __shared__ float dh_s[BL_RB][256], dc_s[BL_RB][256], dg_s[BL_RB][1024], part_s[4][BL_RB][256];
+  const int dir = blockIdx.x, b0 = blockIdx.y * BL_RB, tid = threadIdx.x;
+  const int G4 = 4 * H;
+  const float* W = dir == 0 ? whh_fwd : whh_rev;  // [4H][H]
+  for (int i = tid; i < BL_RB * H; i += 1024) { (&dh_s[0][0])[i] = 0.f; (&dc_s[0][0])[i] = 0.f; }
+  __syncthreads();
+  for (int step = T - 1; step >= 0; --step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;  // the step processed before t (none when step == 0)
+    {
+      const int b = tid >> 8, j = tid & 255;
+      float di = 0.f, df = 0.f, dgg = 0.f, dop = 0.f;
+      if (b0 + b < B) {
+        const size_t row = (size_t)(b0 + b) * T + t;
+        const float* sg = sv_gates + row * (2 * G4) + dir * G4;
+        const float ig = sg[j], fg = sg[H + j], gg = sg[2 * H + j], og = sg[3 * H + j];
+        const float cc = sv_c[row * (2 * H) + dir * H + j];
+        const float cp = step > 0 ? sv_c[((size_t)(b0 + b) * T + tp) * (2 * H) + dir * H + j] : 0.f;
+        const float dh = dout[row * (2 * H) + dir * H + j] + dh_s[b][j];
+        const float tc = tanhf(cc);
+        const float dc = dc_s[b][j] + dh * og * (1.f - tc * tc);
+        di = dc * gg * ig * (1.f - ig);
+        df = dc * cp * fg * (1.f - fg);
+        dgg = dc * ig * (1.f - gg * gg);
+        dop = dh * tc * og * (1.f - og);
+        dc_s[b][j] = dc * fg;
+        float* o = dgates + row * (2 * G4) + dir * G4;
+        o[j] = di; o[H + j] = df; o[2 * H + j] = dgg; o[3 * H + j] = dop;
+      }
+      dg_s[b][j] = di; dg_s[b][H + j] = df; dg_s[b][2 * H + j] = dgg; dg_s[b][3 * H + j] = dop;
+    }
+    __syncthreads();
+    {
+      const int q = tid >> 8, k = tid & 255;
+      float acc[BL_RB];
+#pragma unroll
+      for (int b = 0; b < BL_RB; ++b) acc[b] = 0.f;
+      const int r0 = q * 256;
+#pragma unroll 8
+      for (int r = r0; r < r0 + 256; ++r) {
+        const float w = W[(size_t)r * H + k];
+#pragma unroll
+        for (int b = 0; b < BL_RB; ++b) acc[b] = fmaf(dg_s[b][r], w, acc[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < BL_RB; ++b) part_s[q][b][k] = acc[b];
+    }
+    __syncthreads();
+    {
+      const int b = tid >> 8, k = tid & 255;
+      dh_s[b][k] = (part_s[0][b][k] + part_s[1][b][k]) + (part_s[2][b][k] + part_s[3][b][k]);
+    }
+    __syncthreads();
+  }
+}
+hipError_t launch_bilstm_train_bwd(const float* dout, const float* sv_gates, const float* sv_c, const float* whh_fwd,
+                                   const float* whh_rev, float* dgates, int B, int T, int H, hipStream_t s) {
+  if (H != 256 || B < 1 || T < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bilstm_train_bwd_kernel, dim3(2, (B + BL_RB - 1) / BL_RB), dim3(1024), 0, s, dout, sv_gates, sv_c, whh_fwd,
+                     whh_rev, dgates, B, T, H);
+  return hipGetLastError();
+}
+__global__ void bilstm_hprev_kernel(const float* __restrict__ out, float* __restrict__ hf, float* __restrict__ hr, int B, int T,
+                                    int H) {
+  const size_t total = (size_t)B * T * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H), t = (int)((i / H) % T);
+    const size_t b = i / ((size_t)H * T);
+    hf[i] = t > 0 ? out[((b * T + t - 1) * 2) * H + j] : 0.f;
+    hr[i] = t + 1 < T ? out[((b * T + t + 1) * 2 + 1) * H + j] : 0.f;
+  }
+}
+hipError_t launch_bilstm_hprev(const float* out, float* hprev_fwd, float* hprev_rev, int B, int T, int H, hipStream_t s) {
+  const size_t total = (size_t)B * T * H;
+  hipLaunchKernelGGL(bilstm_hprev_kernel, dim3(ew_grid((total + 3) / 4)), dim3(EW_THREADS), 0, s, out, hprev_fwd, hprev_rev, B, T, H);
   return hipGetLastError();
 }
 

@@ -419,16 +419,17 @@ def tfm_beam(mem, sd, p, layers, heads, max_seq_len, beam_size):
 ATTN_GO, ATTN_END = 0, 1  # modules/converter/attn_converter.py:8,19-29
 
 
-def vgg(x, sd, p, faithful=True):
-    """VGG_FeatureExtractor.forward, feature_extractor/vgg.py:16-44 (p = '...ConvNet.')."""
+def vgg(x, sd, p, faithful=True, bn_train=None):
+    """VGG_FeatureExtractor.forward, feature_extractor/vgg.py:16-44 (p = '...ConvNet.'); bn_train: module.train() batch
+    statistics for its two BatchNorm layers (as _bn)."""
     c = lambda x, i, pad=1: F.conv2d(x, sd[f"{p}{i}.weight"], sd.get(f"{p}{i}.bias"), 1, pad)
     x = F.max_pool2d(F.relu(c(x, 0)), 2, 2)
     x = F.max_pool2d(F.relu(c(x, 3)), 2, 2)
     x = F.relu(c(x, 6))
     x = F.max_pool2d(F.relu(c(x, 8)), (2, 1), (2, 1))
     for conv, bn in ((11, 12), (14, 15)):
-        if faithful:
-            x = F.relu(_bn(c(x, conv), sd, f"{p}{bn}"))
+        if faithful or bn_train is not None:
+            x = F.relu(_bn(c(x, conv), sd, f"{p}{bn}", bn_train=bn_train))
         else:
             wf, bf = fold_bn(sd[f"{p}{conv}.weight"], sd, f"{p}{bn}")
             x = F.relu(F.conv2d(x, wf, bf, 1, 1))
@@ -446,8 +447,8 @@ def bilstm(x, sd, p):
         wi, wh = sd[f"{p}rnn.weight_ih_l0{sfx}"], sd[f"{p}rnn.weight_hh_l0{sfx}"]
         bi, bh = sd[f"{p}rnn.bias_ih_l0{sfx}"], sd[f"{p}rnn.bias_hh_l0{sfx}"]
         H = wh.shape[1]
-        h = torch.zeros(B, H)
-        c = torch.zeros(B, H)
+        h = torch.zeros(B, H, dtype=x.dtype)
+        c = torch.zeros(B, H, dtype=x.dtype)
         out = [None] * T
         for t in order:
             g = F.linear(x[:, t], wi, bi) + F.linear(h, wh, bh)
@@ -655,8 +656,10 @@ def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None, dro
         return x, shape, pad_info
     if seq["name"] == "BiLSTM":
         # Feat=VGG|ResNet -> AdaptiveAvgPool2d((None,1)) over the height (build_feat.py:50-55) -> 2x BiLSTM
-        fe = resnet if cfg["FeatureExtraction"]["name"] == "ResNet" else vgg
-        f = fe(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful)
+        if cfg["FeatureExtraction"]["name"] == "ResNet":
+            f = resnet(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful, bn_train, drop)
+        else:
+            f = vgg(image, sd, "featextractor.FeatureExtraction.ConvNet.", faithful, bn_train)
         if taps is not None:
             taps["backbone"] = f
         x = f.permute(0, 3, 1, 2).mean(dim=3)  # [B,W,C]

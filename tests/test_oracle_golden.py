@@ -148,7 +148,7 @@ def gc_drop_from_seed(seed):
 
 
 @pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step", "c3_train_step", "t2g_train_step",
-                                  "t1g_train_step"])
+                                  "t1g_train_step", "c0_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
     reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""

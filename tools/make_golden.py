@@ -112,7 +112,9 @@ TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_tra
                     # 8256 pixels per BatchNorm channel in the deepest stage instead of ~100 in the toys above)
                     ("c3_train_step", "C3", 4, 128, 512, 150, 1234, 1033),
                     # GlobalContext blocks on (gcb: True): the two TFM stacks
-                    ("t2g_train_step", "T2G", 3, 48, 64, 24, 1234, 1034), ("t1g_train_step", "T1G", 2, 32, 64, 22, 1234, 1035)]
+                    ("t2g_train_step", "T2G", 3, 48, 64, 24, 1234, 1034), ("t1g_train_step", "T1G", 2, 32, 64, 22, 1234, 1035),
+                    # BASELINE configs[0]'s stack in training: VGG + 2x BidirectionalLSTM + Attn (coverage cell, init from the mean)
+                    ("c0_train_step", "C0", 3, 32, 160, 24, 1234, 1036)]
 LOGIT_STRIDE = {"c3_train_step": 8}  # store every 8th position of the [B, 151, V] logits (fixture size)
 GRAD_SAMPLES = 48
 GC_MASK_SEED = 99  # seeded keep masks of the GlobalContext blocks' dropout in the *g_train_step fixtures
@@ -600,7 +602,7 @@ def main():
         with open(os.path.join(GOLD, "cases.json")) as f:
             summary = json.load(f)
         for case in TRAIN_STEP_CASES:
-            if case[0] not in ("t2g_train_step", "t1g_train_step"):
+            if case[0] not in os.environ.get("GOLDEN_CASES", "t2g_train_step,t1g_train_step").split(","):
                 continue
             rep = run_train_step(case)
             summary["train_step"] = [r for r in summary["train_step"] if r["case"] != rep["case"]] + [rep]
