@@ -337,10 +337,6 @@ class Model(nn.Module):
             else:  # Attn / Attnv2
                 if self.stages["Seq"] not in ("ViT", "BiLSTM"):
                     raise NotImplementedError("training the LSTM-attention head is implemented on the HybridViT and BiLSTM encoders")
-                pp = self.opt["Prediction"]["params"]
-                if pp.get("attn_type", "coverage") not in ("coverage", "loc_aware") or not pp.get("embed_target", False):
-                    raise NotImplementedError("training the LSTM-attention head is implemented for the location-aware cells "
-                                              "(attn_type 'coverage' / 'loc_aware') with embed_target: True")
             logits = train_forward(self, input, text)
             return logits.argmax(dim=2), logits, {}
         contextual_feature, output_shape, feat_pad = self.forward_encoder(input)

@@ -368,6 +368,7 @@ hipError_t launch_relu_mask(const float* y, uint8_t* m, size_t n, hipStream_t s)
 hipError_t launch_pool_argmax(const float* x, uint8_t* k, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
                               hipStream_t s, int KW = 2);
 hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, int Cd, hipStream_t s);
+hipError_t launch_copy2d(const float* src, int lds, float* dst, int ldd, size_t rows, int cols, hipStream_t s);
 hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, int C, int DH, int DW, int SH, int SW, int offh,
                          int offw, hipStream_t s);
 hipError_t launch_flip_oihw(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);

@@ -66,6 +66,7 @@ struct Node {
   // N_LINEAR: out = act(in @ W[woff : woff+N]^T + b) (+ in2)
   std::string bkey;
   int N = 0, K = 0, woff = 0;
+  bool nobias = false;  // nn.Linear(..., bias=False)
   // N_LN
   std::string gkey;
   float eps = 0.f;
@@ -507,16 +508,18 @@ struct Tr {  // builder / runner bound to one context and stream
   }
 
   // out = act(in @ W[woff:woff+N]^T + b[woff:woff+N]) + res;  `into`: write the result into caller memory
-  int linear(int in, const std::string& key, int N, int K, int woff, int act, int res, int* out, float* into = nullptr) {
+  int linear(int in, const std::string& key, int N, int K, int woff, int act, int res, int* out, float* into = nullptr,
+             bool bias = true) {
     const TT x = st->t[in];
     if (x.cols != K) return fail(c, D2T_EINVAL, "linear '%s': input has %d columns, expected %d", key.c_str(), x.cols, K);
-    const float *w, *b;
+    const float *w, *b = nullptr;
     RC(raw(key + (key.find("in_proj") != std::string::npos ? "_weight" : ".weight"), &w));
-    RC(raw(key + (key.find("in_proj") != std::string::npos ? "_bias" : ".bias"), &b));
+    if (bias) RC(raw(key + (key.find("in_proj") != std::string::npos ? "_bias" : ".bias"), &b));
     RC(new_tensor(x.rows, N, out, 0, 0, 0, into));
-    RC(gemm_nt(x.p, w + (size_t)woff * K, b + woff, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, x.rows, N, K, act));
+    RC(gemm_nt(x.p, w + (size_t)woff * K, b ? b + woff : nullptr, res >= 0 ? st->t[res].p : nullptr, st->t[*out].p, x.rows, N, K, act));
     Node n;
     n.kind = N_LINEAR; n.in = in; n.in2 = res; n.out = *out; n.wkey = key; n.N = N; n.K = K; n.woff = woff; n.relu = act == ACT_RELU;
+    n.nobias = !bias;
     st->nodes.push_back(n);
     return D2T_OK;
   }
@@ -766,8 +769,11 @@ struct Tr {  // builder / runner bound to one context and stream
     const int Hh = g.attn_hidden, V = g.vocab, T = (int)(st->t[mem].rows / B);
     const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0, Tk = T - key_off;
     if (!c->finalized) return fail(c, D2T_ESTATE, "the Attn training step needs finalized weights");
+    // key projection: key_proj of the location-aware cell, i2h (no bias) of the Bahdanau cell (attention1D.py:77-82)
+    const bool bahdanau = g.attn_cell == D2T_ATTN_CELL_BAHDANAU;
     int kp;
-    RC(linear(mem, "predicter.Prediction.attention_cell.attn.key_proj", Hh, Hh, 0, ACT_NONE, -1, &kp));
+    RC(linear(mem, std::string("predicter.Prediction.attention_cell.attn.") + (bahdanau ? "i2h" : "key_proj"), Hh, Hh, 0, ACT_NONE, -1,
+              &kp, nullptr, !bahdanau));
     Node n;
     n.kind = N_LSTM; n.in = mem; n.in2 = kp; n.nb = B; n.Lq = S; n.Lk = T; n.koff = key_off;
     const size_t BS = (size_t)B * S;
@@ -805,7 +811,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.taps = c->attn.taps; p.wscore = c->attn.wscore; p.bscore = c->attn.bscore;
     p.wx_t = c->attn.wx_t; p.bx = c->attn.bx; p.wg_t = c->attn.wg_t; p.bg = c->attn.bg;
     p.wih_t = c->attn.wih_t; p.bih = c->attn.bih; p.wic_t = c->attn.wic_t; p.bic = c->attn.bic;
-    p.emb = c->attn.emb; p.probs = logits; p.tokens = reinterpret_cast<int64_t*>(dummy);
+    p.emb = c->attn.emb; p.tokgate = c->attn.tokgate; p.probs = logits; p.tokens = reinterpret_cast<int64_t*>(dummy);
     p.end_step = reinterpret_cast<int*>(dummy + BS * 2);
     p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage; p.end_token = 1;
     p.teacher = tgt; p.use_teacher = d_flags; p.out_dropmask = n.mask; p.out_dropscale = n.mscale;
@@ -837,13 +843,26 @@ struct Tr {  // builder / runner bound to one context and stream
       TCHK(launch_apply_mask(dl, n.mask, n.mscale, dlm, (size_t)BS * V, s));
       dl = dlm;
     }
-    const float *wih, *whh, *wq, *cw, *cb, *pw;
+    // Bahdanau cell: h2h is the query projection, no location layers, no score bias (the kernel's location filter is the
+    // zero filter the forward pass used).  One-hot targets: rnn.weight_ih is [4H][H + V]; the kernel gets its context
+    // columns beside a zero "embedding" block, and the token columns' gradients are gathered per token below.
+    const bool bahdanau = g.attn_cell == D2T_ATTN_CELL_BAHDANAU, onehot = g.attn_onehot != 0;
+    const std::string qk = ac + (bahdanau ? "attn.h2h" : "attn.query_proj");
+    const float *wih, *whh, *wq, *cw = nullptr, *cb = nullptr, *pw = nullptr;
     RC(raw(ac + "rnn.weight_ih", &wih));
     RC(raw(ac + "rnn.weight_hh", &whh));
-    RC(raw(ac + "attn.query_proj.weight", &wq));
-    RC(raw(ac + "attn.loc_conv.weight", &cw));
-    RC(raw(ac + "attn.loc_conv.bias", &cb));
-    RC(raw(ac + "attn.loc_proj.weight", &pw));
+    RC(raw(qk + ".weight", &wq));
+    if (!bahdanau) {
+      RC(raw(ac + "attn.loc_conv.weight", &cw));
+      RC(raw(ac + "attn.loc_conv.bias", &cb));
+      RC(raw(ac + "attn.loc_proj.weight", &pw));
+    }
+    if (onehot) {
+      float* wc;
+      RC(zeros(&wc, (size_t)4 * Hh * 2 * Hh));
+      TCHK(launch_copy2d(wih, Hh + V, wc, 2 * Hh, (size_t)4 * Hh, Hh, s));
+      wih = wc;
+    }
     AttnTrainBwdP p{};
     p.dlogits = dl; p.mem = mem.p; p.T = T; p.D = Hh; p.key_off = key_off; p.kp = kp.p;
     p.wg_t = c->attn.wg_t; p.wih_raw = wih; p.whh_raw = whh; p.wq_raw = wq; p.wloc = c->attn.wloc; p.bloc = c->attn.bloc;
@@ -872,29 +891,45 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(wgrad(dl, V, n.aux[2], Hh, BS, V, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
     RC(colsum(dl, BS, V, gB));
     RC(grad_buf(ac + "rnn.weight_ih", &gW));
-    RC(wgrad(dgates, 4 * Hh, n.aux[7], 2 * Hh, BS, 4 * Hh, 2 * Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    if (!onehot) {
+      RC(wgrad(dgates, 4 * Hh, n.aux[7], 2 * Hh, BS, 4 * Hh, 2 * Hh, 1, nullptr, nullptr, nullptr, gW, 0));
+    } else {  // columns [0, H): the context part; column H + v: the sum of the gate gradients of the steps fed token v
+      float *gc, *gt, *gtt;
+      RC(alloc(&gc, (size_t)4 * Hh * Hh));
+      RC(alloc(&gt, (size_t)V * 4 * Hh));
+      RC(alloc(&gtt, (size_t)4 * Hh * V));
+      RC(wgrad(dgates, 4 * Hh, n.aux[7], 2 * Hh, BS, 4 * Hh, Hh, 1, nullptr, nullptr, nullptr, gc, 0));
+      TCHK(launch_copy2d(gc, Hh, gW, Hh + V, (size_t)4 * Hh, Hh, s));
+      TCHK(launch_embed_bwd(dgates, n.keytok, gt, (int)BS, V, 4 * Hh, 1.f, -1, s));
+      TCHK(launch_transpose(gt, gtt, V, 4 * Hh, s));
+      TCHK(launch_copy2d(gtt, V, gW + Hh, Hh + V, (size_t)4 * Hh, V, s));
+    }
     RC(grad_buf(ac + "rnn.weight_hh", &gW));
     RC(wgrad(dgates, 4 * Hh, n.aux[0], Hh, BS, 4 * Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
     RC(grad_buf(ac + "rnn.bias_ih", &gB));
     RC(grad_buf(ac + "rnn.bias_hh", &gB2));
     RC(colsum(dgates, BS, 4 * Hh, gB));
     TCHK(launch_copy(gB, gB2, (size_t)4 * Hh, s));
-    RC(grad_buf(ac + "attn.query_proj.weight", &gW));
-    RC(grad_buf(ac + "attn.query_proj.bias", &gB));
+    RC(grad_buf(qk + ".weight", &gW));
+    RC(grad_buf(qk + ".bias", &gB));
     RC(wgrad(dhq, Hh, n.aux[0], Hh, BS, Hh, Hh, 1, nullptr, nullptr, nullptr, gW, 0));
     RC(colsum(dhq, BS, Hh, gB));
     RC(grad_buf(ac + "attn.score.weight", &gW));
-    RC(grad_buf(ac + "attn.score.bias", &gB));
     TCHK(launch_sum_over_rows(dwscore, gW, B, Hh, s));
-    TCHK(launch_sum_over_rows(dbscore, gB, B, 1, s));
-    float *gcw, *gcb, *gpw, *gpb;
-    RC(grad_buf(ac + "attn.loc_conv.weight", &gcw));
-    RC(grad_buf(ac + "attn.loc_conv.bias", &gcb));
-    RC(grad_buf(ac + "attn.loc_proj.weight", &gpw));
-    RC(grad_buf(ac + "attn.loc_proj.bias", &gpb));
-    TCHK(launch_loc_unfold_bwd(dwloc, dbloc, B, cw, cb, pw, Hh, kd, taps, gcw, gcb, gpw, gpb, s));
-    RC(grad_buf(pp + "embedding.weight", &gW));
-    TCHK(launch_embed_bwd(demb, n.keytok, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
+    if (!bahdanau) {
+      RC(grad_buf(ac + "attn.score.bias", &gB));
+      TCHK(launch_sum_over_rows(dbscore, gB, B, 1, s));
+      float *gcw, *gcb, *gpw, *gpb;
+      RC(grad_buf(ac + "attn.loc_conv.weight", &gcw));
+      RC(grad_buf(ac + "attn.loc_conv.bias", &gcb));
+      RC(grad_buf(ac + "attn.loc_proj.weight", &gpw));
+      RC(grad_buf(ac + "attn.loc_proj.bias", &gpb));
+      TCHK(launch_loc_unfold_bwd(dwloc, dbloc, B, cw, cb, pw, Hh, kd, taps, gcw, gcb, gpw, gpb, s));
+    }
+    if (!onehot) {
+      RC(grad_buf(pp + "embedding.weight", &gW));
+      TCHK(launch_embed_bwd(demb, n.keytok, gW, (int)BS, V, Hh, 1.f, 0, s));  // padding_idx = [GO] = 0 (seq2seq.py:33-35)
+    }
     if (g.attn_enc_init) {  // h0 / c0 = proj_init_{h,c}(memory[:, 0]) or, on a BiLSTM encoder, of the mean over the tokens
       const bool mean = n.causal == 1;
       const float* initv = mem.p;  // row b = memory[b][0] with a row stride of T * Hh
@@ -955,8 +990,10 @@ struct Tr {  // builder / runner bound to one context and stream
     const std::string wk = n.wkey + (inproj ? "_weight" : ".weight"), bk = n.wkey + (inproj ? "_bias" : ".bias");
     float *dW, *db;
     RC(grad_buf(wk, &dW));
-    RC(grad_buf(bk, &db));
-    RC(colsum(g, y.rows, n.N, db + n.woff));
+    if (!n.nobias) {
+      RC(grad_buf(bk, &db));
+      RC(colsum(g, y.rows, n.N, db + n.woff));
+    }
     RC(wgrad(g, n.N, x.p, n.K, y.rows, n.N, n.K, 1, nullptr, nullptr, nullptr, dW + (size_t)n.woff * n.K, 0));
     // dx = g @ W  ->  NT GEMM against W^T [K][N]; the reduction dimension N must be a multiple of 32
     const float* w;
@@ -1242,8 +1279,6 @@ int d2t_train_forward(d2t_ctx* c, const float* image, int32_t B, int32_t H, int3
   if (!lstm && lstm_enc) return fail(c, D2T_ESTATE, "the BiLSTM encoders train with the Attn / Attnv2 heads");
   if (lstm && L != g.batch_max_length + 1) return fail(c, D2T_EINVAL, "the Attn head trains on batch_max_length + 1 = %d steps", g.batch_max_length + 1);
   if (!lstm && L > g.max_seq_len + 1) return fail(c, D2T_EINVAL, "teacher sequence longer than max_seq_len + 1");
-  if (lstm && (g.attn_cell != D2T_ATTN_CELL_LOCATION || g.attn_onehot))
-    return fail(c, D2T_ESTATE, "the Attn training step is implemented for the location-aware cells with embedded targets");
   if (!c->train) c->train = new d2t_train_state();
   d2t_train_state* st = c->train;
   st->tape.reset();

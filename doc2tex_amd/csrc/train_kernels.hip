@@ -1123,6 +1123,21 @@ hipError_t launch_pad_cols(const float* src, float* dst, size_t rows, int Cs, in
                      rows, Cs, Cd);
   return hipGetLastError();
 }
+// dst[r][0..cols) = src[r][0..cols) between two row-major matrices of different leading dimensions
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, size_t rows, int cols) {
+  const size_t total = rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    const size_t r = i / cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+hipError_t launch_copy2d(const float* src, int lds, float* dst, int ldd, size_t rows, int cols, hipStream_t s) {
+  const size_t total = rows * cols;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, lds,
+                     dst, ldd, rows, cols);
+  return hipGetLastError();
+}
 // Zero-dilated, zero-padded copy of an NHWC map: dst[b][oh*SH + OFFH][ow*SW + OFFW][c] = src[b][oh][ow][c], rest 0.
 // (input of the stride-1 convolution that evaluates the data gradient of a strided convolution)
 __global__ void dilate_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int OH, int OW, int C, int DH,

@@ -127,7 +127,7 @@ def train_step_labels(c):
     text = synth.synth_labels(c["B"], max_len=L, seed=c["iseed"])
     text[0, L // 2:] = 0
     text[0, L // 2 - 1] = R.END
-    if c["config"] in ("TS0", "S0", "C0"):
+    if c["config"] in ("TS0", "S0", "C0", "B0", "TB0", "TO0"):
         t = text.clone()
         t[text == 1] = 0
         t[text == 2] = 1
@@ -148,7 +148,8 @@ def gc_drop_from_seed(seed):
 
 
 @pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step", "c3_train_step", "t2g_train_step",
-                                  "t1g_train_step", "c0_train_step"])
+                                  "t1g_train_step", "c0_train_step", "b0_train_step", "tb0_train_step",
+                                  "to0_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
     reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""

@@ -114,7 +114,11 @@ TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_tra
                     # GlobalContext blocks on (gcb: True): the two TFM stacks
                     ("t2g_train_step", "T2G", 3, 48, 64, 24, 1234, 1034), ("t1g_train_step", "T1G", 2, 32, 64, 22, 1234, 1035),
                     # BASELINE configs[0]'s stack in training: VGG + 2x BidirectionalLSTM + Attn (coverage cell, init from the mean)
-                    ("c0_train_step", "C0", 3, 32, 160, 24, 1234, 1036)]
+                    ("c0_train_step", "C0", 3, 32, 160, 24, 1234, 1036),
+                    # the other attention cells / target encodings of the LSTM heads: Bahdanau cell (VGG + BiLSTM + Attn),
+                    # Bahdanau cell with one-hot targets and a zero initial state, coverage cell with one-hot targets
+                    ("b0_train_step", "B0", 3, 32, 160, 24, 1234, 1037), ("tb0_train_step", "TB0", 3, 48, 64, 24, 1234, 1038),
+                    ("to0_train_step", "TO0", 3, 48, 64, 24, 1234, 1039)]
 LOGIT_STRIDE = {"c3_train_step": 8}  # store every 8th position of the [B, 151, V] logits (fixture size)
 GRAD_SAMPLES = 48
 GC_MASK_SEED = 99  # seeded keep masks of the GlobalContext blocks' dropout in the *g_train_step fixtures
