@@ -78,6 +78,7 @@ SIGNATURES = {
     "d2t_train_forward": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "d2t_train_backward": (_I, [_P, _P, _P]),
     "d2t_train_grad": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "d2t_reload_weights": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _P]),
     "d2t_train_gather": (_I, [_P, _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, _P]),
     "d2t_read_weight": (_I, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "d2t_train_set_dropout": (_I, [_P, C.c_float, C.c_uint64]),

@@ -305,8 +305,14 @@ struct WgradP {
   int H, W, OH, OW, KW, SH, SW, PH, PW;
   int S, chunk;     // split over row chunks of `chunk` rows
   int bf16x3;       // 128 x 128 tiles only: split-bf16 arithmetic (three bf16 MFMAs per product)
+  // both set: the operands as split-bf16 records ([row][32 x hi | 32 x lo] per 32-column group, conv_common.h) of a / b --
+  // geom convolutions with M % 128 == N % 128 == 0 and chunk % 16 == 0 in bf16x3 mode; `zero`: 256 zero bytes
+  const uint16_t* a_rec = nullptr;
+  const uint16_t* b_rec = nullptr;
+  const void* zero = nullptr;
 };
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s);
+bool wgrad_rec_wide(int M);  // record kernel: 256 x 128 block tiles (two blocks per CU) instead of 128 x 128 (three)
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
                                hipStream_t s);
 enum { CR_SUM = 0, CR_SUM_SQ = 1, CR_BN_BWD = 2, CR_LN_BWD = 3 };
@@ -320,7 +326,7 @@ struct ColRedP {
   long long R;
   int C, mode;
 };
-int colreduce_chunks(long long R);
+int colreduce_chunks(long long R, int C);
 hipError_t launch_colreduce(const ColRedP& p, hipStream_t s);
 hipError_t launch_colreduce_final(const float* part, int chunks, int C, float* out0, float* out1, int accumulate,
                                   hipStream_t s);

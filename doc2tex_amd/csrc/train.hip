@@ -221,7 +221,7 @@ struct Tr {  // builder / runner bound to one context and stream
   }
   // dst[c] (+)= column sums of a[R][C]
   int colsum(const float* a, long long R, int C, float* dst) {
-    const int chunks = colreduce_chunks(R);
+    const int chunks = colreduce_chunks(R, C);
     RC(ensure_part((size_t)chunks * 2 * C));
     ColRedP p{};
     p.a = a; p.part = st->part; p.R = R; p.C = C; p.mode = CR_SUM;
@@ -231,20 +231,32 @@ struct Tr {  // builder / runner bound to one context and stream
   }
   // dW[M][N](taps) = a^T (x) b  with the split-K two-pass reduction
   int wgrad(const float* a, int lda, const float* b, int ldb, long long P, int M, int N, int taps, const Node* geom,
-            const TT* xin, const TT* yout, float* dst, int layout) {
+            const TT* xin, const TT* yout, float* dst, int layout, const uint16_t* a_rec = nullptr,
+            const uint16_t* b_rec = nullptr) {
+    // both operands exist as split-bf16 records (a convolution between BatchNorm layers): the LDS-DMA kernel
+    static const bool rec_off = getenv("D2T_WGRAD_REC") && atoi(getenv("D2T_WGRAD_REC")) == 0;
+    const bool rec = !rec_off && a_rec && b_rec && geom && c->conv_bf16x3 && c->zero_page && M % 128 == 0 && N % 128 == 0 &&
+                     lda == M && ldb == N;
     const int tile = (M <= 64 || N <= 64) ? 64 : 128;
-    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps;
-    // split the rows into S chunks so that tiles * S blocks fill whole rounds of the 512 block slots (two 64 KB-LDS
-    // blocks per CU on 256 CUs): among the S that give >= ~2 rounds pick the one wasting least of its last round
+    const bool wide = rec && wgrad_rec_wide(M);
+    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps / (wide ? 2 : 1);
+    // split the rows into S chunks so that tiles * S blocks fill whole rounds of the block slots (two 64 KB-LDS blocks per
+    // CU on 256 CUs; three of the record kernel's 48 KB blocks): among the S that give >= ~2 rounds pick the one wasting
+    // least of its last round
+    const long long slots = rec && !wide ? 768 : 512;
     const long long smax = std::max<long long>(1, (P + 511) / 512);
     long long S = 1;
     double best = -1.0;
     for (long long cand = 1; cand <= std::min<long long>(smax, 64); ++cand) {
-      const long long blocks = tiles * cand, rounds = (blocks + 511) / 512;
-      double eff = (double)blocks / (double)(rounds * 512);
-      if (blocks < 1024 && cand < smax) eff *= 0.5;  // prefer enough blocks to hide the tile prologue / epilogue
+      const long long blocks = tiles * cand, rounds = (blocks + slots - 1) / slots;
+      double eff = (double)blocks / (double)(rounds * slots);
+      if (blocks < 2 * slots && cand < smax) eff *= 0.5;  // prefer enough blocks to hide the tile prologue / epilogue
       if (eff > best + 1e-9) { best = eff; S = cand; }
     }
+    // the record kernel's K loops are cheap to keep long and every extra split is another [taps][M][N] partial to write
+    // and sum: one round of blocks (measured against 2 ... 4 rounds and the rule above: 113.8 vs 114.2 ... 117.8 ms per step)
+    static const int rec_rounds = getenv("D2T_WGRAD_ROUNDS") ? std::max(1, atoi(getenv("D2T_WGRAD_ROUNDS"))) : 1;
+    if (rec) S = std::max<long long>(1, std::min<long long>(smax, rec_rounds * slots / tiles));
     long long chunk = ((P + S - 1) / S + 31) / 32 * 32;
     S = (P + chunk - 1) / chunk;
     RC(ensure_part((size_t)S * taps * M * N));
@@ -252,6 +264,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.a = a; p.b = b; p.part = st->part; p.P = P; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.taps = taps;
     p.KW = 1; p.S = (int)S; p.chunk = (int)chunk;
     p.bf16x3 = c->conv_bf16x3 ? 1 : 0;
+    if (rec) { p.a_rec = a_rec; p.b_rec = b_rec; p.zero = c->zero_page; }
     if (geom) {
       p.geom = 1; p.H = xin->H; p.W = xin->W; p.OH = yout->H; p.OW = yout->W;
       p.KW = geom->KW; p.SH = geom->SH; p.SW = geom->SW; p.PH = geom->PH; p.PW = geom->PW;
@@ -304,6 +317,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.cols; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW; p.M = (int)P; p.K = n.K; p.act = ACT_NONE;
     RC(split_input(&p, x.p, x.rows, x.cols, x.planes));
+    if (p.in_hi && !x.planes) st->t[in].planes = p.in_hi;  // records made here: the weight gradient reads them again
     TCHK(d2t_internal_conv_timed(c, p, s));
     if (bnkey.empty()) {
       RC(new_tensor(P, Cout, out, x.B, OH, OW, n.z));
@@ -325,7 +339,7 @@ struct Tr {  // builder / runner bound to one context and stream
   int bn_forward(Node& n, long long P, int C, int /*res*/) {
     RC(alloc(&n.mean, C));
     RC(alloc(&n.rstd, C));
-    const int chunks = colreduce_chunks(P);
+    const int chunks = colreduce_chunks(P, C);
     RC(ensure_part((size_t)chunks * 2 * C));
     ColRedP p{};
     p.a = n.z; p.part = st->part; p.R = P; p.C = C; p.mode = CR_SUM_SQ;
@@ -1027,7 +1041,7 @@ struct Tr {  // builder / runner bound to one context and stream
     float *dg, *db;
     RC(grad_buf(n.gkey + ".weight", &dg));
     RC(grad_buf(n.gkey + ".bias", &db));
-    const int chunks = colreduce_chunks(x.rows);
+    const int chunks = colreduce_chunks(x.rows, x.cols);
     RC(ensure_part((size_t)chunks * 2 * x.cols));
     ColRedP p{};
     p.a = y.grad; p.z = x.p; p.mean = n.mean; p.rstd = n.rstd; p.part = st->part; p.R = x.rows; p.C = x.cols; p.mode = CR_LN_BWD;
@@ -1066,7 +1080,7 @@ struct Tr {  // builder / runner bound to one context and stream
       float *dgam, *dbet, *s0, *s1, *dzb, *gres = nullptr;
       RC(grad_buf(n.bnkey + ".weight", &dgam));
       RC(grad_buf(n.bnkey + ".bias", &dbet));
-      const int chunks = colreduce_chunks(P);
+      const int chunks = colreduce_chunks(P, Cout);
       RC(ensure_part((size_t)chunks * 2 * Cout));
       ColRedP p{};
       p.a = y.grad; p.y = n.relu ? y.p : nullptr; p.z = n.z; p.mean = n.mean; p.rstd = n.rstd; p.part = st->part;
@@ -1093,7 +1107,7 @@ struct Tr {  // builder / runner bound to one context and stream
       return D2T_OK;
     }
     const TT& x = st->t[n.in];
-    RC(wgrad(dz, Cout, x.p, x.cols, P, Cout, x.cols, n.KH * n.KW, &n, &x, &y, dW, 1));
+    RC(wgrad(dz, Cout, x.p, x.cols, P, Cout, x.cols, n.KH * n.KW, &n, &x, &y, dW, 1, dz_planes, x.planes));
     // data gradient: stride-1 convolution of the (zero-dilated) dz with the flipped, transposed filter
     const float* w;
     RC(raw(n.wkey + ".weight", &w));
@@ -1345,6 +1359,32 @@ int d2t_train_grad(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_
   return D2T_OK;
 }
 
+// launch one multi-copy kernel over `table` on stream s; the table travels through a pinned block of the gather ring
+static int run_copy_table(d2t_ctx* c, d2t_train_state* st, const std::vector<CopyChunk>& table, hipStream_t s) {
+  if (table.empty()) return D2T_OK;
+  const size_t bytes = table.size() * sizeof(CopyChunk);
+  d2t_train_state::GatherStage& g = st->gather[st->gather_calls++ & 3];
+  if (g.pending) {
+    HIPCHK(c, hipEventSynchronize(g.ev));
+    g.pending = false;
+  }
+  if (bytes > g.cap) {
+    if (g.h) { HIPCHK(c, hipHostFree(g.h)); HIPCHK(c, hipFree(g.d)); }
+    g.h = g.d = nullptr;
+    g.cap = 0;
+    HIPCHK(c, hipHostMalloc(&g.h, bytes * 2, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(&g.d, bytes * 2));
+    g.cap = bytes * 2;
+    if (!g.ev) HIPCHK(c, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+  }
+  memcpy(g.h, table.data(), bytes);
+  HIPCHK(c, hipMemcpyAsync(g.d, g.h, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(g.ev, s));
+  g.pending = true;
+  HIPCHK(c, launch_multi_copy(reinterpret_cast<const CopyChunk*>(g.d), (int)table.size(), s));
+  return D2T_OK;
+}
+
 int d2t_train_gather(d2t_ctx* c, int32_t source, int32_t n, const char* const* names, const int64_t* offsets,
                      const int64_t* numels, float* flat, d2t_stream stream) {
   DevGuard dg_(c);
@@ -1369,29 +1409,29 @@ int d2t_train_gather(d2t_ctx* c, int32_t source, int32_t n, const char* const* n
     for (long long o = 0; o < numels[i]; o += CHUNK)
       table.push_back(CopyChunk{src + o, flat + offsets[i] + o, std::min<long long>(CHUNK, numels[i] - o)});
   }
-  if (table.empty()) return D2T_OK;
-  // the table travels through a pinned block
-  const size_t bytes = table.size() * sizeof(CopyChunk);
-  d2t_train_state::GatherStage& g = st->gather[st->gather_calls++ & 3];
-  if (g.pending) {
-    HIPCHK(c, hipEventSynchronize(g.ev));
-    g.pending = false;
+  return run_copy_table(c, st, table, s);
+}
+
+/* Refresh the engine's copies of tensors that are already loaded (same names, same sizes) from device memory, all in one
+ * kernel: what the step after optimizer.step() needs -- every parameter changed, and one d2t_load_weight per tensor
+ * is ~400 four-microsecond device copies.  Anything not loaded yet (or resized) is an error: use d2t_load_weight. */
+int d2t_reload_weights(d2t_ctx* c, int32_t n, const char* const* names, const float* const* srcs, const int64_t* numels,
+                       d2t_stream stream) {
+  DevGuard dg_(c);
+  if (!c || n < 0 || (n && (!names || !srcs || !numels))) return fail(c, D2T_EINVAL, "bad argument");
+  if (!c->train) c->train = new d2t_train_state();
+  hipStream_t s = (hipStream_t)stream;
+  constexpr long long CHUNK = 1 << 16;
+  std::vector<CopyChunk> table;
+  for (int i = 0; i < n; ++i) {
+    auto it = c->raw.find(names[i]);
+    if (it == c->raw.end() || !it->second.p || (int64_t)it->second.numel != numels[i])
+      return fail(c, D2T_EINVAL, "tensor '%s': not loaded or size mismatch", names[i]);
+    if (int rc = check_dev_ptr(c, srcs[i], names[i])) return rc;
+    for (long long o = 0; o < numels[i]; o += CHUNK)
+      table.push_back(CopyChunk{srcs[i] + o, it->second.p + o, std::min<long long>(CHUNK, numels[i] - o)});
   }
-  if (bytes > g.cap) {
-    if (g.h) { HIPCHK(c, hipHostFree(g.h)); HIPCHK(c, hipFree(g.d)); }
-    g.h = g.d = nullptr;
-    g.cap = 0;
-    HIPCHK(c, hipHostMalloc(&g.h, bytes * 2, hipHostMallocDefault));
-    HIPCHK(c, hipMalloc(&g.d, bytes * 2));
-    g.cap = bytes * 2;
-    if (!g.ev) HIPCHK(c, hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
-  }
-  memcpy(g.h, table.data(), bytes);
-  HIPCHK(c, hipMemcpyAsync(g.d, g.h, bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipEventRecord(g.ev, s));
-  g.pending = true;
-  HIPCHK(c, launch_multi_copy(reinterpret_cast<const CopyChunk*>(g.d), (int)table.size(), s));
-  return D2T_OK;
+  return run_copy_table(c, c->train, table, s);
 }
 
 int d2t_read_weight(d2t_ctx* c, const char* name, float* dst, int64_t numel, d2t_stream stream) {

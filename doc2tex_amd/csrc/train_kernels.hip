@@ -287,10 +287,220 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradP p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 weight gradient on operand RECORDS (the convolution layers whose dz and input already exist as
+// [pixel][32 x hi | 32 x lo] records: the BatchNorm kernels write them for the forward / data-gradient convolutions).
+// Same products as wgrad_bf16x3_kernel -- lo*hi, hi*lo, hi*hi into one fp32 accumulator -- but nothing is split or staged
+// through registers: a K-step's 16 pixel rows of both operands travel global -> LDS by LDS-DMA (16 bytes per lane), three
+// stages deep with a counted vmcnt wait and ONE raw barrier per step (the scheme of conv_bf16x3p.hip), and three blocks
+// share a CU so that one block's barrier is covered by the others' MFMAs.
+//   LDS stage = A [16 rows][512 B] | B [16 rows][512 B]; a row = the tile's four records of one pixel = 32 chunks of
+//   16 bytes (chunk 8 g + 0..3: hi of group g, 8 g + 4..7: lo).  Row stride 512 B puts every row on the same banks, so
+//   chunk c of row r is stored at position c ^ ((r & 3) << 2): the four rows of a transposing read (ds_read_b64_tr_b16:
+//   4 rows x 64 B per 32 lanes) then start 64 B apart modulo 256 B and cover the 64 banks once.  The LDS-DMA writes lane
+//   l of a wave at base + 16 l, so the swizzle is applied on the SOURCE side: the lane fetches the chunk that belongs at
+//   its position.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+template <int MI, int ABL = 0>  // (ABL: timing probes -- 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA, 4 plain ds_read_b64,
+                               //  5 the step's LDS-DMA issued in one burst behind the barrier)
+                               // wave tile (32 MI) x 64, block tile (64 MI) x 128: MI = 2 -> 128 x 128, three blocks per CU; 4 -> 256 x 128, two
+__global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const WgradP p) {
+  constexpr int BK = 16, NS = 3, BM = 64 * MI;
+  constexpr int AROWB = BM * 4, BROWB = 512;        // bytes per LDS row: the tile's records of one pixel
+  constexpr int AOPB = BK * AROWB, BOPB = BK * BROWB, STAGE = AOPB + BOPB;
+  constexpr int ACH = AROWB / 16;                    // 16-byte chunks per A row (32 | 64)
+  constexpr int ARPI = 256 / ACH, ANI = BK / ARPI;   // A rows per block-wide DMA instruction, instructions per step
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_n = p.N / 128;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * 128;
+  const int tap = blockIdx.y, kh = tap / p.KW, kw = tap % p.KW;
+  const long long r_begin = (long long)blockIdx.z * p.chunk;
+  const long long r_end = r_begin + p.chunk < p.P ? r_begin + p.chunk : p.P;
+  const int KT = (int)((r_end - r_begin + BK - 1) / BK);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero) + (lane & 15) * 16;
+
+  // ---- LDS-DMA source side.  A: rows arow + ARPI i (i < ANI) of every stage, chunk position acpos; B: rows brow, brow + 8 ----
+  const int arow = tid / ACH, acpos = tid % ACH, brow = tid >> 5, bcpos = tid & 31;
+  const int acsrc = acpos ^ ((arow & 3) << 2), bcsrc = bcpos ^ ((brow & 3) << 2);  // (row + 4 k) & 3 == row & 3
+  const size_t arow_b = (size_t)p.M * 4, brow_b = (size_t)p.N * 4;  // bytes per pixel row of the record arrays
+  const unsigned char* a_src = reinterpret_cast<const unsigned char*>(p.a_rec) + (size_t)(r_begin + arow) * arow_b +
+                               (size_t)(m0 / 32 + (acsrc >> 3)) * 128 + (acsrc & 7) * 16;
+  const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.b_rec) + (size_t)(n0 / 32 + (bcsrc >> 3)) * 128 + (bcsrc & 7) * 16;
+  long long rr = r_begin;  // first pixel row of the step about to be issued
+  int pb[2], poh[2], pow_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long r = r_begin + brow + 8 * i;
+    const int ohow = p.OH * p.OW;
+    pb[i] = (int)(r / ohow);
+    const int rem = (int)(r - (long long)pb[i] * ohow);
+    poh[i] = rem / p.OW;
+    pow_[i] = rem - poh[i] * p.OW;
+  }
+  long long rrb = r_begin;
+  // one LDS-DMA instruction of the stage: pieces 0 .. ANI-1 = the A rows, ANI, ANI+1 = the B rows
+  auto issue_piece = [&](int stage, int k) {
+    unsigned char* sa = smem + stage * STAGE + wave * 1024;  // wave-uniform bases; the hardware adds 16 * lane
+    if (k < ANI) {
+      const bool live = rr + arow + ARPI * k < r_end;
+      const unsigned char* as = live ? a_src + (size_t)(ARPI * k) * arow_b : zero;
+      __builtin_amdgcn_global_load_lds(as, (lds_void_ptr)(sa + k * 4096), 16, 0, 0);
+      if (k == ANI - 1) { a_src += (size_t)BK * arow_b; rr += BK; }
+    } else {
+      const int i = k - ANI;
+      const bool live = rrb + brow + 8 * i < r_end;
+      const int ih = poh[i] * p.SH - p.PH + kh, iw = pow_[i] * p.SW - p.PW + kw;
+      const bool ok = live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const unsigned char* bs = ok ? b_base + ((size_t)((long long)pb[i] * p.H + ih) * p.W + iw) * brow_b : zero;
+      __builtin_amdgcn_global_load_lds(bs, (lds_void_ptr)(sa + AOPB + i * 4096), 16, 0, 0);
+      pow_[i] += BK;  // advance to the same piece of the next step
+      while (pow_[i] >= p.OW) {
+        pow_[i] -= p.OW;
+        if (++poh[i] == p.OH) { poh[i] = 0; ++pb[i]; }
+      }
+      if (i == 1) rrb += BK;
+    }
+  };
+  auto issue_a = [&](int stage) {
+#pragma unroll
+    for (int k = 0; k < ANI; ++k) issue_piece(stage, k);
+  };
+  auto issue_b = [&](int stage) {
+    issue_piece(stage, ANI);
+    issue_piece(stage, ANI + 1);
+  };
+  auto issue = [&](int stage) { issue_a(stage); issue_b(stage); };
+
+  // ---- fragment side ----
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int g16 = lane >> 4, l16 = lane & 15;
+  const int frow = 8 * (g16 >> 1) + (l16 >> 2), fx = ((l16 >> 2) & 3) << 2, fsub = (g16 & 1) * 2 + ((l16 & 3) >> 1);
+  int offa[MI][2], offb[2][2];  // [fragment][hi, lo]
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      offa[i][part] = frow * AROWB + (l16 & 1) * 8 + (((((wm * MI + i) << 3) | (part << 2) | fsub) ^ fx) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      offb[j][part] = AOPB + frow * BROWB + (l16 & 1) * 8 + (((((wn * 2 + j) << 3) | (part << 2) | fsub) ^ fx) << 4);
+  }
+  auto frag = [&](const unsigned char* q, int rowb) -> bf16x8_t {
+    if (ABL == 4) {
+      const s4_t a4 = *reinterpret_cast<const s4_t*>(q), b4 = *reinterpret_cast<const s4_t*>(q + 4 * rowb);
+      s8_t v = {a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+      return __builtin_bit_cast(bf16x8_t, v);
+    }
+    const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(q));
+    const s4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(q + 4 * rowb));
+    s8_t v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (KT > 0) issue(0);
+  if (KT > 1) issue(1);
+  int cur = 0, nxt2 = 2;
+  constexpr bool burst = ABL == 3 || ABL == 5;
+  bf16x8_t ah[MI], al[MI], bh[2], bl[2];
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) wg_wait_vm<ANI + 2>(); else wg_wait_vm<0>();  // this wave's pieces of step kt have landed
+    __builtin_amdgcn_s_barrier();  // ... and everybody else's; nobody reads stage kt-1 any more
+    if (burst && kt + 2 < KT && (ABL != 3 || kt + 2 < 3)) issue(nxt2);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* st = smem + cur * STAGE;
+    if (ABL != 2 || kt == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = frag(st + offb[j][0], BROWB);
+        bl[j] = frag(st + offb[j][1], BROWB);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        ah[i] = frag(st + offa[i][0], AROWB);
+        al[i] = frag(st + offa[i][1], AROWB);
+      }
+    }
+    if (ABL == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (ABL != 1 || kt == 0) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+        // the LDS-DMA of step kt+2: one instruction behind each (i, j) group of MFMAs, the last ANI + 2 groups of the step.
+        // (In one burst behind the barrier the waves of a block queue up in the vector-memory path together and the
+        // MFMAs wait behind them: 951 us on the dominant layer against 833 us this way; all at once after the first /
+        // second row of groups: 867 / 847 us.)
+        if (!burst && kt + 2 < KT) {
+          constexpr int first = 2 * MI - (ANI + 2);
+          const int g = 2 * i + j - first;
+          if (g >= 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(nxt2, g); __builtin_amdgcn_sched_barrier(0); }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads have returned before the next barrier (WAR on the stage)
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+  }
+  float* out = p.part + ((size_t)blockIdx.z * p.taps + tap) * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 32 * MI + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[(size_t)m * p.N + n] = acc[i][j][reg];
+      }
+    }
+}
+
+bool wgrad_rec_wide(int M) {
+  static const int mode = getenv("D2T_WGRAD_WIDE") ? atoi(getenv("D2T_WGRAD_WIDE")) : 1;
+  return mode && M % 256 == 0;
+}
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.P <= 0) return hipSuccess;
   if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
-  if (p.M <= 64 || p.N <= 64) {
+  if (p.a_rec) {  // record operands: see wgrad_rec_ok
+    if (!p.b_rec || !p.zero || !p.geom || !p.bf16x3 || p.M % 128 || p.N % 128 || p.chunk % 16) return hipErrorInvalidValue;
+    if (wgrad_rec_wide(p.M)) {
+      dim3 grid((p.M / 256) * (p.N / 128), p.taps, p.S);
+      static const int abl = getenv("D2T_WGRAD_ABL") ? atoi(getenv("D2T_WGRAD_ABL")) : 0;
+      if (abl == 1) hipLaunchKernelGGL((wgrad_rec_kernel<4, 1>), grid, dim3(256), 0, s, p);
+      else if (abl == 2) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2>), grid, dim3(256), 0, s, p);
+      else if (abl == 3) hipLaunchKernelGGL((wgrad_rec_kernel<4, 3>), grid, dim3(256), 0, s, p);
+      else if (abl == 4) hipLaunchKernelGGL((wgrad_rec_kernel<4, 4>), grid, dim3(256), 0, s, p);
+      else if (abl == 5) hipLaunchKernelGGL((wgrad_rec_kernel<4, 5>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_rec_kernel<4, 0>), grid, dim3(256), 0, s, p);
+    } else {
+      dim3 grid((p.M / 128) * (p.N / 128), p.taps, p.S);
+      hipLaunchKernelGGL((wgrad_rec_kernel<2, 0>), grid, dim3(256), 0, s, p);
+    }
+  } else if (p.M <= 64 || p.N <= 64) {
     dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.taps, p.S);
     hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, p);
   } else {
@@ -324,13 +534,19 @@ hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, i
 // ---------------------------------------------------------------------------
 // Column reductions over the rows of row-major [R][C] matrices -> part[chunk][2][C]
 // ---------------------------------------------------------------------------
-constexpr int CR_ROWS = 2048;  // rows per block
-__global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p) {
+// rows per block: about 2048 blocks per launch (eight per CU -- these kernels are HBM streams and one block per CU, which
+// 2048-row chunks gave on the large maps, kept them near 2 TB/s), at least 128 rows each
+static int colreduce_rows(long long R, int C) {
+  const long long col_blocks = (C + 63) / 64, chunks = std::max<long long>(1, 2048 / col_blocks);
+  const long long rows = ((R + chunks - 1) / chunks + 15) / 16 * 16;
+  return (int)std::max<long long>(128, rows);
+}
+__global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p, int rows_per_block) {
   __shared__ float red[16][2][64];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
-  const long long r0 = (long long)blockIdx.y * CR_ROWS;
-  const long long r1 = r0 + CR_ROWS < p.R ? r0 + CR_ROWS : p.R;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = r0 + rows_per_block < p.R ? r0 + rows_per_block : p.R;
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < p.C) {
     float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
@@ -338,6 +554,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { mu[k] = p.mean[c + k]; rs[k] = p.rstd[c + k]; }
     }
+#pragma unroll 4
     for (long long r = r0 + ty; r < r1; r += 16) {
       const size_t off = (size_t)r * p.C + c;
       const float4 a4 = *reinterpret_cast<const float4*>(p.a + off);
@@ -381,35 +598,58 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p) {
     if (cc < p.C) p.part[((size_t)blockIdx.y * 2 + which) * p.C + cc] = v;
   }
 }
-int colreduce_chunks(long long R) { return (int)((R + CR_ROWS - 1) / CR_ROWS); }
+int colreduce_chunks(long long R, int C) {
+  const int rows = colreduce_rows(R, C);
+  return (int)((R + rows - 1) / rows);
+}
 hipError_t launch_colreduce(const ColRedP& p, hipStream_t s) {
   if (p.C % 4 || p.R <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(colreduce_kernel, dim3((p.C + 63) / 64, colreduce_chunks(p.R)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(colreduce_kernel, dim3((p.C + 63) / 64, colreduce_chunks(p.R, p.C)), dim3(256), 0, s, p,
+                     colreduce_rows(p.R, p.C));
   return hipGetLastError();
 }
 // out0[c] = (acc ? out0[c] : 0) + sum_chunks part[.][0][c];  out1 likewise (nullable)
-__global__ void colreduce_final_kernel(const float* __restrict__ part, int chunks, int C, float* out0, float* out1,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int k = 0; k < chunks; ++k) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+// sums over the chunks of part[chunk][2][C] for 32 channels per 256-thread block: eight threads per channel take every
+// eighth chunk (double accumulators), thread 0 of the eight adds their partial sums in a fixed order
+__device__ __forceinline__ void chunk_sums(const float* __restrict__ part, int chunks, int C, int c, int lane8, double (*red)[8][32],
+                                           double& a, double& b) {
+  a = 0.0; b = 0.0;
+  if (c < C)
+    for (int k = lane8; k < chunks; k += 8) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+  red[0][lane8][threadIdx.x & 31] = a;
+  red[1][lane8][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (lane8 == 0) {
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a += red[0][t][threadIdx.x & 31]; b += red[1][t][threadIdx.x & 31]; }
+  }
+}
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, int chunks, int C, float* out0,
+                                                              float* out1, int accumulate) {
+  __shared__ double red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane8 = threadIdx.x >> 5;
+  double a, b;
+  chunk_sums(part, chunks, C, c, lane8, red, a, b);
+  if (lane8 != 0 || c >= C) return;
   if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)a;
   if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)b;
 }
 hipError_t launch_colreduce_final(const float* part, int chunks, int C, float* out0, float* out1, int accumulate,
                                   hipStream_t s) {
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, chunks, C, out0, out1, accumulate);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((C + 31) / 32), dim3(256), 0, s, part, chunks, C, out0, out1, accumulate);
   return hipGetLastError();
 }
 // BatchNorm batch statistics from (sum, sum of squares) partials; running statistics updated in place
 // (momentum 0.1, unbiased variance: nn.BatchNorm2d defaults used by resnet.py).
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, int C, long long R, float eps, float momentum,
-                                   float* mean, float* rstd, float* run_mean, float* run_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int k = 0; k < chunks; ++k) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int chunks, int C, long long R, float eps,
+                                                          float momentum, float* mean, float* rstd, float* run_mean,
+                                                          float* run_var) {
+  __shared__ double red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane8 = threadIdx.x >> 5;
+  double a, b;
+  chunk_sums(part, chunks, C, c, lane8, red, a, b);
+  if (lane8 != 0 || c >= C) return;
   const double m = a / (double)R;
   double var = b / (double)R - m * m;
   if (var < 0.0) var = 0.0;
@@ -423,7 +663,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int chunks, i
 }
 hipError_t launch_bn_finalize(const float* part, int chunks, int C, long long R, float eps, float momentum, float* mean,
                               float* rstd, float* run_mean, float* run_var, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, chunks, C, R, eps, momentum, mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, part, chunks, C, R, eps, momentum, mean,
                      rstd, run_mean, run_var);
   return hipGetLastError();
 }

@@ -280,6 +280,11 @@ int d2t_train_grad(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2
  * copy of loaded tensors (the BatchNorm running statistics after a training forward, as d2t_read_weight). */
 int d2t_train_gather(d2t_ctx* ctx, int32_t source, int32_t n, const char* const* names, const int64_t* offsets,
                      const int64_t* numels, float* flat, d2t_stream stream);
+/* The other direction, after optimizer.step(): refresh the engine's copies of tensors that are ALREADY loaded (same names and
+ * sizes as the d2t_load_weight calls that created them) from device memory, in one kernel.  Folded / packed inference
+ * weights are not rebuilt: call d2t_finalize_weights before the next inference forward (the training step reads the raw copies). */
+int d2t_reload_weights(d2t_ctx* ctx, int32_t n, const char* const* names, const float* const* srcs, const int64_t* numels,
+                       d2t_stream stream);
 /* copy the engine's current copy of a loaded tensor (e.g. BatchNorm running statistics after a training forward) */
 int d2t_read_weight(d2t_ctx* ctx, const char* name, float* dst, int64_t numel, d2t_stream stream);
 /* Dropout of nn.TransformerDecoderLayer(dropout=p) in the training step: on the attention probabilities of both

@@ -53,6 +53,8 @@ CONV_CASES = [
     (2, 512, 4, 12, 512, (2, 2), (1, 1), (0, 0), True, True, False),   # conv4_2
     (1, 512, 16, 129, 512, (3, 3), (1, 1), (1, 1), True, True, True),  # the hot 16x129 layer (odd width)
     (2, 512, 7, 9, 256, (2, 2), (2, 2), (0, 0), False, False, False),  # patch embedding: stride 2, bias, no BN (odd H: floor)
+    (4, 128, 24, 37, 256, (3, 3), (1, 1), (1, 1), True, True, False),  # layer2 entry: 3552 pixels, several row chunks of the
+                                                                       # record weight-gradient kernel, the last one ragged
 ]
 
 
