@@ -691,9 +691,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, const float* __rest
     float o[4] = {v.x, v.y, v.z, v.w};
     float r4[4] = {0, 0, 0, 0};
     if (res) { const float4 t = reinterpret_cast<const float4*>(res)[i]; r4[0] = t.x; r4[1] = t.y; r4[2] = t.z; r4[3] = t.w; }
+    // (per-channel parameters as 16-byte loads: c and C are multiples of 4)
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + c), q4 = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(g + c), b4 = *reinterpret_cast<const float4*>(b + c);
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float t = (o[k] - mean[c + k]) * rstd[c + k] * g[c + k] + b[c + k] + r4[k];
+      float t = (o[k] - mm[k]) * qq[k] * gg[k] + bb[k] + r4[k];
       o[k] = relu ? fmaxf(t, 0.f) : t;
     }
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
@@ -727,10 +732,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
       for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
     }
     float o[4];
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + c), q4 = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 a4 = *reinterpret_cast<const float4*>(s0 + c), b4 = *reinterpret_cast<const float4*>(s1 + c);
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float sa[4] = {a4.x, a4.y, a4.z, a4.w}, sb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float xh = (zz[k] - mean[c + k]) * rstd[c + k];
-      o[k] = gamma[c + k] * rstd[c + k] * (g[k] - s0[c + k] * invR - xh * s1[c + k] * invR);
+      const float xh = (zz[k] - mm[k]) * qq[k];
+      o[k] = gm[k] * qq[k] * (g[k] - sa[k] * invR - xh * sb[k] * invR);
     }
     reinterpret_cast<float4*>(dz)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (planes) store_split4(planes, i, o);
