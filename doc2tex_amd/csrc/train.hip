@@ -1100,7 +1100,7 @@ struct Tr {  // builder / runner bound to one context and stream
       RC(colsum(dz, P, Cout, db));
     }
     if (n.stem) {
-      const int chunk = 4096, nch = (int)((P + chunk - 1) / chunk);
+      const int chunk = 1024, nch = (int)((P + chunk - 1) / chunk);
       RC(ensure_part((size_t)nch * 9 * Cout));
       TCHK(launch_stem_wgrad(st->image, dz, st->part, st->B, st->H, st->W, Cout, chunk, nch, s));
       TCHK(launch_wgrad_reduce(st->part, dW, nch, 9, Cout, 1, 1, 0, s));

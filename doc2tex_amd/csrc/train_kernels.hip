@@ -799,34 +799,46 @@ hipError_t launch_ew(const float* a, const float* b, float* out, size_t n, int o
 // ---------------------------------------------------------------------------
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int B,
                                    int H, int W, int C, int OH, int OW, int SH, int SW, int PH, int PW, int KW) {
-  const size_t total = (size_t)B * H * W * C;
+  const int C4 = C >> 2;  // four channels per thread (C % 4 == 0): one set of index arithmetic, 16-byte accesses
+  const size_t total = (size_t)B * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int w = (int)((i / C) % W), h = (int)((i / ((size_t)C * W)) % H), b = (int)(i / ((size_t)C * W * H));
-    float acc = 0.f;
+    const int c = (int)(i % C4) * 4;
+    const int w = (int)((i / C4) % W), h = (int)((i / ((size_t)C4 * W)) % H), b = (int)(i / ((size_t)C4 * W * H));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // windows (oh, ow) that contain (h, w): oh*SH - PH <= h <= oh*SH - PH + 1
     const int oh_lo = h + PH - 1 > 0 ? (h + PH - 1 + SH - 1) / SH : 0, oh_hi = min((h + PH) / SH, OH - 1);
     const int ow_lo = w + PW - (KW - 1) > 0 ? (w + PW - (KW - 1) + SW - 1) / SW : 0, ow_hi = min((w + PW) / SW, OW - 1);
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        float best = -INFINITY;
-        int bh = -1, bw = -1;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        bool mine[4] = {false, false, false, false};  // is (h, w) the first maximum so far
+        bool any = false;
         for (int kh = 0; kh < 2; ++kh)
           for (int kw = 0; kw < KW; ++kw) {
             const int ih = oh * SH - PH + kh, iw = ow * SW - PW + kw;
             if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
-            const float v = x[(((size_t)b * H + ih) * W + iw) * C + c];
-            if (v > best || bh < 0) { best = v; bh = ih; bw = iw; }
+            const float4 v4 = *reinterpret_cast<const float4*>(x + (((size_t)b * H + ih) * W + iw) * C + c);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const bool here = ih == h && iw == w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k] > best[k] || !any) { best[k] = v[k]; mine[k] = here; }
+            any = true;
           }
-        if (bh == h && bw == w) acc += dy[(((size_t)b * OH + oh) * OW + ow) * C + c];
+        const float4 d4 = *reinterpret_cast<const float4*>(dy + (((size_t)b * OH + oh) * OW + ow) * C + c);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (mine[k]) acc[k] += d[k];
       }
-    dx[i] = acc;
+    *reinterpret_cast<float4*>(dx + i * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 hipError_t launch_maxpool_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int SH, int SW, int PH,
                               int PW, hipStream_t s, int KW) {  // window 2 x KW (KW = 1: VGG's (2,1) pools)
   const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
-  const size_t total = (size_t)B * H * W * C;
+  if (C % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)B * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, x,
                      dy, dx, B, H, W, C, OH, OW, SH, SW, PH, PW, KW);
   return hipGetLastError();
@@ -1288,19 +1300,56 @@ hipError_t launch_embed_train(const float* E, const float* pe, const int64_t* to
   hipLaunchKernelGGL(embed_train_kernel, dim3(rows), dim3(256), 0, s, E, pe, tok, x, rows, L, D, scale);
   return hipGetLastError();
 }
-__global__ void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok, float* __restrict__ dE,
-                                 int rows, int D, float scale, int pad_id) {
-  const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    float a = 0.f;
-    if (v != pad_id)
-      for (int r = 0; r < rows; ++r)
-        if (tok[r] == v) a += dx[(size_t)r * D + c];
-    dE[(size_t)v * D + c] = a * scale;
+// One block per vocabulary row v (deterministic: rows are added in ascending order).  The block first lists the rows whose
+// token is v -- 256 rows per pass, positions by ballot prefix -- and then adds only those (a token occurs in a handful of
+// the B*L rows; scanning every row for every column was 0.37 ms).  D <= 1024.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok,
+                                                        float* __restrict__ dE, int rows, int D, float scale, int pad_id) {
+  constexpr int CAP = 1024;
+  __shared__ int list[CAP + 256];
+  __shared__ int wcnt[4];
+  const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int n = 0;  // rows listed and not yet added (block-uniform)
+  auto flush = [&]() {
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+      const float* src = dx + (size_t)list[k] * D;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = tid + j * 256;
+        if (c < D) acc[j] += src[c];
+      }
+    }
+    __syncthreads();
+    n = 0;
+  };
+  if (v != pad_id) {
+    for (int base = 0; base < rows; base += 256) {
+      const int r = base + tid;
+      const bool hit = r < rows && tok[r] == v;
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = n;
+      for (int w = 0; w < wave; ++w) off += wcnt[w];
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+      const int add = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
+      n += add;
+      if (n >= CAP) flush();
+    }
+    flush();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + j * 256;
+    if (c < D) dE[(size_t)v * D + c] = acc[j] * scale;
   }
 }
 hipError_t launch_embed_bwd(const float* dx, const int64_t* tok, float* dE, int rows, int V, int D, float scale, int pad_id,
                             hipStream_t s) {
+  if (D > 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, s, dx, tok, dE, rows, D, scale, pad_id);
   return hipGetLastError();
 }
@@ -1464,27 +1513,37 @@ hipError_t launch_sum_rows_strided(const float* x, float* out, int B, long long 
 
 // Stem convolution (Cin = 1, 3x3, pad 1) in training mode: raw weights, no bias / BN (z = conv(x)); and its
 // weight gradient dW[co][kh][kw] = sum_p dz[p][co] * x[p + tap]  (block per (co-group), deterministic).
-__global__ void stem_raw_kernel(const float* __restrict__ img, const float* __restrict__ w, float* __restrict__ z, int B,
-                                int H, int W, int Cout) {
-  const size_t total = (size_t)B * H * W * Cout;
+__global__ __launch_bounds__(256) void stem_raw_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                       float* __restrict__ z, int B, int H, int W, int Cout) {
+  // a thread owns four consecutive output channels of one pixel: nine image loads serve all four, the filter comes
+  // from LDS as [tap][co] float4s, the store is 16 bytes
+  __shared__ __attribute__((aligned(16))) float ws[9][64];
+  for (int i = threadIdx.x; i < 9 * Cout; i += 256) ws[i % 9][i / 9] = w[i];  // w is [co][9]
+  __syncthreads();
+  const int C4 = Cout >> 2;
+  const size_t total = (size_t)B * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout);
-    const int x = (int)((i / Cout) % W), y = (int)((i / ((size_t)Cout * W)) % H), b = (int)(i / ((size_t)Cout * W * H));
-    float a = 0.f;
+    const int co = (int)(i % C4) * 4;
+    const int x = (int)((i / C4) % W), y = (int)((i / ((size_t)C4 * W)) % H), b = (int)(i / ((size_t)C4 * W * H));
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = y + kh - 1, iw = x + kw - 1;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-          a = fmaf(img[((size_t)b * H + ih) * W + iw], w[co * 9 + kh * 3 + kw], a);
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float v = img[((size_t)b * H + ih) * W + iw];
+          const float4 w4 = *reinterpret_cast<const float4*>(&ws[kh * 3 + kw][co]);
+          a[0] = fmaf(v, w4.x, a[0]); a[1] = fmaf(v, w4.y, a[1]); a[2] = fmaf(v, w4.z, a[2]); a[3] = fmaf(v, w4.w, a[3]);
+        }
       }
-    z[i] = a;
+    *reinterpret_cast<float4*>(z + i * 4) = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
 hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, int H, int W, int Cout, hipStream_t s) {
-  const size_t total = (size_t)B * H * W * Cout;
-  hipLaunchKernelGGL(stem_raw_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, img, w, z,
+  if (Cout % 4 || Cout > 64) return hipErrorInvalidValue;
+  const size_t total = (size_t)B * H * W * (Cout / 4);
+  hipLaunchKernelGGL(stem_raw_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 16)), dim3(256), 0, s, img, w, z,
                      B, H, W, Cout);
   return hipGetLastError();
 }
