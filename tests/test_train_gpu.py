@@ -546,3 +546,31 @@ def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, nam
         # layer and the coverage recursion; measured 1.2e-3 ... 1.6e-3 on its attention projections (4e-5 in fp32)
         tol = 3e-3
     assert all(v <= tol for _, v, _ in worst.values()), worst
+
+
+def test_weights_follow_the_optimizer_between_steps(cases):
+    """After optimizer.step() the next training forward must run on the updated parameters: the engine refreshes its copies
+    of all of them with one kernel (d2t_reload_weights) instead of one device copy per tensor.  Checked on every tensor
+    through d2t_read_weight, and on the loss: a second step with a large learning rate must not repeat the first one's."""
+    c = _case(cases, "train_step", "t2_train_step")
+    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"])
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.05)
+    loss0, _ = _step(m, img, text)
+    opt.step()
+    loss1, _ = _step(m, img, text)  # sync_weights sees new versions of the same tensors -> the batched refresh
+    assert abs(float(loss1) - float(loss0)) > 1e-3
+    eng = m._engine
+    assert getattr(eng, "_loaded_shapes", None) is not None
+    for name, p in m.named_parameters():
+        got = torch.empty_like(p, dtype=torch.float32).contiguous()
+        eng.read_weight(name, got)
+        assert torch.equal(got, p.detach().float()), name
+    # a tensor the engine has never seen (or a resized one) is refused by the batched call
+    import ctypes as C
+    from doc2tex_amd import _lib
+    bad = torch.zeros(7, device="cuda")
+    rc = eng.lib.d2t_reload_weights(eng.ctx, 1, (C.c_char_p * 1)(b"no.such.tensor"), (C.c_void_p * 1)(bad.data_ptr()),
+                                    (C.c_int64 * 1)(7), _lib.stream_of(bad))
+    assert rc != 0
