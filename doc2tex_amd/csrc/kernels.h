@@ -312,7 +312,7 @@ struct WgradP {
   const void* zero = nullptr;
 };
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s);
-bool wgrad_rec_wide(int M);  // record kernel: 256 x 128 block tiles (two blocks per CU) instead of 128 x 128 (three)
+int wgrad_rec_shape(int M, int N);  // record kernel's block tile: 0 = 128 x 128 (three blocks per CU), 1 = 256 x 128 (two), 2 = 256 x 256 (one)
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
                                hipStream_t s);
 enum { CR_SUM = 0, CR_SUM_SQ = 1, CR_BN_BWD = 2, CR_LN_BWD = 3 };

@@ -238,12 +238,12 @@ struct Tr {  // builder / runner bound to one context and stream
     const bool rec = !rec_off && a_rec && b_rec && geom && c->conv_bf16x3 && c->zero_page && M % 128 == 0 && N % 128 == 0 &&
                      lda == M && ldb == N;
     const int tile = (M <= 64 || N <= 64) ? 64 : 128;
-    const bool wide = rec && wgrad_rec_wide(M);
-    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps / (wide ? 2 : 1);
+    const int shape = rec ? wgrad_rec_shape(M, N) : 0;
+    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps / (shape == 2 ? 4 : shape == 1 ? 2 : 1);
     // split the rows into S chunks so that tiles * S blocks fill whole rounds of the block slots (two 64 KB-LDS blocks per
     // CU on 256 CUs; three of the record kernel's 48 KB blocks): among the S that give >= ~2 rounds pick the one wasting
     // least of its last round
-    const long long slots = rec && !wide ? 768 : 512;
+    const long long slots = !rec ? 512 : shape == 2 ? 256 : shape == 1 ? 512 : 768;
     const long long smax = std::max<long long>(1, (P + 511) / 512);
     long long S = 1;
     double best = -1.0;

@@ -307,37 +307,41 @@ __device__ __forceinline__ void wg_wait_vm() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <int MI, int ABL = 0>  // (ABL: timing probes -- 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA, 4 plain ds_read_b64,
-                               //  5 the step's LDS-DMA issued in one burst behind the barrier)
-                               // wave tile (32 MI) x 64, block tile (64 MI) x 128: MI = 2 -> 128 x 128, three blocks per CU; 4 -> 256 x 128, two
-__global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const WgradP p) {
-  constexpr int BK = 16, NS = 3, BM = 64 * MI;
-  constexpr int AROWB = BM * 4, BROWB = 512;        // bytes per LDS row: the tile's records of one pixel
+template <int MI, int NWN, int ABL = 0>  // (ABL: timing probes -- 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA, 4 plain ds_read_b64,
+                                        //  5 the step's LDS-DMA issued in one burst behind the barrier)
+// wave tile (32 MI) x 64, 2 x NWN waves: block tile (64 MI) x (64 NWN) -- <2,2> 128 x 128, three blocks per CU; <4,2> 256 x 128,
+// two; <4,4> 256 x 256 with 512 threads, one (a third less L2 -> LDS traffic per MFMA than 256 x 128)
+__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void wgrad_rec_kernel(const WgradP p) {
+  constexpr int BK = 16, NS = 3, BM = 64 * MI, BN = 64 * NWN, NT = 128 * NWN;
+  constexpr int AROWB = BM * 4, BROWB = BN * 4;      // bytes per LDS row: the tile's records of one pixel
   constexpr int AOPB = BK * AROWB, BOPB = BK * BROWB, STAGE = AOPB + BOPB;
-  constexpr int ACH = AROWB / 16;                    // 16-byte chunks per A row (32 | 64)
-  constexpr int ARPI = 256 / ACH, ANI = BK / ARPI;   // A rows per block-wide DMA instruction, instructions per step
+  constexpr int ACH = AROWB / 16, BCH = BROWB / 16;  // 16-byte chunks per row
+  constexpr int ARPI = NT / ACH, ANI = BK / ARPI;    // rows per block-wide DMA instruction, instructions per step
+  constexpr int BRPI = NT / BCH, BNI = BK / BRPI;
+  constexpr int PIECES = ANI + BNI, IBYTES = NT * 16;
+  static_assert(ARPI % 4 == 0 && BRPI % 4 == 0, "the source-side swizzle needs (row + k RPI) & 3 == row & 3");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tiles_n = p.N / 128;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * 128;
+  const int tiles_n = p.N / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int tap = blockIdx.y, kh = tap / p.KW, kw = tap % p.KW;
   const long long r_begin = (long long)blockIdx.z * p.chunk;
   const long long r_end = r_begin + p.chunk < p.P ? r_begin + p.chunk : p.P;
   const int KT = (int)((r_end - r_begin + BK - 1) / BK);
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero) + (lane & 15) * 16;
 
-  // ---- LDS-DMA source side.  A: rows arow + ARPI i (i < ANI) of every stage, chunk position acpos; B: rows brow, brow + 8 ----
-  const int arow = tid / ACH, acpos = tid % ACH, brow = tid >> 5, bcpos = tid & 31;
-  const int acsrc = acpos ^ ((arow & 3) << 2), bcsrc = bcpos ^ ((brow & 3) << 2);  // (row + 4 k) & 3 == row & 3
+  // ---- LDS-DMA source side.  A: rows arow + ARPI i (i < ANI) of every stage, chunk position acpos; B: rows brow + BRPI i ----
+  const int arow = tid / ACH, acpos = tid % ACH, brow = tid / BCH, bcpos = tid % BCH;
+  const int acsrc = acpos ^ ((arow & 3) << 2), bcsrc = bcpos ^ ((brow & 3) << 2);
   const size_t arow_b = (size_t)p.M * 4, brow_b = (size_t)p.N * 4;  // bytes per pixel row of the record arrays
   const unsigned char* a_src = reinterpret_cast<const unsigned char*>(p.a_rec) + (size_t)(r_begin + arow) * arow_b +
                                (size_t)(m0 / 32 + (acsrc >> 3)) * 128 + (acsrc & 7) * 16;
   const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.b_rec) + (size_t)(n0 / 32 + (bcsrc >> 3)) * 128 + (bcsrc & 7) * 16;
   long long rr = r_begin;  // first pixel row of the step about to be issued
-  int pb[2], poh[2], pow_[2];
+  int pb[BNI], poh[BNI], pow_[BNI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long long r = r_begin + brow + 8 * i;
+  for (int i = 0; i < BNI; ++i) {
+    const long long r = r_begin + brow + BRPI * i;
     const int ohow = p.OH * p.OW;
     pb[i] = (int)(r / ohow);
     const int rem = (int)(r - (long long)pb[i] * ohow);
@@ -345,41 +349,36 @@ __global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const W
     pow_[i] = rem - poh[i] * p.OW;
   }
   long long rrb = r_begin;
-  // one LDS-DMA instruction of the stage: pieces 0 .. ANI-1 = the A rows, ANI, ANI+1 = the B rows
+  // one LDS-DMA instruction of the stage: pieces 0 .. ANI-1 = the A rows, ANI .. ANI+BNI-1 = the B rows
   auto issue_piece = [&](int stage, int k) {
     unsigned char* sa = smem + stage * STAGE + wave * 1024;  // wave-uniform bases; the hardware adds 16 * lane
     if (k < ANI) {
       const bool live = rr + arow + ARPI * k < r_end;
       const unsigned char* as = live ? a_src + (size_t)(ARPI * k) * arow_b : zero;
-      __builtin_amdgcn_global_load_lds(as, (lds_void_ptr)(sa + k * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(as, (lds_void_ptr)(sa + k * IBYTES), 16, 0, 0);
       if (k == ANI - 1) { a_src += (size_t)BK * arow_b; rr += BK; }
     } else {
       const int i = k - ANI;
-      const bool live = rrb + brow + 8 * i < r_end;
+      const bool live = rrb + brow + BRPI * i < r_end;
       const int ih = poh[i] * p.SH - p.PH + kh, iw = pow_[i] * p.SW - p.PW + kw;
       const bool ok = live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       const unsigned char* bs = ok ? b_base + ((size_t)((long long)pb[i] * p.H + ih) * p.W + iw) * brow_b : zero;
-      __builtin_amdgcn_global_load_lds(bs, (lds_void_ptr)(sa + AOPB + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(bs, (lds_void_ptr)(sa + AOPB + i * IBYTES), 16, 0, 0);
       pow_[i] += BK;  // advance to the same piece of the next step
       while (pow_[i] >= p.OW) {
         pow_[i] -= p.OW;
         if (++poh[i] == p.OH) { poh[i] = 0; ++pb[i]; }
       }
-      if (i == 1) rrb += BK;
+      if (i == BNI - 1) rrb += BK;
     }
   };
-  auto issue_a = [&](int stage) {
+  auto issue = [&](int stage) {
 #pragma unroll
-    for (int k = 0; k < ANI; ++k) issue_piece(stage, k);
+    for (int k = 0; k < PIECES; ++k) issue_piece(stage, k);
   };
-  auto issue_b = [&](int stage) {
-    issue_piece(stage, ANI);
-    issue_piece(stage, ANI + 1);
-  };
-  auto issue = [&](int stage) { issue_a(stage); issue_b(stage); };
 
   // ---- fragment side ----
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int wm = wave / NWN, wn = wave % NWN, r = lane & 31, h = lane >> 5;
   const int g16 = lane >> 4, l16 = lane & 15;
   const int frow = 8 * (g16 >> 1) + (l16 >> 2), fx = ((l16 >> 2) & 3) << 2, fsub = (g16 & 1) * 2 + ((l16 & 3) >> 1);
   int offa[MI][2], offb[2][2];  // [fragment][hi, lo]
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const W
   constexpr bool burst = ABL == 3 || ABL == 5;
   bf16x8_t ah[MI], al[MI], bh[2], bl[2];
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) wg_wait_vm<ANI + 2>(); else wg_wait_vm<0>();  // this wave's pieces of step kt have landed
+    if (kt + 1 < KT) wg_wait_vm<PIECES>(); else wg_wait_vm<0>();  // this wave's pieces of step kt have landed
     __builtin_amdgcn_s_barrier();  // ... and everybody else's; nobody reads stage kt-1 any more
     if (burst && kt + 2 < KT && (ABL != 3 || kt + 2 < 3)) issue(nxt2);
     __builtin_amdgcn_sched_barrier(0);
@@ -449,12 +448,13 @@ __global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const W
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-        // the LDS-DMA of step kt+2: one instruction behind each (i, j) group of MFMAs, the last ANI + 2 groups of the step.
+        // the LDS-DMA of step kt+2: one instruction behind each (i, j) group of MFMAs, the last PIECES groups of the step.
         // (In one burst behind the barrier the waves of a block queue up in the vector-memory path together and the
         // MFMAs wait behind them: 951 us on the dominant layer against 833 us this way; all at once after the first /
         // second row of groups: 867 / 847 us.)
         if (!burst && kt + 2 < KT) {
-          constexpr int first = 2 * MI - (ANI + 2);
+          constexpr int first = 2 * MI - PIECES;
+          static_assert(first >= 0, "more DMA pieces than MFMA groups");
           const int g = 2 * i + j - first;
           if (g >= 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(nxt2, g); __builtin_amdgcn_sched_barrier(0); }
         }
@@ -478,27 +478,34 @@ __global__ __launch_bounds__(256, MI == 2 ? 3 : 2) void wgrad_rec_kernel(const W
     }
 }
 
-bool wgrad_rec_wide(int M) {
-  static const int mode = getenv("D2T_WGRAD_WIDE") ? atoi(getenv("D2T_WGRAD_WIDE")) : 1;
-  return mode && M % 256 == 0;
+// block tile of the record kernel: 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256 (D2T_WGRAD_WIDE caps it)
+int wgrad_rec_shape(int M, int N) {
+  static const int mode = getenv("D2T_WGRAD_WIDE") ? atoi(getenv("D2T_WGRAD_WIDE")) : 2;
+  if (mode >= 2 && M % 256 == 0 && N % 256 == 0) return 2;
+  if (mode >= 1 && M % 256 == 0) return 1;
+  return 0;
 }
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.P <= 0) return hipSuccess;
   if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
   if (p.a_rec) {  // record operands: see wgrad_rec_ok
     if (!p.b_rec || !p.zero || !p.geom || !p.bf16x3 || p.M % 128 || p.N % 128 || p.chunk % 16) return hipErrorInvalidValue;
-    if (wgrad_rec_wide(p.M)) {
+    static const int abl = getenv("D2T_WGRAD_ABL") ? atoi(getenv("D2T_WGRAD_ABL")) : 0;
+    const int shape = wgrad_rec_shape(p.M, p.N);
+    if (shape == 2) {
+      dim3 grid((p.M / 256) * (p.N / 256), p.taps, p.S);
+      hipLaunchKernelGGL((wgrad_rec_kernel<4, 4, 0>), grid, dim3(512), 0, s, p);
+    } else if (shape == 1) {
       dim3 grid((p.M / 256) * (p.N / 128), p.taps, p.S);
-      static const int abl = getenv("D2T_WGRAD_ABL") ? atoi(getenv("D2T_WGRAD_ABL")) : 0;
-      if (abl == 1) hipLaunchKernelGGL((wgrad_rec_kernel<4, 1>), grid, dim3(256), 0, s, p);
-      else if (abl == 2) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2>), grid, dim3(256), 0, s, p);
-      else if (abl == 3) hipLaunchKernelGGL((wgrad_rec_kernel<4, 3>), grid, dim3(256), 0, s, p);
-      else if (abl == 4) hipLaunchKernelGGL((wgrad_rec_kernel<4, 4>), grid, dim3(256), 0, s, p);
-      else if (abl == 5) hipLaunchKernelGGL((wgrad_rec_kernel<4, 5>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((wgrad_rec_kernel<4, 0>), grid, dim3(256), 0, s, p);
+      if (abl == 1) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 1>), grid, dim3(256), 0, s, p);
+      else if (abl == 2) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2>), grid, dim3(256), 0, s, p);
+      else if (abl == 3) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 3>), grid, dim3(256), 0, s, p);
+      else if (abl == 4) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 4>), grid, dim3(256), 0, s, p);
+      else if (abl == 5) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 5>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 0>), grid, dim3(256), 0, s, p);
     } else {
       dim3 grid((p.M / 128) * (p.N / 128), p.taps, p.S);
-      hipLaunchKernelGGL((wgrad_rec_kernel<2, 0>), grid, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((wgrad_rec_kernel<2, 2, 0>), grid, dim3(256), 0, s, p);
     }
   } else if (p.M <= 64 || p.N <= 64) {
     dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.taps, p.S);
@@ -523,9 +530,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     dst[o] = accumulate ? dst[o] + v : v;
   }
 }
+// few outputs, many partials (the stem's 288 filter taps over ~2000 pixel chunks): one block per output, its 256 threads
+// take every 256th partial and a fixed-order tree adds them (a thread per output would walk the partials serially)
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ part, float* __restrict__ dst, int S,
+                                                                 int taps, int M, int N, int layout, int accumulate) {
+  __shared__ float red[256];
+  const size_t total = (size_t)taps * M * N, i = blockIdx.x;
+  float v = 0.f;
+  for (int z = threadIdx.x; z < S; z += 256) v += part[(size_t)z * total + i];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int n = (int)(i % N), m = (int)((i / N) % M), tap = (int)(i / ((size_t)M * N));
+    const size_t o = layout == 1 ? ((size_t)m * N + n) * taps + tap : (size_t)m * N + n;
+    dst[o] = accumulate ? dst[o] + red[0] : red[0];
+  }
+}
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
                                hipStream_t s) {
   const size_t total = (size_t)taps * M * N;
+  if (total <= 4096 && S >= 256) {
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)total), dim3(256), 0, s, part, dst, S, taps, M, N, layout,
+                       accumulate);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, part,
                      dst, S, taps, M, N, layout, accumulate);
   return hipGetLastError();
