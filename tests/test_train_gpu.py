@@ -524,7 +524,8 @@ def test_gradients_with_the_engines_own_decisions_replayed(cases, manifests, nam
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"], precision=precision)
     worst = {}
-    for iseed in (c["iseed"], 1130, 1230):
+    # three instances on the HybridViT + TFM stack, two on the others (~6 s of float64 autograd each)
+    for iseed in ((c["iseed"], 1130, 1230) if name.startswith("t2") else (c["iseed"], 1130)):
         img = synth.synth_images(c["B"], c["H"], c["W"], seed=iseed)
         text = train_step_labels({**c, "iseed": iseed})
         m.load_state_dict({k: v for k, v in synth.synth_state_dict(m.state_dict(), seed=c["wseed"]).items()})
