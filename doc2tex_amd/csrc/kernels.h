@@ -306,13 +306,15 @@ struct WgradP {
   int S, chunk;     // split over row chunks of `chunk` rows
   int bf16x3;       // 128 x 128 tiles only: split-bf16 arithmetic (three bf16 MFMAs per product)
   // both set: the operands as split-bf16 records ([row][32 x hi | 32 x lo] per 32-column group, conv_common.h) of a / b --
-  // geom convolutions with M % 128 == N % 128 == 0 and chunk % 16 == 0 in bf16x3 mode; `zero`: 256 zero bytes
+  // geom convolutions with wgrad_rec_shape(M, N) >= 0 and chunk % 16 == 0 in bf16x3 mode; `zero`: 256 zero bytes
   const uint16_t* a_rec = nullptr;
   const uint16_t* b_rec = nullptr;
   const void* zero = nullptr;
 };
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s);
-int wgrad_rec_shape(int M, int N);  // record kernel's block tile: 0 = 128 x 128 (three blocks per CU), 1 = 256 x 128 (two), 2 = 256 x 256 (one)
+// record kernel's block tile: 0 = 128 x 128 (three blocks per CU), 1 = 256 x 128 (two), 2 = 256 x 256 (one), 3 = 128 x 64 (N = 64),
+// 4 = 64 x 32 (M = 64, N = 32); -1 = not served
+int wgrad_rec_shape(int M, int N);
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
                                hipStream_t s);
 enum { CR_SUM = 0, CR_SUM_SQ = 1, CR_BN_BWD = 2, CR_LN_BWD = 3 };

@@ -235,15 +235,16 @@ struct Tr {  // builder / runner bound to one context and stream
             const uint16_t* b_rec = nullptr) {
     // both operands exist as split-bf16 records (a convolution between BatchNorm layers): the LDS-DMA kernel
     static const bool rec_off = getenv("D2T_WGRAD_REC") && atoi(getenv("D2T_WGRAD_REC")) == 0;
-    const bool rec = !rec_off && a_rec && b_rec && geom && c->conv_bf16x3 && c->zero_page && M % 128 == 0 && N % 128 == 0 &&
-                     lda == M && ldb == N;
+    const int shape = !rec_off && a_rec && b_rec && geom && c->conv_bf16x3 && c->zero_page && lda == M && ldb == N ? wgrad_rec_shape(M, N) : -1;
+    const bool rec = shape >= 0;
+    static const int TM[5] = {128, 256, 256, 128, 64}, TN[5] = {128, 128, 256, 64, 32}, SLOTS[5] = {768, 512, 256, 1024, 2048};
     const int tile = (M <= 64 || N <= 64) ? 64 : 128;
-    const int shape = rec ? wgrad_rec_shape(M, N) : 0;
-    const long long tiles = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps / (shape == 2 ? 4 : shape == 1 ? 2 : 1);
+    const long long tiles = rec ? (long long)(M / TM[shape]) * (N / TN[shape]) * taps
+                                : (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile) * taps;
     // split the rows into S chunks so that tiles * S blocks fill whole rounds of the block slots (two 64 KB-LDS blocks per
-    // CU on 256 CUs; three of the record kernel's 48 KB blocks): among the S that give >= ~2 rounds pick the one wasting
-    // least of its last round
-    const long long slots = !rec ? 512 : shape == 2 ? 256 : shape == 1 ? 512 : 768;
+    // CU on 256 CUs; the record kernel: one to eight per CU by tile shape): among the S that give >= ~2 rounds pick the
+    // one wasting least of its last round
+    const long long slots = rec ? SLOTS[shape] : 512;
     const long long smax = std::max<long long>(1, (P + 511) / 512);
     long long S = 1;
     double best = -1.0;

@@ -307,12 +307,25 @@ __device__ __forceinline__ void wg_wait_vm() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <int MI, int NWN, int ABL = 0>  // (ABL: timing probes -- 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA, 4 plain ds_read_b64,
-                                        //  5 the step's LDS-DMA issued in one burst behind the barrier)
-// wave tile (32 MI) x 64, 2 x NWN waves: block tile (64 MI) x (64 NWN) -- <2,2> 128 x 128, three blocks per CU; <4,2> 256 x 128,
-// two; <4,4> 256 x 256 with 512 threads, one (a third less L2 -> LDS traffic per MFMA than 256 x 128)
-__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void wgrad_rec_kernel(const WgradP p) {
-  constexpr int BK = 16, NS = 3, BM = 64 * MI, BN = 64 * NWN, NT = 128 * NWN;
+// chunk swizzle of an LDS row of ROWB bytes: the four consecutive rows of a transposing read must start in four different
+// 64-byte slots modulo 256 bytes.  Rows of 256 bytes or more all start in the same slot: XOR the row's low two bits into
+// bits 2-3 of the chunk index; 128-byte rows alternate between two slots: flip bit 2 (hi <-> lo half) on rows 2, 3 mod 4.
+template <int ROWB>
+__device__ __forceinline__ int wg_swz(int row) {
+  static_assert(ROWB >= 128, "a row holds at least one record");
+  return ROWB >= 256 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;
+}
+
+template <int MI, int NJ, int WM, int WN, int ABL = 0>
+// (ABL: timing probes -- 1 no MFMAs, 2 no fragment reads, 3 no LDS-DMA, 4 plain ds_read_b64, 5 the step's LDS-DMA issued
+// in one burst behind the barrier)
+// wave tile (32 MI) x (32 NJ), WM x WN waves.  <4,2,2,4> 256 x 256 with 512 threads, one block per CU (a third less
+// L2 -> LDS traffic per MFMA than 256 x 128); <4,2,2,2> 256 x 128, two; <2,2,2,2> 128 x 128, three; and for the narrow
+// layers at the front of the network <2,2,2,1> 128 x 64 (two waves) and <2,1,1,1> 64 x 32 (one wave)
+// (second launch bound = waves per SIMD the register budget must allow: 3 for the 128 x 128 tile, 2 otherwise)
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 && MI == 2 ? 3 : 2)
+void wgrad_rec_kernel(const WgradP p) {
+  constexpr int BK = 16, NS = 3, BM = 32 * MI * WM, BN = 32 * NJ * WN, NT = 64 * WM * WN;
   constexpr int AROWB = BM * 4, BROWB = BN * 4;      // bytes per LDS row: the tile's records of one pixel
   constexpr int AOPB = BK * AROWB, BOPB = BK * BROWB, STAGE = AOPB + BOPB;
   constexpr int ACH = AROWB / 16, BCH = BROWB / 16;  // 16-byte chunks per row
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
 
   // ---- LDS-DMA source side.  A: rows arow + ARPI i (i < ANI) of every stage, chunk position acpos; B: rows brow + BRPI i ----
   const int arow = tid / ACH, acpos = tid % ACH, brow = tid / BCH, bcpos = tid % BCH;
-  const int acsrc = acpos ^ ((arow & 3) << 2), bcsrc = bcpos ^ ((brow & 3) << 2);
+  const int acsrc = acpos ^ wg_swz<AROWB>(arow), bcsrc = bcpos ^ wg_swz<BROWB>(brow);
   const size_t arow_b = (size_t)p.M * 4, brow_b = (size_t)p.N * 4;  // bytes per pixel row of the record arrays
   const unsigned char* a_src = reinterpret_cast<const unsigned char*>(p.a_rec) + (size_t)(r_begin + arow) * arow_b +
                                (size_t)(m0 / 32 + (acsrc >> 3)) * 128 + (acsrc & 7) * 16;
@@ -378,18 +391,20 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
   };
 
   // ---- fragment side ----
-  const int wm = wave / NWN, wn = wave % NWN, r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
   const int g16 = lane >> 4, l16 = lane & 15;
-  const int frow = 8 * (g16 >> 1) + (l16 >> 2), fx = ((l16 >> 2) & 3) << 2, fsub = (g16 & 1) * 2 + ((l16 & 3) >> 1);
-  int offa[MI][2], offb[2][2];  // [fragment][hi, lo]
+  // (the second transposing read of a fragment is four rows further down: same swizzle term)
+  const int frow = 8 * (g16 >> 1) + (l16 >> 2), fsub = (g16 & 1) * 2 + ((l16 & 3) >> 1);
+  const int fxa = wg_swz<AROWB>(frow), fxb = wg_swz<BROWB>(frow);
+  int offa[MI][2], offb[NJ][2];  // [fragment][hi, lo]
 #pragma unroll
   for (int part = 0; part < 2; ++part) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
-      offa[i][part] = frow * AROWB + (l16 & 1) * 8 + (((((wm * MI + i) << 3) | (part << 2) | fsub) ^ fx) << 4);
+      offa[i][part] = frow * AROWB + (l16 & 1) * 8 + (((((wm * MI + i) << 3) | (part << 2) | fsub) ^ fxa) << 4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      offb[j][part] = AOPB + frow * BROWB + (l16 & 1) * 8 + (((((wn * 2 + j) << 3) | (part << 2) | fsub) ^ fx) << 4);
+    for (int j = 0; j < NJ; ++j)
+      offb[j][part] = AOPB + frow * BROWB + (l16 & 1) * 8 + (((((wn * NJ + j) << 3) | (part << 2) | fsub) ^ fxb) << 4);
   }
   auto frag = [&](const unsigned char* q, int rowb) -> bf16x8_t {
     if (ABL == 4) {
@@ -402,11 +417,11 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
     s8_t v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  f32x16 acc[MI][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
   if (KT > 1) issue(1);
   int cur = 0, nxt2 = 2;
   constexpr bool burst = ABL == 3 || ABL == 5;
-  bf16x8_t ah[MI], al[MI], bh[2], bl[2];
+  bf16x8_t ah[MI], al[MI], bh[NJ], bl[NJ];
   for (int kt = 0; kt < KT; ++kt) {
     if (kt + 1 < KT) wg_wait_vm<PIECES>(); else wg_wait_vm<0>();  // this wave's pieces of step kt have landed
     __builtin_amdgcn_s_barrier();  // ... and everybody else's; nobody reads stage kt-1 any more
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
     const unsigned char* st = smem + cur * STAGE;
     if (ABL != 2 || kt == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         bh[j] = frag(st + offb[j][0], BROWB);
         bl[j] = frag(st + offb[j][1], BROWB);
       }
@@ -437,12 +452,12 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
 #pragma unroll
       for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (ABL != 1 || kt == 0) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
@@ -452,11 +467,18 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
         // (In one burst behind the barrier the waves of a block queue up in the vector-memory path together and the
         // MFMAs wait behind them: 951 us on the dominant layer against 833 us this way; all at once after the first /
         // second row of groups: 867 / 847 us.)
+        // The narrow tiles have more pieces than groups: PPG pieces behind each group from the first on.
         if (!burst && kt + 2 < KT) {
-          constexpr int first = 2 * MI - PIECES;
-          static_assert(first >= 0, "more DMA pieces than MFMA groups");
-          const int g = 2 * i + j - first;
-          if (g >= 0) { __builtin_amdgcn_sched_barrier(0); issue_piece(nxt2, g); __builtin_amdgcn_sched_barrier(0); }
+          constexpr int GROUPS = MI * NJ, PPG = (PIECES + GROUPS - 1) / GROUPS;
+          constexpr int first = PPG == 1 ? GROUPS - PIECES : 0;
+          const int g = i * NJ + j - first;
+          if (g >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PPG; ++q)
+              if (g * PPG + q < PIECES) issue_piece(nxt2, g * PPG + q);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -468,8 +490,8 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * 32 * NJ + j * 32 + r;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + wm * 32 * MI + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -478,34 +500,49 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 2 ? 3 : 2)) void w
     }
 }
 
-// block tile of the record kernel: 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256 (D2T_WGRAD_WIDE caps it)
+// block tile of the record kernel: 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256 (D2T_WGRAD_WIDE caps these three),
+// 3 = 128 x 64 (Cin = 64), 4 = 64 x 32 (conv0_2: 32 -> 64 channels); -1: the channel counts fit none of them
 int wgrad_rec_shape(int M, int N) {
   static const int mode = getenv("D2T_WGRAD_WIDE") ? atoi(getenv("D2T_WGRAD_WIDE")) : 2;
-  if (mode >= 2 && M % 256 == 0 && N % 256 == 0) return 2;
-  if (mode >= 1 && M % 256 == 0) return 1;
-  return 0;
+  static const bool narrow = !(getenv("D2T_WGRAD_NARROW") && atoi(getenv("D2T_WGRAD_NARROW")) == 0);
+  if (M % 128 == 0 && N % 128 == 0) {
+    if (mode >= 2 && M % 256 == 0 && N % 256 == 0) return 2;
+    if (mode >= 1 && M % 256 == 0) return 1;
+    return 0;
+  }
+  if (narrow && M % 128 == 0 && N == 64) return 3;
+  if (narrow && M == 64 && N == 32) return 4;
+  return -1;
 }
 hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.P <= 0) return hipSuccess;
   if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
   if (p.a_rec) {  // record operands: see wgrad_rec_ok
-    if (!p.b_rec || !p.zero || !p.geom || !p.bf16x3 || p.M % 128 || p.N % 128 || p.chunk % 16) return hipErrorInvalidValue;
+    if (!p.b_rec || !p.zero || !p.geom || !p.bf16x3 || wgrad_rec_shape(p.M, p.N) < 0 || p.chunk % 16) return hipErrorInvalidValue;
     static const int abl = getenv("D2T_WGRAD_ABL") ? atoi(getenv("D2T_WGRAD_ABL")) : 0;
     const int shape = wgrad_rec_shape(p.M, p.N);
     if (shape == 2) {
       dim3 grid((p.M / 256) * (p.N / 256), p.taps, p.S);
-      hipLaunchKernelGGL((wgrad_rec_kernel<4, 4, 0>), grid, dim3(512), 0, s, p);
+      hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 4, 0>), grid, dim3(512), 0, s, p);
     } else if (shape == 1) {
       dim3 grid((p.M / 256) * (p.N / 128), p.taps, p.S);
-      if (abl == 1) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 1>), grid, dim3(256), 0, s, p);
-      else if (abl == 2) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2>), grid, dim3(256), 0, s, p);
-      else if (abl == 3) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 3>), grid, dim3(256), 0, s, p);
-      else if (abl == 4) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 4>), grid, dim3(256), 0, s, p);
-      else if (abl == 5) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 5>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 0>), grid, dim3(256), 0, s, p);
-    } else {
+      if (abl == 1) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 1>), grid, dim3(256), 0, s, p);
+      else if (abl == 2) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+      else if (abl == 3) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 3>), grid, dim3(256), 0, s, p);
+      else if (abl == 4) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 4>), grid, dim3(256), 0, s, p);
+      else if (abl == 5) hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 5>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_rec_kernel<4, 2, 2, 2, 0>), grid, dim3(256), 0, s, p);
+    } else if (shape == 0) {
       dim3 grid((p.M / 128) * (p.N / 128), p.taps, p.S);
-      hipLaunchKernelGGL((wgrad_rec_kernel<2, 2, 0>), grid, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((wgrad_rec_kernel<2, 2, 2, 2, 0>), grid, dim3(256), 0, s, p);
+    } else if (shape == 3) {
+      dim3 grid((p.M / 128) * (p.N / 64), p.taps, p.S);
+      hipLaunchKernelGGL((wgrad_rec_kernel<2, 2, 2, 1, 0>), grid, dim3(128), 0, s, p);
+    } else if (shape == 4) {
+      dim3 grid((p.M / 64) * (p.N / 32), p.taps, p.S);
+      hipLaunchKernelGGL((wgrad_rec_kernel<2, 1, 1, 1, 0>), grid, dim3(64), 0, s, p);
+    } else {
+      return hipErrorInvalidValue;
     }
   } else if (p.M <= 64 || p.N <= 64) {
     dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.taps, p.S);
