@@ -567,7 +567,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     dst[o] = accumulate ? dst[o] + v : v;
   }
 }
-// few outputs, many partials (the stem's 288 filter taps over ~2000 pixel chunks): one block per output, its 256 threads
+// few outputs, many partials (the stem's 288 filter taps over ~2000 pixel chunks, conv0_2's 18432 over 227): one block per output, its 256 threads
 // take every 256th partial and a fixed-order tree adds them (a thread per output would walk the partials serially)
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ part, float* __restrict__ dst, int S,
                                                                  int taps, int M, int N, int layout, int accumulate) {
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
 hipError_t launch_wgrad_reduce(const float* part, float* dst, int S, int taps, int M, int N, int layout, int accumulate,
                                hipStream_t s) {
   const size_t total = (size_t)taps * M * N;
-  if (total <= 4096 && S >= 256) {
+  if ((total <= 4096 && S >= 256) || (total <= 65536 && S >= 128)) {
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)total), dim3(256), 0, s, part, dst, S, taps, M, N, layout,
                        accumulate);
     return hipGetLastError();
