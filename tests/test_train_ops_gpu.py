@@ -55,6 +55,8 @@ CONV_CASES = [
     (2, 512, 7, 9, 256, (2, 2), (2, 2), (0, 0), False, False, False),  # patch embedding: stride 2, bias, no BN (odd H: floor)
     (4, 128, 24, 37, 256, (3, 3), (1, 1), (1, 1), True, True, False),  # layer2 entry: 3552 pixels, several row chunks of the
                                                                        # record weight-gradient kernel, the last one ragged
+    (3, 128, 10, 18, 128, (3, 3), (1, 1), (1, 1), True, True, True),   # layer1.conv2: the 128 x 128 tile of that kernel (the
+                                                                       # cases above take 64 x 32, 128 x 64, 256 x 128, 256 x 256)
 ]
 
 
