@@ -356,6 +356,7 @@ struct AttnTrainP {
   int B, heads, hd, Lq, Lk, ldq, ldk, ldv, ldo, causal, pad_id;
   const uint8_t* dropmask; // optional [B][heads][Lq][Lk] keep mask of the attention-probability dropout
   float dropscale;         // 1 / (1 - p)
+  int probe = 0;           // timing probe of the backward kernel (D2T_ATTN_BWD_PROBE): bit k set = phase k+1 skipped
 };
 hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s);
 hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s);

@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainP p
     constexpr int PH = 64 / HD;
     const int c = lane % HD, ph = lane / HD;
     float o = 0.f;
+#pragma unroll 8
     for (int j = ph; j < p.Lk; j += PH) o = fmaf(P[j], Vs[j * HD + c], o);
     if (PH == 2) o += __shfl_xor(o, 32, 64);
     if (lane < HD) p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c] = o;
@@ -1194,6 +1195,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
   // phase 1: dV[j][c] = sum_i (P o D)[i][j] * dO[i][c]   (wave per key; D = dropout keep mask * scale)
   for (int j = wave; j < p.Lk; j += 4) {
     float a = 0.f;
+#pragma unroll 8
     for (int i = ph; i < p.Lq; i += PH) {
       float w = probs[(size_t)i * p.Lk + j];
       if (dmask) w *= dmask[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
@@ -1231,6 +1233,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
       Ds[wave * p.Lk + j] = ds;
     }
     float a = 0.f;
+#pragma unroll 8
     for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[j * (HD + 1) + c], a);
     if (PH == 2) a += __shfl_xor(a, 32, 64);
     if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
@@ -1239,6 +1242,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
   // phase 3: dK[j][c] = scale * sum_i dS[i][j] * Q[i][c]   (wave per key)
   for (int j = wave; j < p.Lk; j += 4) {
     float a = 0.f;
+#pragma unroll 8
     for (int i = ph; i < p.Lq; i += PH) a = fmaf(probs[(size_t)i * p.Lk + j], p.q[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c], a);
     if (PH == 2) a += __shfl_xor(a, 32, 64);
     if (lane < HD) p.dk[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c] = a * scale;
@@ -1281,6 +1285,7 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_fast_kernel(const AttnTra
 #pragma unroll
       for (int c = 0; c < CG; ++c) acc[c] = 0.f;
       if (j < p.Lk) {
+#pragma unroll 8
         for (int i = 0; i < p.Lq; ++i) {
           float m = probs[(size_t)i * p.Lk + j];
           if (dm) m *= dm[(size_t)i * p.Lk + j] ? p.dropscale : 0.f;
@@ -1294,12 +1299,12 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_fast_kernel(const AttnTra
       }
     }
   };
-  colred(dOs, p.dv, p.ldv, 1.f, dmask);  // phase 1: dV = (P o D)^T dO
+  if (!(p.probe & 1)) colred(dOs, p.dv, p.ldv, 1.f, dmask);  // phase 1: dV = (P o D)^T dO
   __syncthreads();
   const float scale = rsqrtf((float)HD);
   constexpr int PH = 64 / HD;
   const int c = lane % HD, ph = lane / HD;
-  for (int i = wave; i < p.Lq; i += NW) {  // phase 2: dS (in place) and dQ, one wave per query row
+  for (int i = wave; i < p.Lq && !(p.probe & 2); i += NW) {  // phase 2: dS (in place) and dQ, one wave per query row
     const float* d_o = dOs + i * HD;
     float* prow = probs + (size_t)i * p.Lk;
     float dsum = 0.f;
@@ -1318,15 +1323,19 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_fast_kernel(const AttnTra
       Ds[wave * p.Lk + j] = ds;
     }
     float a = 0.f;
+#pragma unroll 8
     for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[j * (HD + 1) + c], a);
     if (PH == 2) a += __shfl_xor(a, 32, 64);
     if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
   }
   __syncthreads();
-  colred(Qs, p.dk, p.ldk, scale, nullptr);  // phase 3: dK = scale * dS^T Q
+  if (!(p.probe & 4)) colred(Qs, p.dk, p.ldk, scale, nullptr);  // phase 3: dK = scale * dS^T Q
 }
 
-hipError_t launch_attn_train_bwd(const AttnTrainP& p, hipStream_t s) {
+hipError_t launch_attn_train_bwd(const AttnTrainP& p_in, hipStream_t s) {
+  AttnTrainP p = p_in;
+  static const int probe = getenv("D2T_ATTN_BWD_PROBE") ? atoi(getenv("D2T_ATTN_BWD_PROBE")) : 0;  // timing probe: skip phases (bit mask)
+  p.probe = probe;
   const size_t lds = ((size_t)2 * p.Lk * (p.hd + 1) + 4 * (size_t)p.Lk) * 4;
   const size_t base_fast = ((size_t)2 * p.Lk * (p.hd + 1) + (size_t)2 * p.Lq * p.hd) * 4;
   const int nw = attn_waves(base_fast, p.Lk);
