@@ -145,10 +145,12 @@ struct AttnTrainBwdP {
   const float *sv_cprev, *sv_cafter, *sv_gates, *sv_alpha, *sv_hq;
   float* dmem;             // [B][T][D]  += context path (zero-initialised by the caller)
   float* dkp;              // [B][T][H]  += score path   (zero-initialised by the caller)
-  float *dgates, *dhq, *demb;   // [B][S][4H], [B][S][H], [B][S][E]
+  float *dgates, *dhq, *demb;   // [B][S][4H], [B][S][H], [B][S][E] (demb null: the caller forms it from dgates afterwards)
+  const float* dhl = nullptr;   // optional [B][S][H]: dlogits . generator.weight for every (row, step), formed beforehand
   float *dh0, *dc0;        // [B][H]
   float *dwloc, *dbloc, *dwscore, *dbscore;   // per-row partials [B][H][taps], [B][H], [B][H], [B]
   int B, S, V, H, E, coverage;
+  int probe = 0;           // timing probe (D2T_LSTM_BWD_PROBE): bit mask of phases to skip -- 1 B, 2 D, 4 E, 8 G, 16 H
 };
 hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p, hipStream_t s);
 // fold / unfold of loc_proj o loc_conv: gradients of the four location-layer tensors from the per-row partials

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
     {
       const int c = tid & 255, gq = tid >> 8;
       float a = 0.f;
+#pragma unroll 8
       for (int t = gq; t < Tk; t += 4) a = fmaf(alpha_s[t], keys[(size_t)t * p.D + c], a);
       gate_s[gq * H + c] = a;
     }
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
   constexpr int H = 256;
   __shared__ float dh_s[H], dc_s[H], dgate_s[4 * H], dctx_s[H], dhprev_s[H], hq_s[H], dhq_s[H];
   __shared__ float alpha_s[AD_MAXT], mem_s[AD_MAXT + 16], dal_s[AD_MAXT], de_s[AD_MAXT], dcov_s[AD_MAXT], dmem_s[AD_MAXT + 16];
-  __shared__ float part_s[16][H];
+  __shared__ __attribute__((aligned(16))) float part_s[16][H];
   __shared__ float dl_s[1024], red_s[32];
   __shared__ __attribute__((aligned(16))) float wloc_s[11 * H];  // [tap][n]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -387,7 +388,11 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
     if (tid < H) hq_s[tid] = p.sv_hq[bt * H + tid];
     __syncthreads();
     // B. dh += generator^T dlogits   (4 threads per hidden unit)
-    {
+    // (p.dhl: that product for every (row, step) from one GEMM before this kernel -- it does not depend on the recurrence,
+    // and inside the loop it cost half a megabyte of generator weights per row and step)
+    if (p.dhl) {
+      if (tid < H) dh_s[tid] += p.dhl[bt * H + tid];
+    } else if (!(p.probe & 1)) {
       const int n = tid >> 2, q = tid & 3;
       float a = 0.f;
       for (int v = q; v < p.V; v += 4) a = fmaf(dl_s[v], p.wg_t[(size_t)n * p.V + v], a);
@@ -411,23 +416,74 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
       dc_s[tid] = dc * fg;
     }
     __syncthreads();
-    // D. gradient of the LSTMCell input [ctx | emb] and of h_prev (coalesced over the raw weights' columns)
-    if (tid < 2 * H) {
-      float a = 0.f;
+    // D. gradient of the LSTMCell input and of h_prev: dgates (1 x 4H) times W_ih (4H x 2H: context | embedding columns)
+    // and W_hh (4H x H).  All 1024 threads take part: a thread owns four consecutive columns (16-byte loads) and one
+    // part of the 4H rows, the parts are added through LDS in a fixed order.  The embedding half is not part of the
+    // recurrence: when p.demb is null the caller computes it for all (row, step) with one GEMM on the saved dgates, and
+    // only the context half (1 MB of the 2 MB of W_ih) is streamed here.  The phase is bound by the CU's L2 ingest.
+    if (!(p.probe & 2)) {
+      if (p.demb) {
+        const int cg = tid & 127, rp = tid >> 7;  // 128 column groups x 8 row parts of 128 rows
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* w = p.wih_raw + (size_t)(rp * 128) * 2 * H + cg * 4;
 #pragma unroll 8
-      for (int r = 0; r < 4 * H; ++r) a = fmaf(dgate_s[r], p.wih_raw[(size_t)r * 2 * H + tid], a);
-      if (tid < H) dctx_s[tid] = a;
-      else p.demb[bt * p.E + (tid - H)] = a;
-    } else if (tid < 3 * H) {
-      const int k = tid - 2 * H;
-      float a = 0.f;
+        for (int r = 0; r < 128; ++r) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)r * 2 * H);
+          const float g = dgate_s[rp * 128 + r];
+          a.x = fmaf(g, w4.x, a.x); a.y = fmaf(g, w4.y, a.y); a.z = fmaf(g, w4.z, a.z); a.w = fmaf(g, w4.w, a.w);
+        }
+        *reinterpret_cast<float4*>(&part_s[0][0] + rp * 2 * H + cg * 4) = a;  // part_s as [8][2H]
+      } else {
+        const int cg = tid & 63, rp = tid >> 6;  // context columns only: 64 column groups x 16 row parts of 64 rows
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* w = p.wih_raw + (size_t)(rp * 64) * 2 * H + cg * 4;
 #pragma unroll 8
-      for (int r = 0; r < 4 * H; ++r) a = fmaf(dgate_s[r], p.whh_raw[(size_t)r * H + k], a);
-      dhprev_s[k] = a;
+        for (int r = 0; r < 64; ++r) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)r * 2 * H);
+          const float g = dgate_s[rp * 64 + r];
+          a.x = fmaf(g, w4.x, a.x); a.y = fmaf(g, w4.y, a.y); a.z = fmaf(g, w4.z, a.z); a.w = fmaf(g, w4.w, a.w);
+        }
+        *reinterpret_cast<float4*>(&part_s[rp][cg * 4]) = a;
+      }
+    }
+    __syncthreads();
+    if (p.demb) {
+      if (tid < 2 * H) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a += (&part_s[0][0])[q * 2 * H + tid];
+        if (tid < H) dctx_s[tid] = a;
+        else p.demb[bt * p.E + (tid - H)] = a;
+      }
+    } else if (tid < H) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a += part_s[q][tid];
+      dctx_s[tid] = a;
+    }
+    __syncthreads();
+    if (!(p.probe & 2)) {
+      const int cg = tid & 63, rp = tid >> 6;  // W_hh: 64 column groups x 16 row parts of 64 rows
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* w = p.whh_raw + (size_t)(rp * 64) * H + cg * 4;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)r * H);
+        const float g = dgate_s[rp * 64 + r];
+        a.x = fmaf(g, w4.x, a.x); a.y = fmaf(g, w4.y, a.y); a.z = fmaf(g, w4.z, a.z); a.w = fmaf(g, w4.w, a.w);
+      }
+      *reinterpret_cast<float4*>(&part_s[rp][cg * 4]) = a;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a += part_s[q][tid];
+      dhprev_s[tid] = a;
     }
     __syncthreads();
     // E. context backward: dalpha_j = dctx . key_j ; dkeys_j += alpha_j * dctx   (wave per key)
-    {
+    if (!(p.probe & 4)) {
       const float4 dc4 = *reinterpret_cast<const float4*>(dctx_s + n0);
       for (int j = wave; j < Tk; j += 16) {
         const float4 k4 = *reinterpret_cast<const float4*>(keys + (size_t)j * p.D + n0);
@@ -462,7 +518,7 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
     }
     __syncthreads();
     // G. score backward: u = key_proj_j + query + loc_j ; du = de_j * w * (1 - tanh(u)^2)   (wave per key)
-    {
+    if (!(p.probe & 8)) {
       const float4 hq4 = *reinterpret_cast<const float4*>(hq_s + n0);
       const float4 ws4 = *reinterpret_cast<const float4*>(p.wscore + n0);
       const float4 bl4 = *reinterpret_cast<const float4*>(p.bloc + n0);
@@ -520,7 +576,7 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
     if (tid < H) {
       float a = dhprev_s[tid];
 #pragma unroll 8
-      for (int n = 0; n < H; ++n) a = fmaf(dhq_s[n], p.wq_raw[(size_t)n * H + tid], a);
+      for (int n = 0; n < H && !(p.probe & 16); ++n) a = fmaf(dhq_s[n], p.wq_raw[(size_t)n * H + tid], a);
       dh_s[tid] = a;
     }
     for (int j = tid; j < Tk; j += 1024) {
@@ -569,7 +625,10 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
     p.dbscore[b] = tot;
   }
 }
-hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p, hipStream_t s) {
+hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p_in, hipStream_t s) {
+  AttnTrainBwdP p = p_in;
+  static const int probe = getenv("D2T_LSTM_BWD_PROBE") ? atoi(getenv("D2T_LSTM_BWD_PROBE")) : 0;
+  p.probe = probe;
   if (p.H != 256 || p.D != 256 || p.E != 256 || p.V > 1024 || p.T - p.key_off > AD_MAXT || p.T - p.key_off < 1 || p.taps > 11)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(attn_train_lstm_bwd_kernel, dim3(p.B), dim3(1024), 0, s, p);

@@ -895,10 +895,29 @@ struct Tr {  // builder / runner bound to one context and stream
     RC(alloc(&dbloc, (size_t)B * Hh));
     RC(alloc(&dwscore, (size_t)B * Hh));
     RC(alloc(&dbscore, (size_t)B + 16));
-    p.dmem = dmem; p.dkp = dkp; p.dgates = dgates; p.dhq = dhq; p.demb = demb; p.dh0 = dh0; p.dc0 = dc0;
+    p.dmem = dmem; p.dkp = dkp; p.dgates = dgates; p.dhq = dhq; p.dh0 = dh0; p.dc0 = dc0;
     p.dwloc = dwloc; p.dbloc = dbloc; p.dwscore = dwscore; p.dbscore = dbscore;
     p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage;
+    // The two products that do not take part in the recurrence leave the sequential kernel (each cost its weight matrix
+    // per row and step from L2): dlogits . generator.weight for all (row, step) as one GEMM before it ...
+    static const bool hoist = !(getenv("D2T_LSTM_BWD_HOIST") && atoi(getenv("D2T_LSTM_BWD_HOIST")) == 0);
+    if (hoist) {
+      const int Vp = (V + 31) / 32 * 32;
+      float *gpad, *wgp, *dhl;
+      RC(alloc(&gpad, (size_t)BS * Vp));
+      RC(alloc(&wgp, (size_t)Hh * Vp));
+      RC(alloc(&dhl, (size_t)BS * Hh));
+      TCHK(launch_pad_cols(dl, gpad, (size_t)BS, V, Vp, s));
+      TCHK(launch_pad_cols(c->attn.wg_t, wgp, (size_t)Hh, V, Vp, s));
+      RC(gemm_nt(gpad, wgp, nullptr, nullptr, dhl, BS, Hh, Vp, ACT_NONE));
+      p.dhl = dhl;
+      p.demb = nullptr;
+    } else {
+      p.demb = demb;
+    }
     TCHK(launch_attn_train_lstm_bwd(p, s));
+    // ... and the gradient of the embedded target, dgates . W_ih[:, H:], as one GEMM after it (not needed with one-hot targets)
+    if (hoist && !onehot) RC(gemm_nt(dgates, c->attn.wx_t + (size_t)Hh * 4 * Hh, nullptr, nullptr, demb, BS, Hh, 4 * Hh, ACT_NONE));
     // weight gradients = sums over (row, step) of outer products -> TN GEMMs on the saved factors
     float *gW, *gB, *gB2;
     RC(grad_buf(ac + "generator.weight", &gW));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel-trace stats of the training step on the GPU box: bash tools/profile_train.sh <tag> [batch [steps]]
+# Kernel-trace stats of the training step on the GPU box: bash tools/profile_train.sh <tag> [batch [steps [C2|S0]]]
 # -> gpurun_out/prof_<tag>/{trace/, kernel_stats_train.csv}
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -7,7 +7,7 @@ tag=$1; shift
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 $R/tools/train_bench.py ${1:-32} ${2:-3} > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 $R/tools/train_bench.py ${1:-32} ${2:-3} bf16x3 ${3:-C2} > $out/trace.log 2>&1
 tail -1 $out/trace.log
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
