@@ -561,6 +561,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   const size_t total = (size_t)taps * M * N;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float v = 0.f;
+#pragma unroll 8
     for (int z = 0; z < S; ++z) v += part[(size_t)z * total + i];
     const int n = (int)(i % N), m = (int)((i / N) % M), tap = (int)(i / ((size_t)M * N));
     const size_t o = layout == 1 ? ((size_t)m * N + n) * taps + tap : (size_t)m * N + n;
@@ -683,8 +684,10 @@ hipError_t launch_colreduce(const ColRedP& p, hipStream_t s) {
 __device__ __forceinline__ void chunk_sums(const float* __restrict__ part, int chunks, int C, int c, int lane8, double (*red)[8][32],
                                            double& a, double& b) {
   a = 0.0; b = 0.0;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 8
     for (int k = lane8; k < chunks; k += 8) { a += part[((size_t)k * 2) * C + c]; b += part[((size_t)k * 2 + 1) * C + c]; }
+  }
   red[0][lane8][threadIdx.x & 31] = a;
   red[1][lane8][threadIdx.x & 31] = b;
   __syncthreads();
