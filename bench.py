@@ -77,6 +77,20 @@ def pmc_traffic(precision):
 _PMC = {}
 
 
+def train_pmc_traffic(precision, gemm):
+    """HBM bytes per launch of the training step's dominant forward / data-gradient convolution from the latest committed PMC
+    pass of the training bench (profiles/rNN_pmc_train_dominant_<precision>.json, tools/profile_train_pmc.sh), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_train_dominant_{precision}.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        pm = json.load(f)
+    if list(pm.get("gemm_MNK", [])) != list(gemm):
+        return None, None
+    return pm.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def stem_hbm():
     """HBM traffic and rate of the HBM-bound front of the network (conv0_1 stem, conv0_2, first max-pool) from the latest
     committed PMC pass (profiles/rNN_pmc_stem.json: FETCH_SIZE x 2 + WRITE_SIZE per launch, tools/pmc_aggregate.py), or None."""
@@ -112,13 +126,14 @@ def cpu_baseline(cfg_name, H, W, max_len, sample_b, passes=3):
     img = synth.synth_images(sample_b, H, W, seed=1000)
     text = torch.full((sample_b, 1), R.GO, dtype=torch.long)
     out = []
+    answers = None
     for faithful in (True, False):
         log(f"cpu baseline ({'faithful' if faithful else 'cached'} mode): {sample_b} crops on {cores} threads, 1 + {passes} passes ...")
         times = []
         with torch.no_grad():
             for i in range(passes + 1):
                 t0 = time.perf_counter()
-                R.forward(cfg, sd, img, text, is_test=False, faithful=faithful)
+                answers = R.forward(cfg, sd, img, text, is_test=False, faithful=faithful)[:2]
                 if i:  # pass 0 warms the thread pool / allocator
                     times.append(time.perf_counter() - t0)
         dt = statistics.median(times)
@@ -129,16 +144,17 @@ def cpu_baseline(cfg_name, H, W, max_len, sample_b, passes=3):
             "sample": f"{sample_b} crops {H}x{W}, {max_len + 1} greedy steps, oracle/restatement.py {mode}; median of "
                       f"{passes} timed passes after 1 warm-up = {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in times)})",
         })
-    return out[0], out[1]
+    return out[0], out[1], answers  # answers: the oracle's (tokens, logits) for the sample crops (the bench line's parity check)
 
 
-def train_bench(args, rank, world, dev, dist):
+def train_bench(args, rank, world, dev, dist, emit=True):
     """BASELINE configs[3]: HybridViT + TFM-6 training step, CE loss on synthetic labels, per-GPU batch 32, data-parallel
-    with the gradient all-reduce of doc2tex_amd.dist.GradSync.  One step = forward + loss + backward + clip + AdamW."""
+    with the gradient all-reduce of doc2tex_amd.dist.GradSync.  One step = forward + loss + backward + clip + AdamW.
+    emit=False: return the line (rank 0) instead of printing it and leave the process group alone (secondary.train_c3)."""
     from doc2tex_amd.dist import GradSync
     name = "C3"
     H, W = synth.crop_shape(name)
-    B = args.batch or synth.batch_size(name)
+    B = (args.batch if emit else 0) or synth.batch_size(name)
     cfg = synth.make_config(name, device=str(dev))
     L = cfg["Prediction"]["params"]["max_seq_len"]
     model = Model(cfg)
@@ -199,14 +215,16 @@ def train_bench(args, rank, world, dev, dist):
             peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
             ach = flop / (dom_ms * 1e-3) / 1e12
             total_ms = sum(sum(v) for v in by_shape.values())
+            traffic, traffic_src = train_pmc_traffic(args.precision, dom)
             roofline = {"bound": "mfma", "kernel": "forward / data-gradient convolution GEMM (split-bf16, LDS-DMA kernels on split-record copies of the inputs)" if bf
                         else "forward / data-gradient convolution GEMM (fp32 MFMA)",
-                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                        "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                         "gemm_MNK": list(dom), "avg_launch_ms": round(dom_ms, 4), "launches_timed": len(by_shape[dom]),
                         "gemm_ms_per_step": round(total_ms / args.steps, 2),
                         "note": "GEMM launches timed with HIP events (weight-gradient kernels, BatchNorm / attention / element-wise "
                                 "kernels, CE, clip and AdamW make up the rest of the step)"}
-        print(json.dumps({
+        line = {
             "metric": "formulas/s (training step, 128x512 crops, CE loss)", "value": round(B * world * args.steps / elapsed, 2),
             "unit": "formulas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -216,84 +234,24 @@ def train_bench(args, rank, world, dev, dist):
                        "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world} (per-rank batches, gradient all-reduce-mean in 64 MB buckets over RCCL)"},
             "roofline": roofline, "criterion": "fused CE (d2t_ce_forward / d2t_ce_backward)",
-            "loss": round(float(loss), 4)}), flush=True)
-    if dist:
+            "loss": round(float(loss), 4)}
+        if not emit:
+            del model, opt
+            torch.cuda.empty_cache()
+            return line
+        print(json.dumps(line), flush=True)
+    if dist and emit:
         dist.destroy_process_group()
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
-    ap.add_argument("--reserve", type=int, default=0,
-                    help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
-    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch"],
-                    help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
-    ap.add_argument("--reserve-cus", type=int, default=0,
-                    help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
-    ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
-                    help="pipelined mode: decode loops in flight side by side")
-    ap.add_argument("--group", type=int, default=0,
-                    help="pipelined mode: decode the rows of this many consecutive batches in one step loop "
-                         "(default: 6 for C2 -- the loop's duration hardly depends on the row count and it runs in the "
-                         "gaps the convolutions leave, so larger groups mean fewer loops beside the encoders; 4 for C1)")
-    ap.add_argument("--end-bias", type=float, default=0.0,
-                    help="secondary run (SURVEY 8d): raise the [s] logit bias of the synthetic weights by this much so that "
-                         "rows terminate, and decode with is_test=True (the reference's early exit: a batch stops at the "
-                         "first step at which every row has ended); synchronous, not pipelined")
-    ap.add_argument("--train", action="store_true",
-                    help="secondary mode (BASELINE configs[3]): time the training step of config C3 -- forward under "
-                         "module.train(), CE, backward in the HIP engine, bucketed RCCL gradient all-reduce when more than "
-                         "one rank runs, clip, AdamW -- and print its own JSON line instead of the headline metric")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="finish each batch's decode before the next batch's encoder starts")
-    ap.add_argument("--cpu-sample", type=int, default=8,
-                    help="crops in the CPU-baseline sample (1 warm-up + 3 timed passes in each of the two oracle modes: ~30 s)")
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary measurements (transfer-inclusive rate, exact-fp32 mode)")
-    args = ap.parse_args()
-
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # `python bench.py --gpus N` without a launcher: start one fresh rank process per GPU ourselves (before anything here
-        # has touched the GPU -- never re-exec a process that initialised HIP) and exit with the worst of their codes.
-        # Rank 0 prints the JSON line to the stdout the children inherit.
-        import socket
-        import subprocess
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        procs = []
-        for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        codes = [q.wait() for q in procs]
-        sys.exit(max(abs(c) for c in codes))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        args.gpus = world
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    if args.train:
-        return train_bench(args, rank, world, dev, dist)
-    name = args.config
-    if args.group <= 0:
-        args.group = 4 if name == "C1" else 6
+def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps=None, warmup=None):
+    """Greedy serving of one BASELINE config (C2 = the headline, C1): returns (line, out) on rank 0 -- the contract fields
+    with `roofline` (and, with secondary_runs, `secondary.incl_transfers` / `secondary.fp32`) and the (tokens, logits) of
+    the first timed measurement's last step -- and (None, None) on the other ranks."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    group = args.group if args.group > 0 else (4 if name == "C1" else 6)
     H, W = synth.crop_shape(name)
     B = args.batch or synth.batch_size(name)
     cfg = synth.make_config(name, device=str(dev))
@@ -306,7 +264,7 @@ def main():
     early = args.end_bias != 0.0
     model.pipelined = not args.no_pipeline and not early
     model.decode_chains = args.chains
-    model.decode_group = args.group
+    model.decode_group = group
     model.reserved_blocks = args.reserve  # decode of batch i overlaps the encoder of batch i+1
     model.reserved_cus = args.reserve_cus
     if args.conv_kernel:
@@ -320,12 +278,15 @@ def main():
         with torch.no_grad():
             return model(img if x is None else x, text, is_train=False, is_test=early)
 
+    primed = []  # the decode graphs depend on the decode buffers only (not on the arithmetic mode or the input tensor)
+
     def prime():
         """Capture every decode launch configuration the timed region can need before anything is timed: a group that
         synchronize() finds incomplete is decoded at its own row count, on either decode chain (largest group first: the
         engine's buffers only grow, so the addresses the smaller graphs capture stay valid)."""
-        if model.pipelined:
-            for n in range(max(1, args.group), 0, -1):
+        if model.pipelined and not primed:
+            primed.append(True)
+            for n in range(max(1, group), 0, -1):
                 for _ in range(2 * max(1, args.chains)):
                     for _ in range(n):
                         step()
@@ -447,21 +408,22 @@ def main():
                                         "max_ms": round(max(l[2] for l in loops), 2)}
         return roofline
 
-    elapsed, recs, out = timed(args.steps, args.warmup)
+    elapsed, recs, out = timed(steps, warmup)
+    first_out = (out[0], out[1])
     if rank == 0:
-        log(f"timed {args.steps} steps in {elapsed:.3f} s")
+        log(f"{name}: timed {steps} steps in {elapsed:.3f} s")
     # secondary measurements of the SAME workload (rank-symmetric, so that the collectives inside timed() match up):
     #   incl. transfers -- H2D of every batch and D2H of its token ids inside the timed region (SURVEY 8d's metric definition)
     #   fp32            -- the exact-fp32 arithmetic mode (--precision fp32), fewer steps
     secondary = {}
-    if not early and not args.no_secondary:
-        e2, _, _ = timed(args.steps, 2, with_transfers=True)
+    if not early and secondary_runs:
+        e2, _, _ = timed(steps, 2, with_transfers=True)
         secondary["incl_transfers"] = {
-            "value": round(world * B * args.steps / e2, 2), "unit": "formulas/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
+            "value": round(world * B * steps / e2, 2), "unit": "formulas/s", "ms_per_step": round(e2 / steps * 1e3, 3),
             "what": f"as `value`, plus per step the H2D copy of the batch ({host_img.numel() * 4 / 1e6:.1f} MB from pinned host "
                     "memory, on a copy stream) and, before the region ends, the D2H copy of every batch's token ids"}
         if args.precision == "bf16x3":
-            k3 = max(4, args.steps // 3)
+            k3 = max(4, steps // 4)
             model.conv_precision = "fp32"
             e3, r3, _ = timed(k3, 2)
             model.conv_precision = args.precision
@@ -476,9 +438,9 @@ def main():
     if rank == 0:
         T = model.engine().encoder_shape(H, W)[0]
         bf = args.precision == "bf16x3"
-        roofline = roofline_of(recs, args.precision, args.steps)
-        formulas = world * B * args.steps
-        ms_step = elapsed / args.steps * 1e3
+        roofline = roofline_of(recs, args.precision, steps)
+        formulas = world * B * steps
+        ms_step = elapsed / steps * 1e3
         enc_flops = {"C2": 205.28e9, "C1": 50.79e9}.get(name, 0.0)
         algo = enc_flops + decoder_flops(L + 1, T, d=cfg["Prediction"]["params"]["d_model"],
                                          ff=cfg["Prediction"]["params"]["dim_feedforward"],
@@ -486,8 +448,8 @@ def main():
         result = {
             "metric": ("formulas/s (greedy decode, 128x512 crops)" if name == "C2" else f"formulas/s ({name})") +
                       (" -- early exit (is_test), synchronous" if early else ""),
-            "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16x3" if bf else "f32", "data": "synthetic",
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
@@ -505,16 +467,196 @@ def main():
         }
         if secondary:
             result["secondary"] = secondary
+        result["_shape"] = (H, W, L, B)
+        model.synchronize()
+        return result, first_out
+    model.synchronize()
+    return None, None
+
+
+def other_configs(args, dev):
+    """The other BASELINE configs on one GPU, measured after the headline and outside its timed region (world == 1):
+    C1 (configs[1]) greedy serving, C3's per-GPU training step (configs[3]) and C4's beam-5 decode (configs[4])."""
+    import copy
+    out = {}
+    a = copy.copy(args)
+    a.batch, a.group = 0, 0
+    line, _ = serving_bench(a, "C1", 0, 1, dev, None, secondary_runs=False, steps=max(20, args.steps), warmup=4)
+    out["c1"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
+    torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.steps, a.warmup = max(4, args.steps // 4), 2
+    line = train_bench(a, 0, 1, dev, None, emit=False)
+    out["train_c3"] = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "loss")}
+    torch.cuda.empty_cache()
+    out["c4_beam5"] = beam_bench(dev)
+    torch.cuda.empty_cache()
+    return out
+
+
+def beam_bench(dev, n=128, beam=5, per_sample=8):
+    """BASELINE configs[4] per-GPU work: the C2 model under max_dimension [160, 640], beam width 5, one bucket (160x640) of
+    n crops: the batched API (Model.beam_search_batch: encoder on the whole batch, all hypotheses in one step loop) and the
+    reference-shaped call (one sample per forward, tfm.py:146-148) on the first `per_sample` crops."""
+    cfg = synth.make_config("C4", device=str(dev), beam_size=beam)
+    H, W = synth.crop_shape("C4")
+    m = Model(cfg)
+    m.load_state_dict(synth.synth_state_dict({k: v for k, v in m.state_dict().items()}), strict=False)
+    m = m.to(dev).eval()
+    img = synth.synth_images(n, H, W, seed=11).to(dev)
+    go = torch.ones(1, 1, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        m.beam_search_batch(img, beam)  # warm-up (buffers, graphs)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        seqs = m.beam_search_batch(img, beam)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        m(img[:1], go, is_train=False, is_test=True)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(per_sample):
+            m(img[i:i + 1], go, is_train=False, is_test=True)
+        torch.cuda.synchronize(dev)
+        ds = time.perf_counter() - t1
+    return {"value": round(n / dt, 2), "unit": "formulas/s", "ms_per_batch": round(dt * 1e3, 2), "dtype": "bf16x3",
+            "config": {"workload": f"C4: HybridViT + TFM-6, beam width {beam}, {H}x{W} crops (max_dimension [160, 640]), one bucket "
+                                   f"per batch, up to {cfg['Prediction']['params']['max_seq_len'] + 1} steps, batched API",
+                       "per_gpu_batch": n},
+            "sequence_lengths": sorted(set(int(q.shape[1]) for q, _ in seqs)),
+            "per_sample_api": {"value": round(per_sample / ds, 2), "unit": "formulas/s", "samples": per_sample,
+                               "what": "Model.forward on one crop at a time (encoder + beam search per call), as the reference's "
+                                       "forward_beam requires"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
+                    help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
+    ap.add_argument("--reserve", type=int, default=0,
+                    help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
+    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch"],
+                    help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
+    ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
+                    help="pipelined mode: decode loops in flight side by side")
+    ap.add_argument("--group", type=int, default=0,
+                    help="pipelined mode: decode the rows of this many consecutive batches in one step loop "
+                         "(default: 6 for C2 -- the loop's duration hardly depends on the row count and it runs in the "
+                         "gaps the convolutions leave, so larger groups mean fewer loops beside the encoders; 4 for C1)")
+    ap.add_argument("--end-bias", type=float, default=0.0,
+                    help="secondary run (SURVEY 8d): raise the [s] logit bias of the synthetic weights by this much so that "
+                         "rows terminate, and decode with is_test=True (the reference's early exit: a batch stops at the "
+                         "first step at which every row has ended); synchronous, not pipelined")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary mode (BASELINE configs[3]): time the training step of config C3 -- forward under "
+                         "module.train(), CE, backward in the HIP engine, bucketed RCCL gradient all-reduce when more than "
+                         "one rank runs, clip, AdamW -- and print its own JSON line instead of the headline metric")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish each batch's decode before the next batch's encoder starts")
+    ap.add_argument("--cpu-sample", type=int, default=8,
+                    help="crops in the CPU-baseline sample (1 warm-up + 3 timed passes in each of the two oracle modes: ~30 s)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (transfer-inclusive rate, exact-fp32 mode)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start one fresh rank process per GPU ourselves (before anything here
+        # has touched the GPU -- never re-exec a process that initialised HIP) and exit with the worst of their codes.
+        # Rank 0 prints the JSON line to the stdout the children inherit.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # poll: the first rank that exits non-zero takes its siblings with it (they would otherwise sit in a barrier or a
+        # collective until the caller's limit), and the launcher exits non-zero
+        codes = [None] * len(procs)
+        bad = None
+        while any(c is None for c in codes) and bad is None:
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = q.poll()
+                    if codes[i] not in (None, 0):
+                        bad = i
+            if bad is None:
+                time.sleep(0.2)
+        if bad is not None:
+            log(f"rank {bad} exited with code {codes[bad]}: terminating the other ranks")
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    q.terminate()
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = q.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        codes[i] = q.wait()
+            sys.exit(abs(codes[bad]) or 1)
+        sys.exit(0)
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.train:
+        train_bench(args, rank, world, dev, dist)
+        return
+    name = args.config
+    early = args.end_bias != 0.0
+    result, out = serving_bench(args, name, rank, world, dev, dist, secondary_runs=not args.no_secondary)
+    if rank == 0:
+        H, W, L, B = result.pop("_shape")
         stem = stem_hbm()
         if stem:
             result["stem_hbm"] = stem
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"], result["cpu_baseline_cached"] = cpu_baseline(name, H, W, L, args.cpu_sample)
+            result["cpu_baseline"], result["cpu_baseline_cached"], answers = cpu_baseline(name, H, W, L, args.cpu_sample)
             f, c_ = result["cpu_baseline"]["value"], result["cpu_baseline_cached"]["value"]
             result["speedup_vs_cpu"] = round(result["value"] / f, 1)
             # the ratio splits into what the algorithm buys on the same CPU (KV cache, folded BN) and what the GPU buys
             result["speedup_split"] = {"algorithm_on_cpu": round(c_ / f, 2), "hardware_vs_cached_cpu": round(result["value"] / c_, 1)}
+            if not early and args.batch in (0, B) and args.cpu_sample <= B:
+                # the bench line proves its own answers: the CPU sample IS the first rows of the timed batch (same seed), so
+                # the tokens / logits the TIMED configuration produced for them are checked against the oracle's
+                n = args.cpu_sample
+                tok, lg = out[0][:n].cpu(), out[1][:n].cpu()
+                exact = bool(torch.equal(tok, answers[0]))
+                dl = float((lg - answers[1]).abs().max())
+                parity_ok = exact and dl <= 1e-3
+                result["parity"] = {"rows": n, "tokens_exact": exact, "max_abs_dlogit": float(f"{dl:.3e}"), "tolerance": 1e-3,
+                                    "what": f"rows 0..{n - 1} of the last batch of the timed region (pipelined, decode groups of "
+                                            f"{result['config']['decode_group']}) against oracle/restatement.py (KV-cached mode) on the "
+                                            "same crops and weights"}
+        if world == 1 and name == "C2" and not early and not args.no_secondary:
+            result.setdefault("secondary", {}).update(other_configs(args, dev))
         print(json.dumps(result), flush=True)
+        if not parity_ok:
+            log("PARITY FAILURE: the timed configuration's answers differ from the oracle's")
+            sys.exit(3)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

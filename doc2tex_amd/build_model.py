@@ -102,10 +102,17 @@ class DecodeHandle:
     def __init__(self, model, eng, ticket=None, index=0, tensors=None):
         self._model, self._eng, self.ticket = model, eng, ticket
         self._index, self._tensors = index, tensors  # position of this batch inside its decode group; full-size views
+        self._steps = None
 
     def steps(self):
-        self._launch()
-        return self._eng.decode_steps(self.ticket)[self._index]
+        """Valid length of this batch's tokens / logits (blocks the host until its decode is complete).  Cached: the
+        C side keeps the step counts of the last 64 decodes only."""
+        if self._steps is None:
+            self._launch()
+            per_batch = self._eng.decode_steps(self.ticket)
+            # a decode without early exit reports ONE entry (all max_seq_len + 1 steps) whatever the group size
+            self._steps = per_batch[self._index] if len(per_batch) > 1 else per_batch[0]
+        return self._steps
 
     def result(self):
         n = self.steps()  # blocks the host until the decode is complete

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(768, 3) void conv_bf16x3p_probe_dma_only(const Conv
 }
 
 static int abl_probe() {
-  static const int abl = getenv("D2T_CONV_ABL") ? atoi(getenv("D2T_CONV_ABL")) : 0;
+  static const int abl = D2T_PROBE_ENV("D2T_CONV_ABL");
   return abl;
 }
 

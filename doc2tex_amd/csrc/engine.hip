@@ -1070,6 +1070,12 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
     }
   }
   int steps = S;
+  // device-side early exit: the loop stops writing at the group's stop step, so define everything past it (PAD ids, zero
+  // logits) instead of handing the caller whatever an earlier decode left in the staging buffer
+  if (dev_exit) {
+    HIPCHK(c, hipMemsetAsync(logits, 0, log_bytes, s));
+    HIPCHK(c, hipMemsetAsync(tokens, 0, tok_bytes, s));
+  }
   d2t_ctx::ProfRec drec{-1, B, S, nullptr, nullptr};  // profiling: the decode loop as ONE record (M = -1, N = rows, K = steps)
   if (c->profiling && hipEventCreate(&drec.a) == hipSuccess && hipEventCreate(&drec.b) == hipSuccess) HIPCHK(c, hipEventRecord(drec.a, s));
   for (int t = 0; t < S; t += (use_graph ? steps_per_graph : 1)) {

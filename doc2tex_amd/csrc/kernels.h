@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-probe / ablation switches (D2T_CONV_ABL, D2T_WGRAD_ABL, D2T_LSTM_BWD_PROBE, D2T_ATTN_BWD_PROBE) skip kernel phases
+// or launch kernels whose results are garbage by construction.  They exist only in a probe build (build.sh with
+// D2T_PROBES=1 -> -DD2T_PROBES); the shipped library never reads them, so a stray variable in a serving or training
+// environment cannot change any result.
+#include <cstdlib>
+#ifdef D2T_PROBES
+#define D2T_PROBE_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define D2T_PROBE_ENV(name) 0
+#endif
+
 namespace d2t {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };

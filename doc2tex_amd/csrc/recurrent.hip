@@ -627,7 +627,7 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
 }
 hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p_in, hipStream_t s) {
   AttnTrainBwdP p = p_in;
-  static const int probe = getenv("D2T_LSTM_BWD_PROBE") ? atoi(getenv("D2T_LSTM_BWD_PROBE")) : 0;
+  static const int probe = D2T_PROBE_ENV("D2T_LSTM_BWD_PROBE");
   p.probe = probe;
   if (p.H != 256 || p.D != 256 || p.E != 256 || p.V > 1024 || p.T - p.key_off > AD_MAXT || p.T - p.key_off < 1 || p.taps > 11)
     return hipErrorInvalidValue;

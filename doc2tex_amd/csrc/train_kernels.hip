@@ -519,7 +519,7 @@ hipError_t launch_wgrad(const WgradP& p, hipStream_t s) {
   if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4 || p.S < 1 || p.chunk < 1 || p.taps < 1) return hipErrorInvalidValue;
   if (p.a_rec) {  // record operands: see wgrad_rec_ok
     if (!p.b_rec || !p.zero || !p.geom || !p.bf16x3 || wgrad_rec_shape(p.M, p.N) < 0 || p.chunk % 16) return hipErrorInvalidValue;
-    static const int abl = getenv("D2T_WGRAD_ABL") ? atoi(getenv("D2T_WGRAD_ABL")) : 0;
+    static const int abl = D2T_PROBE_ENV("D2T_WGRAD_ABL");
     const int shape = wgrad_rec_shape(p.M, p.N);
     if (shape == 2) {
       dim3 grid((p.M / 256) * (p.N / 256), p.taps, p.S);
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_fast_kernel(const AttnTra
 
 hipError_t launch_attn_train_bwd(const AttnTrainP& p_in, hipStream_t s) {
   AttnTrainP p = p_in;
-  static const int probe = getenv("D2T_ATTN_BWD_PROBE") ? atoi(getenv("D2T_ATTN_BWD_PROBE")) : 0;  // timing probe: skip phases (bit mask)
+  static const int probe = D2T_PROBE_ENV("D2T_ATTN_BWD_PROBE");  // timing probe: skip phases (bit mask)
   p.probe = probe;
   const size_t lds = ((size_t)2 * p.Lk * (p.hd + 1) + 4 * (size_t)p.Lk) * 4;
   const size_t base_fast = ((size_t)2 * p.Lk * (p.hd + 1) + (size_t)2 * p.Lq * p.hd) * 4;

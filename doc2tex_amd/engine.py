@@ -366,17 +366,25 @@ class Engine:
             held = self._held = []
         held.append((ticket, (memory, start, tokens, logits)))
         while held and self.ticket_done(held[0][0]):  # tickets complete in order per chain; at most a few stay pending
-            held.pop(0)
+            self.decode_steps(held.pop(0)[0])  # keep its step counts past the C side's 64-entry ring
         if len(held) > 48:  # the C side keeps 64 ticket events: never let a live ticket fall out of its ring
             self.wait_ticket(held[0][0], host_sync=True)
         return ticket
 
     def decode_steps(self, ticket):
-        """Per-batch step counts of an asynchronous decode (waits for it): [steps of batch 0, batch 1, ...]."""
-        out = (C.c_int32 * 64)()
-        n = C.c_int32(0)
-        self._check(self.lib.d2t_decode_steps(self.ctx, int(ticket), out, 64, C.byref(n)), "decode_steps")
-        return [int(out[i]) for i in range(n.value)]
+        """Per-batch step counts of an asynchronous decode (waits for it): [steps of batch 0, batch 1, ...]; ONE entry
+        (max_seq_len + 1) for a decode without early exit.  Remembered on this side, so a handle consumed more than 64
+        decodes later still learns its length."""
+        cache = self.__dict__.setdefault("_steps_cache", {})
+        ticket = int(ticket)
+        if ticket not in cache:
+            out = (C.c_int32 * 64)()
+            n = C.c_int32(0)
+            self._check(self.lib.d2t_decode_steps(self.ctx, ticket, out, 64, C.byref(n)), "decode_steps")
+            cache[ticket] = [int(out[i]) for i in range(n.value)]
+            for old in [t for t in cache if t <= ticket - 4096]:
+                del cache[old]
+        return cache[ticket]
 
     def ticket_done(self, ticket):
         r = int(self.lib.d2t_decode_query(self.ctx, int(ticket)))
@@ -396,6 +404,8 @@ class Engine:
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self._check(self.lib.d2t_decode_wait(self.ctx, stream, int(bool(host_sync))), "decode_wait")
         if host_sync:
+            for t, _ in getattr(self, "_held", None) or []:
+                self.decode_steps(t)
             self._held = []
 
     def decode_attn_beam(self, memory, beam_size):

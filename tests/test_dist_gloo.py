@@ -24,11 +24,10 @@ def test_shard_bounds_cover_batch():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import restatement as R
-    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with open(os.path.join(GOLD, "manifests.json")) as f:
         man = json.load(f)
@@ -47,13 +46,38 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+RENDEZVOUS_FAILED = 75  # exit code of a rank that could not join the process group (the only failure that is retried)
+
+
+def _rank_main(worker, rank, world, store, q, logdir):
+    """Entry point of a spawned rank: its stderr (with faulthandler's tracebacks on a fatal signal) goes to a per-rank
+    file that the parent attaches to the assertion message; failing to JOIN the group exits with RENDEZVOUS_FAILED."""
+    import faulthandler
+    import traceback
+    err = open(os.path.join(logdir, f"rank{rank}.stderr"), "w", buffering=1)
+    os.dup2(err.fileno(), 2)
+    sys.stderr = err
+    faulthandler.enable(file=err, all_threads=True)
+    try:
+        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world,
+                                timeout=__import__("datetime").timedelta(seconds=120))
+    except Exception:  # noqa: BLE001
+        traceback.print_exc(file=err)
+        os._exit(RENDEZVOUS_FAILED)
+    try:
+        worker(rank, world, q)
+    except BaseException:  # noqa: BLE001 - reported through the file and the exit code
+        traceback.print_exc(file=err)
+        os._exit(1)
+
+
 def _run_world_once(worker, world):
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         store = os.path.join(tmp, "rendezvous")
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, world, store, q)) for r in range(world)]
+        procs = [ctx.Process(target=_rank_main, args=(worker, r, world, store, q, tmp)) for r in range(world)]
         for p in procs:
             p.start()
         err = None
@@ -65,19 +89,34 @@ def _run_world_once(worker, world):
             p.join(timeout=60)
             if p.is_alive():
                 p.kill()
-        return out, [p.exitcode for p in procs], err
+                p.join()
+        logs = []
+        for r in range(world):
+            try:
+                with open(os.path.join(tmp, f"rank{r}.stderr")) as f:
+                    logs.append(f.read()[-4000:])
+            except OSError:
+                logs.append("<no stderr file>")
+        return out, [p.exitcode for p in procs], err, logs
 
 
 def _run_world(worker, world=2):
-    """Spawn `world` ranks of `worker(rank, world, rendezvous, queue)`; returns what rank 0 put on the queue.  The
-    ranks meet through a file store in a fresh temporary directory (no TCP port to collide on).  A world in which a rank
-    died (seen once in some hundred runs on a loaded host, never reproduced) is started ONE more time, with the first
-    attempt's exit codes printed; what the ranks compute is asserted by the callers either way."""
-    out, codes, err = _run_world_once(worker, world)
-    if out is None or any(c != 0 for c in codes):
-        print(f"[test_dist_gloo] first attempt: rank exit codes {codes}: {err!r}; starting the world once more")
-        out, codes, err = _run_world_once(worker, world)
-    assert out is not None and all(c == 0 for c in codes), f"rank exit codes {codes}: {err!r}"
+    """Spawn `world` ranks of `worker(rank, world, queue)` (already joined to a gloo group through a file store in a fresh
+    temporary directory: no TCP port to collide on); returns what rank 0 put on the queue.  A rank that dies -- by a
+    signal or by an exception -- fails the test on the spot with every rank's exit code and captured stderr.  Only a
+    failed rendezvous (exit code RENDEZVOUS_FAILED, nothing of the code under test has run yet) is started once more."""
+    out, codes, err, logs = _run_world_once(worker, world)
+
+    def report():
+        return (f"rank exit codes {codes}: {err!r}\n" +
+                "\n".join(f"--- rank {r} stderr ---\n{t}" for r, t in enumerate(logs)))
+
+    if any(c is not None and c < 0 for c in codes):
+        pytest.fail("a rank was killed by a signal: " + report())
+    if any(c == RENDEZVOUS_FAILED for c in codes) and not any(c not in (0, RENDEZVOUS_FAILED) for c in codes):
+        print("[test_dist_gloo] rendezvous failed, starting the world once more: " + report())
+        out, codes, err, logs = _run_world_once(worker, world)
+    assert out is not None and all(c == 0 for c in codes), report()
     return out
 
 
@@ -94,11 +133,10 @@ def test_sharded_decode_matches_single_process():
         assert _until_end(a) == _until_end(b)
 
 
-def _grad_worker(rank, world, port, q):
+def _grad_worker(rank, world, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import restatement as R
-    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with open(os.path.join(GOLD, "manifests.json")) as f:
         man = json.load(f)

@@ -117,31 +117,62 @@ def test_headline_shape_properties(cases):
 
 
 def test_headline_shape_in_the_benchmarked_serving_mode(cases):
-    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of three batches, no reserved
-    block slots (and the earlier serving configurations: groups of two; ungrouped with 64 reserved slots): four batches in
-    flight give exactly the synchronous results, and the fixture rows stay exact."""
+    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of SIX batches (384 rows per step
+    loop), no reserved block slots -- and the earlier serving configurations (groups of three / two; ungrouped with 64
+    reserved slots).  Seven batches: with groups of six one full 384-row group and an incomplete one (64 rows, launched by
+    synchronize()) both run.  Every batch comes back exactly as the synchronous path returns it, and the fixture rows
+    (computed by the reference) stay exact."""
     c = _case(cases, "greedy", "c2_greedy")
     z = np.load(os.path.join(GOLD, "c2_greedy.npz"))
     cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
     base = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
     imgs = []
-    for i in range(4):
+    for i in range(7):
         x = synth.synth_images(64, c["H"], c["W"], seed=300 + i)
         x[: c["B"]] = base  # the fixture rows ride in every batch
         imgs.append(x.cuda())
     text = torch.full((64, 1), R.GO, dtype=torch.long, device="cuda")
+    steps = z["logit_steps"].tolist()
     with torch.no_grad():
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
-        for group, reserve in ((3, 0), (2, 0), (1, 64)):
+        for group, reserve in ((6, 0), (3, 0), (2, 0), (1, 64)):
             m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, group, reserve
-            got = [m(x, text, is_train=False)[:2] for x in imgs]
+            got = [m(x, text, is_train=False) for x in imgs]
             m.synchronize()
             torch.cuda.synchronize()
-            for (p, l), (rp, rl) in zip(got, ref):
-                assert torch.equal(p, rp) and torch.equal(l, rl)
+            for (p, l, extra), (rp, rl) in zip(got, ref):
+                assert torch.equal(p, rp) and torch.equal(l, rl), (group, reserve)
                 assert np.array_equal(p[: c["B"]].cpu().numpy(), z["tokens"])
+                assert float(np.abs(l[: c["B"], steps].cpu().numpy() - z["logits_sample"]).max()) <= LOGIT_TOL
+                hp, hl = extra["decode"].result()  # the documented way to consume a pipelined forward, at every group index
+                assert hp.shape == rp.shape and torch.equal(hp, rp) and torch.equal(hl, rl)
     m.pipelined, m.decode_group = False, 1
+
+
+def test_all_64_rows_of_a_headline_batch_vs_the_oracle(cases, manifests):
+    """BASELINE configs[2], one whole batch (B=64, 128x512, 151 steps) in the benchmarked serving mode: EVERY row's token
+    ids equal the KV-cached CPU oracle's and every logit is within 1e-3 (the oracle is pinned on the reference by
+    tests/test_oracle_golden.py; its first rows are the reference's own fixture).  ~20 s of host time."""
+    c = _case(cases, "greedy", "c2_greedy")
+    z = np.load(os.path.join(GOLD, "c2_greedy.npz"))
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    ocfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    img = synth.synth_images(64, c["H"], c["W"], seed=4100)
+    img[: c["B"]] = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = torch.full((64, 1), R.GO, dtype=torch.long)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        op, ol, _ = R.forward(ocfg, sd, img, text, is_test=False, faithful=False)
+        m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, 6, 0
+        p, l, extra = m(img.cuda(), text.cuda(), is_train=False)
+        p, l = extra["decode"].result()
+        torch.cuda.synchronize()
+    m.pipelined, m.decode_group = False, 1
+    assert np.array_equal(op[: c["B"]].numpy(), z["tokens"])  # the oracle's rows 0.. are the reference's
+    assert p.shape == (64, 151) and torch.equal(p.cpu(), op), "greedy token ids differ from the oracle on some of the 64 rows"
+    dl = float((l.cpu() - ol).abs().max())
+    assert dl <= LOGIT_TOL, f"logits differ by {dl}"
 
 
 def test_config_c1_at_its_own_batch_and_length(cases):
@@ -345,7 +376,13 @@ def test_grouped_pipelined_decode_equals_synchronous(cases, group):
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
         m.pipelined, m.decode_chains, m.decode_group = True, 2, group
-        got = [m(x, text, is_train=False)[:2] for x in imgs]
+        outs = [m(x, text, is_train=False) for x in imgs]
+        got = [o[:2] for o in outs]
+        # result() -- the documented way to consume a pipelined forward -- at EVERY position of a group, without early exit
+        for o, (rp, rl) in zip(outs, ref):
+            hp, hl = o[2]["decode"].result()
+            assert o[2]["decode"].steps() == rp.shape[1]
+            assert hp.shape == rp.shape and torch.equal(hp, rp) and torch.equal(hl, rl)
         m.synchronize()
         torch.cuda.synchronize()
     for (p, l), (rp, rl) in zip(got, ref):  # all seven, however many groups ago they were decoded
@@ -414,6 +451,14 @@ def test_pipelined_early_exit_decided_on_the_device(cases, group):
             cp, cl = extra["decode"].result()
             assert cp.shape == rp.shape, (cp.shape, rp.shape)
             assert torch.equal(cp, rp) and torch.equal(cl, rl)
+            # past the group's stop step the full-size tensors are defined (PAD ids, zero logits), never stale memory;
+            # between this batch's own cut and the group's stop they hold real decode steps
+            n = cp.shape[1]
+            tail_p, tail_l = p[:, n:], l[:, n:]
+            if tail_p.numel():
+                assert torch.isfinite(tail_l).all() and int(tail_p.min()) >= 0 and int(tail_p.max()) < synth.VOCAB
+                if group == 1:  # the batch is its own group: nothing ran past its cut
+                    assert int(tail_p.abs().max()) == 0 and float(tail_l.abs().max()) == 0.0
         m.synchronize()
         # a mixed stream: is_test and plain forwards interleaved keep their own groups
         a = m(imgs[0], text, is_train=False, is_test=True)
