@@ -26,6 +26,7 @@
 //        step t-1 before it arrives there (they feed MFMAs that precede the barrier in program order, and the compiler's
 //        lgkmcnt waits sit in front of those MFMAs).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -38,6 +39,10 @@ namespace {
 constexpr int PBK = 32;   // K-step
 constexpr int PROW = 64;  // bytes per LDS row of one plane (32 bf16)
 __device__ __forceinline__ int pswz(int row, int c) { return c ^ ((row >> 2) & 3); }
+// the same for the 16x16x32 fragment pattern (lane -> row lane & 15, 16-byte k-chunk lane >> 4): the 16-lane service groups
+// of a ds_read_b128 then pair rows 0-3 / 12-15 at chunk c with rows 4-11 at chunk c ^ 1, and XOR-ing bit 1 of the chunk
+// with bit 3 of the row spreads every group over all 64 banks (tools/probe/lds_swizzle_check.py)
+__device__ __forceinline__ int pswz16(int row, int c) { return c ^ ((row >> 2) & 2); }
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -108,6 +113,51 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
   }
 }
 
+// Element-wise epilogue of one wave's MI x NJ grid of 16x16 accumulators (the layers the wide epilogue does not take: row
+// remap, positional add, Cout % 32 != 0): same arithmetic per element as conv_epilogue.
+template <int MI, int NJ>
+__device__ __forceinline__ void conv_epilogue16(const ConvP& p, float __attribute__((ext_vector_type(4))) (&acc)[MI][NJ], int mw, int nw,
+                                                int r, int q) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = nw + j * 16 + r;
+    if (n >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = mw + i * 16 + 4 * q + reg;
+        if (m >= p.M) continue;
+        float v = acc[i][j][reg] + bias;
+        size_t row = (size_t)m;
+        int in_img = 0;
+        if (p.rows_per_img > 0) {
+          const int img = m / p.rows_per_img;
+          in_img = m - img * p.rows_per_img;
+          row = (size_t)img * p.img_stride + p.row_off + in_img;
+        }
+        const size_t off = row * p.Cout + n;
+        if (p.res) v += p.res[off];
+        if (p.res_hi) {
+          const size_t ri = plane_idx(row, n, p.Cout);
+          v += bf16_bits_to_f32(p.res_hi[ri]) + bf16_bits_to_f32(p.res_hi[ri + 32]);
+        }
+        v = apply_act(v, p.act);
+        if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
+        if (p.out_hi) {
+          uint16_t hi, lo;
+          split_f32(v, hi, lo);
+          const size_t oi = plane_idx(row, n, p.Cout);
+          p.out_hi[oi] = hi;
+          p.out_hi[oi + 32] = lo;
+        } else {
+          p.out[off] = v;
+        }
+      }
+  }
+}
+
 // The vector-memory side of a tile for ONE issuing wave: which 16-row pieces of the A / B planes it copies, their per-lane
 // source addresses (XOR-swizzled k-chunk applied on the SOURCE: the LDS destination of a wave's LDS-DMA is linear) and the
 // per-row validity mask over the filter taps (out-of-image taps and rows beyond M / Cout read a zero page).
@@ -117,7 +167,7 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
 // -- on the source side of the DMA and on the ds_read side -- so that the 16-lane groups of a ds_read_b128 hit every bank once.
 __device__ __forceinline__ int aswz(int row, int c) { return c ^ ((row >> 1) & 7); }
 
-template <int BM, int BN, int LW, int ABL>
+template <int BM, int BN, int LW, int ABL, bool S16 = false>
 struct DmaIssuer {
   static constexpr int AJ = BM / (8 * LW), BJ = BN / (16 * LW);
   static constexpr int PLANE_A = BM * PROW, PLANE_B = BN * PROW, STAGE = 2 * PLANE_A + 2 * PLANE_B;
@@ -155,7 +205,7 @@ struct DmaIssuer {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int row = (lw * BJ + j) * 16 + lr;
-      const int c = pswz(row, pos);
+      const int c = S16 ? pswz16(row, pos) : pswz(row, pos);
       const int n = n0 + row;
       const bool ok = n < p.Cout;
       b_hi[j] = ok ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
@@ -380,6 +430,180 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
     } else {
       __builtin_amdgcn_s_barrier();
       conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_16x16x32_bf16 (round 3).  Block tile, LDS stages, loader waves, counted waits, barriers and
+// tile order are those of conv_bf16x3p_body; what changes is the matrix instruction: one MFMA consumes the WHOLE K-step of
+// 32 for a 16 x 16 output block (16 cycles on a SIMD) instead of half of it for a 32 x 32 block (32 cycles).  Per K-step a
+// wave reads the same 16 fragments (8 of A: 4 row blocks x hi / lo; 8 of B) and issues 48 MFMAs with the same FLOPs and
+// the same matrix-pipe cycles, but the chip holds a higher clock under this shape on random data (MI355X_MICROARCH.md
+// "DVFS give-back" item 7: 1.12-1.15 x the FLOP/s of the 32x32x16 loop with every operand re-read from LDS) -- and this
+// kernel is power-bound, not issue-bound (1.57 ms on random operands, 1.27 ms on zeros).
+// Per output element still three products per K-step in the order lo*hi, hi*lo, hi*hi, fp32 accumulate; the summation
+// INSIDE an MFMA now spans 32 k instead of 16, so results are not bit-identical to the 32x32x16 kernels (they agree to fp32
+// rounding; every kernel that may compute rows of the same layer must use the same shape -- see launch_conv_bf16x3p).
+// The stagger splits a K-step by ROW BLOCKS (first two of A, then the other two) since it can no longer be split by k:
+// waves 4-7 carry the B fragments and the second pair of A fragments across the barrier.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WM, int WN, int NL, bool STG>
+__device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned char* smem) {
+  constexpr int NW = WM * WN, NT = (NW + NL) * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
+  static_assert(MI >= 2 && (MI & 1) == 0 && NJ >= 1 && NL > 0, "wave tile / loader configuration");
+  using Issuer = DmaIssuer<BM, BN, NL, 0, true>;
+  constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, PER_STEP = Issuer::PER_STEP;
+  static_assert(BM * BN * 4 <= 3 * STAGE, "the fp32 epilogue tile must fit in the staging area");
+
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool loader = wave >= NW;  // wave-uniform
+  const int KT = p.K / PBK;
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * BM;
+    const int n0 = (tile % nt) * BN;
+    if (loader) {  // identical to conv_bf16x3p_body's loader (same barrier sequence)
+      Issuer dma;
+      dma.setup(p, m0, n0, wave - NW, lane);
+      dma.issue(p, smem, 0, 0);
+      if (KT > 1) dma.issue(p, smem, 1, 1);
+      int nxt2 = 2;
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    int offa[MI], offal[MI], offb[NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * WTM + i * 16 + r;
+      offa[i] = row * 128 + aswz(row, q) * 16;
+      offal[i] = row * 128 + aswz(row, 4 + q) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wn * WTN + j * 16 + r;
+      offb[j] = row * PROW + pswz16(row, q) * 16;
+    }
+    auto read_b = [&](const unsigned char* ah, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
+      const unsigned char* bh = ah + 2 * PLANE_A;
+      const unsigned char* bl = bh + PLANE_B;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[j]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[j]);
+      }
+    };
+    auto read_a = [&](const unsigned char* ah, auto half_c, bf16x8 (&fah)[MH], bf16x8 (&fal)[MH]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i) {
+        fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[half * MH + i]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[half * MH + i]);
+      }
+    };
+    auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          f32x4v c = acc[half * MH + i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
+          acc[half * MH + i][j] = c;
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    int cur = 0;
+    const bool late = STG && wave >= NW / 2;
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
+        const unsigned char* ah = smem + cur * STAGE;
+        bf16x8 fbh[NJ], fbl[NJ];
+        read_b(ah, fbh, fbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H0{}, fah, fal);
+          mma(H0{}, fah, fal, fbh, fbl);
+        }
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H1{}, fah, fal);
+          mma(H1{}, fah, fal, fbh, fbl);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+      }
+    } else {
+      bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
+      auto step = [&](auto carried_c) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* ah = smem + cur * STAGE;
+        if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);  // second half of the previous K-step
+        __builtin_amdgcn_sched_barrier(0);  // (no reads of this step hoisted above: the carried fragments die first)
+        read_b(ah, gbh, gbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H0{}, fah, fal);
+          mma(H0{}, fah, fal, gbh, gbl);
+        }
+        read_a(ah, H1{}, gah, gal);
+        // the reads have returned before this wave arrives at the next barrier (after it the stage may be overwritten)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cur = cur == 2 ? 0 : cur + 1;
+      };
+      step(H0{});  // peeled: nothing carried into K-step 0
+      for (int kt = 1; kt < KT; ++kt) step(H1{});
+      mma(H1{}, gah, gal, gbh, gbl);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the last stages: the staging area becomes the epilogue's fp32 tile
+    // C/D map of v_mfma_f32_16x16x32: col = lane & 15 -> n, row = 4 * (lane >> 4) + reg -> m
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = wm * WTM + i * 16 + 4 * q + reg;
+            const int col = (wn * WTN + j * 16 + r) ^ (((row >> 2) & 1) << 5);
+            tile_f[row * BN + col] = acc[i][j][reg];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+    } else {
+      __builtin_amdgcn_s_barrier();
+      conv_epilogue16<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, q);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
@@ -661,6 +885,20 @@ __global__ __launch_bounds__(768, 3) void conv_bf16x3p_256x128_s_k4608(const Con
   conv_bf16x3p_body<256, 128, 4, 2, 4, 0, true>(p, smem);
 }
 
+// 16x16x32 MFMA build of the same kernel (p.pipelined == 3)
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p16_256x128_s(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p16_256x128_s_k4608(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p16_256x128(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, false>(p, smem);
+}
+
 // the same without dedicated loader waves: 8 waves (2 per SIMD), the compute waves issue the LDS-DMA themselves
 __global__ __launch_bounds__(512, 2) void conv_bf16x3p_256x128_w8(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
@@ -717,6 +955,14 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
     if (grid > qtiles) grid = qtiles;
     if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3q_3x3_patch_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_bf16x3q_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
+    return hipGetLastError();
+  }
+  if (p.pipelined == 3) {  // the 16x16x32 build: all rows of a layer on ONE MFMA shape (no hand-over of tail rows to the 32x32x16 kernels)
+    if (grid > tiles) grid = tiles;
+    static const int stagger16 = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
+    if (!stagger16) hipLaunchKernelGGL(conv_bf16x3p16_256x128, dim3(grid), dim3(768), 0, s, p2);
+    else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
+    else hipLaunchKernelGGL(conv_bf16x3p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);
     return hipGetLastError();
   }
   // Whole rounds only.  The dominant layer has 2064 tiles: eight rounds on 256 CUs and then sixteen tiles that keep 16 CUs

@@ -1903,8 +1903,8 @@ int d2t_set_reserved_cus(d2t_ctx* c, int32_t cus) {
 
 int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   DevGuard dg_(c);
-  if (!c || kind < 0 || kind > 2)
-    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128) or 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps)");
+  if (!c || kind < 0 || kind > 3)
+    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) or 3 (pipelined 256x128 on 16x16x32 MFMAs)");
   c->conv_pipelined = kind;
   return D2T_OK;
 }
@@ -2008,7 +2008,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 1, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 2 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;
+  if (kind < 0 || kind > 3 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;

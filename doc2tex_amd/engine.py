@@ -290,7 +290,7 @@ class Engine:
 
     def set_conv_kernel(self, kind):
         """'pipelined' (256x128 tile, one block per CU, three LDS stages) or 'classic' (128x128, two blocks per CU)."""
-        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2}[kind]), "set_conv_kernel")
+        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3}[kind]), "set_conv_kernel")
 
     def set_decode_chains(self, chains):
         self._check(self.lib.d2t_set_decode_chains(self.ctx, int(chains)), "set_decode_chains")

@@ -251,7 +251,10 @@ int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
  * also the place where the tile count of the dominant layer comes out in whole rounds).  kind 0: the 128x128 kernel with
  * two blocks per CU (d2t_set_reserved_blocks applies to that one).  kind 2: as 1, but 3x3 / stride 1 / pad 1 layers on
  * maps at most 131 pixels wide take the patch-resident kernel (a tile's input records stay in LDS for all nine taps: half
- * the LDS-DMA; measured equal to kind 1 in sustained runs).  Results are bit-identical between all three. */
+ * the LDS-DMA; measured equal to kind 1 in sustained runs).  Results are bit-identical between kinds 0-2.
+ * kind 3: the pipelined kernel built on v_mfma_f32_16x16x32_bf16 (same tile, stages and loaders; one MFMA per K-step of 32
+ * and 16x16 output block): same three products per element in the same order, but the sum inside an MFMA spans 32 k, so
+ * results agree with kinds 0-2 to fp32 rounding, not bit for bit; all rows of a layer stay on this kernel. */
 int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
 int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
 /* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
