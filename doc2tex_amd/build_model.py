@@ -156,9 +156,10 @@ class Model(nn.Module):
         self.pipelined = False
         # pipelined mode: block slots the persistent convolution leaves free for the decode stream
         self.reserved_blocks = 64
-        # split-bf16 convolution kernel: 'pipelined' (256x128 tile, one block per CU, three LDS stages; default) or 'classic'
-        # (128x128, two blocks per CU); pipelined serving: compute units the pipelined kernel's grid leaves to the decode streams
-        self.conv_kernel = os.environ.get("D2T_CONV_KERNEL_NAME", "pipelined")
+        # split-bf16 convolution kernel: 'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs;
+        # default), 'pipelined' (the same on 32x32x16 MFMAs), 'patch', or 'classic' (128x128, two blocks per CU);
+        # pipelined serving: compute units the pipelined kernel's grid leaves to the decode streams
+        self.conv_kernel = os.environ.get("D2T_CONV_KERNEL_NAME", "pipelined16")
         self.reserved_cus = 0
         # pipelined mode: decode loops in flight side by side (1 or 2)
         self.decode_chains = 1

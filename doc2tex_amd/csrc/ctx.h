@@ -96,7 +96,7 @@ struct d2t_ctx {
   bool conv_bf16x3 = true;   // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
-  int conv_pipelined = 1;    // d2t_set_conv_kernel: 1 = pipelined 256x128 split-bf16 kernel (one block per CU), 0 = 128x128 (two per CU)
+  int conv_pipelined = 3;    // d2t_set_conv_kernel: 3 = pipelined 256x128 split-bf16 kernel on 16x16x32 MFMAs (default), 1 = the same on 32x32x16, 2 = 1 + patch-resident 3x3, 0 = 128x128 (two per CU)
   int reserved_cus = 0;      // d2t_set_reserved_cus: CUs the pipelined kernel's grid leaves to other streams (decode)
   int device = 0;            // HIP device the context was created on: every stream, event and buffer lives there
 

@@ -607,6 +607,303 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 4 : 2) void decoder_row_kernel(co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row kernel, round 3: cross-attention over the encoder MEMORY itself ("absorbed" projections).
+//
+// The kernel above streams, per row and layer, the projected K and V of its sample: 2 * T * D floats (534 KB at T = 261,
+// D = 256) that are different for every layer -- 1.23 GB per decode step at 384 rows, the whole cost of the step.  But
+//     score_h[j] = q_h . (W_k,h m_j + b_k,h) = (W_k,h^T q_h) . m_j + const_h          (the constant cancels in the softmax)
+//     out_h      = sum_j p_hj (W_v,h m_j + b_v,h) = W_v,h (sum_j p_hj m_j) + b_v,h     (sum_j p_hj = 1)
+// so a head can attend over the D-wide memory rows directly with the absorbed query q'_h = W_k,h^T q_h (D floats per head),
+// and project the attention-weighted memory row afterwards.  Per row and layer that reads T * D floats (267 KB) -- the SAME
+// bytes for all six layers, 102 MB for 384 rows: resident in the 256 MB Infinity Cache for the whole step loop -- and the
+// 2 x 205 MB projected-K/V buffers, their GEMM per batch and the per-layer streams disappear.  The price is arithmetic:
+// 8 heads x T x D multiply-adds for the scores and again for the weighted sum (8 x the head-dim form).  It goes to the
+// matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32, an fp32 fma chain per output like the VALU code it replaces):
+//     S^T [16 keys x 16 (8 heads + 8 idle)] = M_tile [16 x D] . Q'^T [D x 16]            64 MFMAs per 16-key tile
+//     ctx [16 (8 heads + 8 idle) x D]      += P [16 x 16 keys] . M_tile [16 x D]          64 MFMAs per tile
+// A wave owns the key tiles w, w + NW, ...: it copies a tile (16 rows x 1 KB) into its private 16 KB of LDS with LDS-DMA
+// (the 16-byte chunks of row i XOR-ed with i on the source side, so that both fragment patterns -- 16 keys x 4 channel
+// groups for the scores, 4 keys x 16 channel groups for the weighted sum -- read without bank conflicts:
+// tools/probe/lds_swizzle_check.py), keeps an online softmax per head (running max and sum, flash-decoding), and the waves'
+// partial (max, sum, ctx) triples are merged through LDS.  The S^T product is taken transposed on purpose: its result
+// layout (lane = (key group g, head), registers = keys 4g..4g+3) IS the A-operand layout of the second product with
+// k-step s <-> register s, so P never moves between lanes.
+// Everything else (self-attention over the cache, the three row GEMVs, LN1) is the code of decoder_row_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_dec;
+
+// this wave's share of the cross-attention of ONE query row set: heads x T keys of `mem` [T][256].
+// qp_s: LDS [8][256] absorbed queries (already scaled by 1/sqrt(head_dim)); stage: this wave's 16 KB; results: the wave's
+// running max / sum per head (lanes with col < 8, reduced over the key groups) and ctx accumulators acc[w][e] (D layout).
+template <int NW>
+__device__ __forceinline__ void cross_absorbed_wave(const float* __restrict__ mem, int T, const float* qp_s, unsigned char* stage,
+                                                    int wave, int lane, float& m_run, float& l_run, f32x4 (&acc)[4][4]) {
+  const int col = lane & 15, g = lane >> 4;
+  // B operand of the score product, constant over the tiles: q'[head = col][16u + 4g + t]
+  float4 qreg[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    qreg[u] = col < 8 ? *reinterpret_cast<const float4*>(qp_s + col * 256 + 16 * u + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  m_run = -INFINITY;
+  l_run = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[w][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 15) >> 4;
+  for (int tile = wave; tile < ntiles; tile += NW) {
+    const int j0 = tile << 4;
+    // ---- stage the tile: row i -> stage + i * 1024, physical 16-byte chunk p holds logical chunk p ^ i ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's fragment reads have returned
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = j0 + i < T ? j0 + i : T - 1;  // rows past the end: a valid row, its probability is forced to zero
+      const float* src = mem + (size_t)j * 256 + ((lane ^ i) << 2);
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- S^T[key = 4g' + reg][head = col] = sum_c m[key][c] q'[head][c] ----
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      // A operand: lane (row = key col, k = g) -> m[key][16u + 4g + t]; logical chunk 4u + g of row `col`
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + col * 1024 + (((4 * u + g) ^ col) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, qreg[u].x, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, qreg[u].y, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, qreg[u].z, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, qreg[u].w, sacc, 0, 0, 0);
+    }
+    // ---- online softmax: this lane holds keys j0 + 4g + reg of head `col` ----
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
+      mx = fmaxf(mx, sv[reg]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // a tile holds at least one valid key: finite
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 for the first tile
+    float pv[4], ps = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      pv[reg] = expf(sv[reg] - m_new);  // exp(-inf) = 0 for keys past the end
+      ps += pv[reg];
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    // the accumulators hold ctx[head = 4g + reg][...]: their scale is the alpha of THAT head (lane 4g + reg has it)
+    float ar[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ar[reg] = __shfl(alpha, 4 * g + reg, 64);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[w][e][reg] *= ar[reg];
+    // ---- ctx[head][64w + 4 col' + e] += sum_keys P[head][key] m[key][chan]; k-step s <-> keys 4g + s ----
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {
+      const int key = 4 * g + sk;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        // B operand: lane (k = g, col) -> m[key][64w + 4 col + e]; logical chunk 16w + col of row `key`
+        const float4 b4 = *reinterpret_cast<const float4*>(stage + key * 1024 + (((16 * w + col) ^ key) << 4));
+        acc[w][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.x, acc[w][0], 0, 0, 0);
+        acc[w][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.y, acc[w][1], 0, 0, 0);
+        acc[w][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.z, acc[w][2], 0, 0, 0);
+        acc[w][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.w, acc[w][3], 0, 0, 0);
+      }
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+}
+
+struct DecRow2P {
+  DecRowP r;            // as decoder_row_kernel (ck / cv unused)
+  const float* mem;     // [samples][T][D] encoder memory (engine-owned copy)
+  long long mem_stride; // floats per sample
+  const float* wk;      // [D][D] cross-attention key projection as stored (rows = output feature h*hd + e)
+  const float* wv_t;    // [D (c)][D (o)] value projection, transposed
+  const float* bv;      // [D]
+};
+
+template <int NTH>  // D = 256, 8 heads of 32
+__global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecRow2P q) {
+  constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
+  const DecRowP& p = q.r;
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
+  // 78 KB: two blocks per CU.  The GEMV partial sums live in the (then idle) tile staging area, the merged context rows
+  // in the absorbed queries' place (the queries are in registers by then).
+  __shared__ __attribute__((aligned(1024))) unsigned char stage_s[NW * 16384];
+  __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D], qp_s[8 * D];
+  __shared__ float wm_s[NW][8], wl_s[NW][8];
+  float* const part_s = reinterpret_cast<float*>(stage_s);
+  float* const ctx_s = qp_s;
+  static_assert(G * D * 4 <= 16384, "GEMV partial sums must fit into one wave's staging area");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const int t = *p.step_ptr;
+  const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
+  // ---- self-attention over the cache (as decoder_row_kernel) ----
+#pragma unroll
+  for (int hp = 0; hp < HPW; ++hp) {
+    const int head = wave + hp * NW;
+    float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+    float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+    const float* curk = qkv + D + head * HD;
+    const float* curv = qkv + 2 * D + head * HD;
+    if (lane < HD) {
+      Kc[(size_t)t * HD + lane] = curk[lane];
+      Vc[(size_t)t * HD + lane] = curv[lane];
+    }
+    row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s + head * HD, lane);
+  }
+  __syncthreads();
+  row_gemv<D, NTH>(a_s, p.wo_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bo[tid] + p.xres[(size_t)b * D + tid];
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) v += part_s[gI * D + tid];
+    y_s[tid] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {  // LN1, two-pass, one wave
+    constexpr int V = D / 64;
+    float v[V], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = y_s[i * 64 + lane]; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] -= mean; qq += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float rstd = 1.f / sqrtf(qq * (1.f / D) + p.eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = i * 64 + lane;
+      x1_s[c] = v[i] * rstd * p.ln1_g[c] + p.ln1_b[c];
+    }
+  }
+  __syncthreads();
+  row_gemv<D, NTH>(x1_s, p.wq_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bq[tid];
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) v += part_s[gI * D + tid];
+    q2_s[tid] = v;
+  }
+  __syncthreads();
+  // ---- absorbed queries: q'[h][c] = scale * sum_e q2[h*32 + e] * W_k[h*32 + e][c] ----
+  {
+    const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+    for (int idx = tid; idx < 8 * (D / 4); idx += NTH) {
+      const int h = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+      const float* w = q.wk + (size_t)(h * HD) * D + c4;
+      float4 accq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int e = 0; e < HD; ++e) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)e * D);
+        const float a = q2_s[h * HD + e];
+        accq.x = fmaf(a, w4.x, accq.x); accq.y = fmaf(a, w4.y, accq.y);
+        accq.z = fmaf(a, w4.z, accq.z); accq.w = fmaf(a, w4.w, accq.w);
+      }
+      *reinterpret_cast<float4*>(qp_s + h * D + c4) = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
+    }
+  }
+  __syncthreads();
+  // ---- cross-attention over the memory rows of this row's sample ----
+  {
+    const int cb = p.c_row_map ? p.c_row_map[b] : b;
+    float m_run, l_run;
+    f32x4 acc[4][4];
+    unsigned char* stage = stage_s + wave * 16384;
+    cross_absorbed_wave<NW>(q.mem + (size_t)cb * q.mem_stride, p.T, qp_s, stage, wave, lane, m_run, l_run, acc);
+    const int col = lane & 15, g = lane >> 4;
+    if (g == 0 && col < 8) { wm_s[wave][col] = m_run; wl_s[wave][col] = l_run; }
+    // this wave's un-normalised ctx [8 heads][256] into its (now idle) staging area: lane (g, col) holds heads 4g + reg
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* mine = reinterpret_cast<float*>(stage);
+    if (g < 2) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
+              make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 8 * (D / 4); idx += NTH) {  // merge the waves' partial softmaxes (log-sum-exp combine)
+    const int h = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, wm_s[w][h]);
+    float L = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = wl_s[w][h] > 0.f ? expf(wm_s[w][h] - M) : 0.f;  // waves without keys contribute nothing
+      L += wl_s[w][h] * f;
+      const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(stage_s + w * 16384) + h * D + c4);
+      o.x += c.x * f; o.y += c.y * f; o.z += c.z * f; o.w += c.w * f;
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<float4*>(ctx_s + h * D + c4) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+  }
+  __syncthreads();
+  // ---- a2[o] = b_v[o] + sum_c ctx[head(o)][c] * W_v^T[c][o] ----
+  {
+    constexpr int LPR = D / 4, KG = D / G;
+    const int lr = tid % LPR, gI = tid / LPR;
+    const float* w = q.wv_t + (size_t)(gI * KG) * D + lr * 4;
+    const float* in = ctx_s + ((lr * 4) / HD) * D + gI * KG;
+    float4 accv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
+      const float a = in[k];
+      accv.x = fmaf(a, w4.x, accv.x); accv.y = fmaf(a, w4.y, accv.y);
+      accv.z = fmaf(a, w4.z, accv.z); accv.w = fmaf(a, w4.w, accv.w);
+    }
+    *reinterpret_cast<float4*>(part_s + gI * D + lr * 4) = accv;
+  }
+  __syncthreads();
+  if (tid < D) {
+    float v = q.bv[tid];
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) v += part_s[gI * D + tid];
+    a_s[tid] = v;
+  }
+  __syncthreads();
+  row_gemv<D, NTH>(a_s, p.wco_t, part_s, tid);
+  __syncthreads();
+  if (tid < D) {
+    float v = p.bco[tid] + x1_s[tid];
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) v += part_s[gI * D + tid];
+    p.y2[(size_t)b * D + tid] = v;
+  }
+}
+
+hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
+                                       const float* bv, hipStream_t s) {
+  if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
+  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv};
+  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256>), dim3(r.M), dim3(256), 0, s, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
   if (p.heads != 8) return hipErrorInvalidValue;
   const bool small = decode_small() != 0;

@@ -2006,7 +2006,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 }
 
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
-static int g_op_conv_kind = 1, g_op_reserved_cus = 0;
+static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
   if (kind < 0 || kind > 3 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;
   g_op_conv_kind = kind;

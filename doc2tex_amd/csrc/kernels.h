@@ -215,6 +215,10 @@ struct DecRowP {
   const int* stop_at;                 // early exit, as SkinnyP::stop_at (the step counter is step_ptr)
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
+// the same step with the cross-attention taken over the encoder memory itself (absorbed K / V projections, decode.hip):
+// mem [samples][T][256] (row b attends over sample c_row_map[b] or b), wk [256][256] as stored, wv_t [c][o], bv [256]
+hipError_t launch_decoder_row_absorbed(const DecRowP& p, const float* mem, long long mem_stride, const float* wk,
+                                       const float* wv_t, const float* bv, hipStream_t s);
 hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
 
 // x[b] = emb[tok]*sqrt(d) + pe[t];  tok = (t == 0) ? start[b] : tokens[b*tok_stride + t - 1]

@@ -289,7 +289,8 @@ class Engine:
         self._check(self.lib.d2t_set_reserved_cus(self.ctx, int(cus)), "set_reserved_cus")
 
     def set_conv_kernel(self, kind):
-        """'pipelined' (256x128 tile, one block per CU, three LDS stages) or 'classic' (128x128, two blocks per CU)."""
+        """'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs), 'pipelined' (32x32x16 MFMAs),
+        'patch' (pipelined + patch-resident 3x3 kernel) or 'classic' (128x128, two blocks per CU)."""
         self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3}[kind]), "set_conv_kernel")
 
     def set_decode_chains(self, chains):

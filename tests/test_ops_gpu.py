@@ -279,9 +279,25 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
                                                   _lib.stream_of(xd)) == 0
             torch.cuda.synchronize()
             outs.append(y.cpu())
+        # the default: the pipelined kernel on 16x16x32 MFMAs.  Same products per element in the same order, but the sum inside
+        # one MFMA spans 32 k instead of 16: equal to fp32 rounding, and exactly as close to float64 as the others
+        assert lib.d2t_op_set_conv_kernel(3, 0) == 0
+        y16 = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16), B, H, W,
+                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
+        # and per sample: a sample's rows do not depend on the batch they are computed in (one kernel per layer shape)
+        y16_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
+                                              _lib.ptr(y16_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
+                                              _lib.stream_of(xd)) == 0
+        torch.cuda.synchronize()
+        y16, y16_0 = y16.cpu(), y16_0.cpu()
     finally:
-        lib.d2t_op_set_conv_kernel(1, 0)
+        lib.d2t_op_set_conv_kernel(3, 0)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = _ref_conv(x, w, b, res, st, pd, 1)
-    assert float((outs[1].permute(0, 3, 1, 2) - ref).abs().max()) <= 4e-4
+    e32 = float((outs[1].permute(0, 3, 1, 2) - ref).abs().max())
+    e16 = float((y16.permute(0, 3, 1, 2) - ref).abs().max())
+    assert e32 <= 4e-4 and e16 <= 4e-4 and e16 <= 1.5 * e32 + 1e-6, (e32, e16)
+    assert torch.isfinite(y16).all() and torch.equal(y16[B - 1:], y16_0)
