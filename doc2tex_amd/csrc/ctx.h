@@ -54,6 +54,11 @@ struct DecLayer {
   LinW sa_in, sa_out, ca_q, ca_out, l1, l2;
   LNW n1, n2, n3;
   float *sa_out_t = nullptr, *ca_q_t = nullptr, *ca_out_t = nullptr;  // [k][n] copies for the row kernel
+  // absorbed cross-attention (decode.hip decoder_row_absorbed_kernel): the key projection as stored ([o][c], in ckv_w), the
+  // value projection transposed ([c][o]) and its bias
+  const float* ca_wk = nullptr;
+  float* ca_v_t = nullptr;
+  const float* ca_bv = nullptr;
 };
 struct Block {
   ConvW c1, c2, down;
@@ -130,6 +135,9 @@ struct d2t_ctx {
   // decoder state
   float* ckv2[2] = {nullptr, nullptr}; size_t ckv2_cap[2] = {0, 0};  // cross K/V, double-buffered across decodes
   float* ckv = nullptr;                                              // the slot the current decode reads
+  // d_model 256 / 8 heads: the decode attends over the encoder memory itself (absorbed K / V projections); the slots then
+  // hold a COPY OF THE MEMORY [B][T][d] instead of the projected K / V of every layer [layers*2][B][heads][T][hd]
+  bool dec_absorbed = false;
   hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
   bool ev_done_valid[2] = {false, false};
   unsigned decode_seq = 0;

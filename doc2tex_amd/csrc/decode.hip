@@ -634,17 +634,17 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 4 : 2) void decoder_row_kernel(co
 typedef __attribute__((address_space(3))) void* lds_ptr_dec;
 
 // this wave's share of the cross-attention of ONE query row set: heads x T keys of `mem` [T][256].
-// qp_s: LDS [8][256] absorbed queries (already scaled by 1/sqrt(head_dim)); stage: this wave's 16 KB; results: the wave's
+// qp_s: LDS [8][256] absorbed queries (already scaled by 1/sqrt(head_dim); the 16-byte chunks of row h XOR-ed with h like
+// the tile rows); stage: this wave's 16 KB; results: the wave's
 // running max / sum per head (lanes with col < 8, reduced over the key groups) and ctx accumulators acc[w][e] (D layout).
 template <int NW>
 __device__ __forceinline__ void cross_absorbed_wave(const float* __restrict__ mem, int T, const float* qp_s, unsigned char* stage,
                                                     int wave, int lane, float& m_run, float& l_run, f32x4 (&acc)[4][4]) {
   const int col = lane & 15, g = lane >> 4;
-  // B operand of the score product, constant over the tiles: q'[head = col][16u + 4g + t]
-  float4 qreg[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u)
-    qreg[u] = col < 8 ? *reinterpret_cast<const float4*>(qp_s + col * 256 + 16 * u + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // B operand of the score product: q'[head = col][16u + 4g + t], re-read from LDS per tile (16 reads against 128 MFMAs; in
+  // registers it would cost 64 VGPRs and the second block per CU).  The idle half of the MFMA tile (columns 8..15) repeats
+  // heads 0..7: its results are never stored, and identical addresses broadcast.
+  const int hrow = col & 7;
   m_run = -INFINITY;
   l_run = 0.f;
 #pragma unroll
@@ -669,10 +669,11 @@ __device__ __forceinline__ void cross_absorbed_wave(const float* __restrict__ me
     for (int u = 0; u < 16; ++u) {
       // A operand: lane (row = key col, k = g) -> m[key][16u + 4g + t]; logical chunk 4u + g of row `col`
       const float4 a4 = *reinterpret_cast<const float4*>(stage + col * 1024 + (((4 * u + g) ^ col) << 4));
-      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, qreg[u].x, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, qreg[u].y, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, qreg[u].z, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, qreg[u].w, sacc, 0, 0, 0);
+      const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(qp_s) + hrow * 1024 + (((4 * u + g) ^ hrow) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, q4.x, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, q4.y, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, q4.z, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, q4.w, sacc, 0, 0, 0);
     }
     // ---- online softmax: this lane holds keys j0 + 4g + reg of head `col` ----
     float sv[4], mx = -INFINITY;
@@ -738,10 +739,11 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
   decode_wave_priority();
   TraceScope trace_(p.trace);
-  // 78 KB: two blocks per CU.  The GEMV partial sums live in the (then idle) tile staging area, the merged context rows
+  // 77 KB: two blocks per CU.  The GEMV partial sums live in the (then idle) tile staging area, the merged context rows
   // in the absorbed queries' place (the queries are in registers by then).
   __shared__ __attribute__((aligned(1024))) unsigned char stage_s[NW * 16384];
-  __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D], qp_s[8 * D];
+  __shared__ __attribute__((aligned(1024))) float qp_s[8 * D];
+  __shared__ __attribute__((aligned(16))) float a_s[D], y_s[D], x1_s[D], q2_s[D];
   __shared__ float wm_s[NW][8], wl_s[NW][8];
   float* const part_s = reinterpret_cast<float*>(stage_s);
   float* const ctx_s = qp_s;
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
         accq.x = fmaf(a, w4.x, accq.x); accq.y = fmaf(a, w4.y, accq.y);
         accq.z = fmaf(a, w4.z, accq.z); accq.w = fmaf(a, w4.w, accq.w);
       }
-      *reinterpret_cast<float4*>(qp_s + h * D + c4) = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
+      *reinterpret_cast<float4*>(qp_s + h * D + ((((c4 >> 2) ^ h)) << 2)) = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
     }
   }
   __syncthreads();

@@ -655,6 +655,15 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
       *pr.first = (float*)tp;
       HIPCHK(c, launch_transpose(pr.second, *pr.first, d, d, s));
     }
+    {  // absorbed cross-attention: W_k as stored, W_v transposed (read from the engine's stacked copy), b_v
+      void* tp;
+      if ((rc = dev_alloc(c, &tp, (size_t)d * d * 4))) return rc;
+      c->owned.push_back(tp);
+      dl.ca_v_t = (float*)tp;
+      dl.ca_wk = c->ckv_w + (size_t)i * 2 * d * d;
+      dl.ca_bv = c->ckv_b + (size_t)i * 2 * d + d;
+      HIPCHK(c, launch_transpose(c->ckv_w + (size_t)i * 2 * d * d + (size_t)d * d, dl.ca_v_t, d, d, s));
+    }
     c->dec.push_back(dl);
   }
   if ((rc = get_lin(c, pp + "proj", &c->out_proj, V, d))) return rc;
@@ -664,6 +673,7 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
     c->ckv_hi = const_cast<uint16_t*>(hi);
     c->ckv_lo = const_cast<uint16_t*>(lo);
   }
+  c->dec_absorbed = d == 256 && g.dec_heads == 8 && !getenv("D2T_DECODE_PROJECTED_KV");
   HIPCHK(c, hipStreamSynchronize(s));
   c->finalized = true;
   return D2T_OK;
@@ -903,6 +913,9 @@ hipError_t skinny(hipStream_t s, const Lin& l, int M, const LNW* ln = nullptr, f
 hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim;
+  // absorbed form: no projection at all -- the step loop reads the memory rows; the slot keeps a copy so that the captured
+  // loop holds an engine address and the caller's tensor is free again as soon as this copy has run
+  if (c->dec_absorbed) return hipMemcpyAsync(c->ckv, memory, (size_t)B * T * d * sizeof(float), hipMemcpyDeviceToDevice, s);
   ConvP p{};
   p.in = memory; p.w = c->ckv_w; p.bias = c->ckv_b; p.out = c->ckv;
   if (c->conv_bf16x3 && c->ckv_hi) { p.w_hi = c->ckv_hi; p.w_lo = c->ckv_lo; }
@@ -952,7 +965,8 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
     r.trace = trace_slot(c);
     r.stop_at = stop;
-    TRY(launch_decoder_row(r, s));
+    if (c->dec_absorbed) TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s));
+    else TRY(launch_decoder_row(r, s));
     TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c), stop, step));
     TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c), stop, step));
   }
