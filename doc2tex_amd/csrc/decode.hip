@@ -732,6 +732,11 @@ struct DecRow2P {
   const float* bv;      // [D]
 };
 
+#ifdef D2T_PROBES
+#define ROW_PROBE(bit) (p.probe & (bit))
+#else
+#define ROW_PROBE(bit) 0
+#endif
 template <int NTH>  // D = 256, 8 heads of 32
 __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecRow2P q) {
   constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
   // ---- self-attention over the cache (as decoder_row_kernel) ----
 #pragma unroll
-  for (int hp = 0; hp < HPW; ++hp) {
+  for (int hp = 0; hp < (ROW_PROBE(1) ? 0 : HPW); ++hp) {
     const int head = wave + hp * NW;
     float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
     float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
     row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s + head * HD, lane);
   }
   __syncthreads();
-  row_gemv<D, NTH>(a_s, p.wo_t, part_s, tid);
+  if (!ROW_PROBE(2)) row_gemv<D, NTH>(a_s, p.wo_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bo[tid] + p.xres[(size_t)b * D + tid];
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
     }
   }
   __syncthreads();
-  row_gemv<D, NTH>(x1_s, p.wq_t, part_s, tid);
+  if (!ROW_PROBE(2)) row_gemv<D, NTH>(x1_s, p.wq_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bq[tid];
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   }
   __syncthreads();
   // ---- absorbed queries: q'[h][c] = scale * sum_e q2[h*32 + e] * W_k[h*32 + e][c] ----
-  {
+  if (!ROW_PROBE(2)) {
     const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
     for (int idx = tid; idx < 8 * (D / 4); idx += NTH) {
       const int h = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   }
   __syncthreads();
   // ---- cross-attention over the memory rows of this row's sample ----
-  {
+  if (!ROW_PROBE(4)) {
     const int cb = p.c_row_map ? p.c_row_map[b] : b;
     float m_run, l_run;
     f32x4 acc[4][4];
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < 8 * (D / 4); idx += NTH) {  // merge the waves' partial softmaxes (log-sum-exp combine)
+  for (int idx = tid; idx < (ROW_PROBE(4) ? 0 : 8 * (D / 4)); idx += NTH) {  // merge the waves' partial softmaxes (log-sum-exp combine)
     const int h = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
     float M = -INFINITY;
 #pragma unroll
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   }
   __syncthreads();
   // ---- a2[o] = b_v[o] + sum_c ctx[head(o)][c] * W_v^T[c][o] ----
-  {
+  if (!ROW_PROBE(2)) {
     constexpr int LPR = D / 4, KG = D / G;
     const int lr = tid % LPR, gI = tid / LPR;
     const float* w = q.wv_t + (size_t)(gI * KG) * D + lr * 4;
@@ -888,7 +893,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
     a_s[tid] = v;
   }
   __syncthreads();
-  row_gemv<D, NTH>(a_s, p.wco_t, part_s, tid);
+  if (!ROW_PROBE(2)) row_gemv<D, NTH>(a_s, p.wco_t, part_s, tid);
   __syncthreads();
   if (tid < D) {
     float v = p.bco[tid] + x1_s[tid];
@@ -902,6 +907,8 @@ hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long 
                                        const float* bv, hipStream_t s) {
   if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
   DecRow2P q{r, mem, mem_stride, wk, wv_t, bv};
+  static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
+  q.r.probe = probe;
   hipLaunchKernelGGL((decoder_row_absorbed_kernel<256>), dim3(r.M), dim3(256), 0, s, q);
   return hipGetLastError();
 }

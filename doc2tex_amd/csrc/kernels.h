@@ -213,6 +213,7 @@ struct DecRowP {
   int M, D, heads;
   unsigned long long* trace;          // debug (D2T_DECODE_TRACE), as SkinnyP::trace
   const int* stop_at;                 // early exit, as SkinnyP::stop_at (the step counter is step_ptr)
+  int probe;                          // probe builds only (D2T_ROW_PROBE bit mask: 1 no self-attention, 2 no GEMVs, 4 no cross-attention)
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 // the same step with the cross-attention taken over the encoder memory itself (absorbed K / V projections, decode.hip):

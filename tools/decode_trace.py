@@ -10,7 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from doc2tex_amd import Model, synth
+from doc2tex_amd import Model, _lib, synth
+
+if os.environ.get("D2T_PROBE_LIB"):  # a probe build of the library (D2T_PROBES=1, e.g. doc2tex_amd/csrc/libd2t_probe.so): phase-ablation switches
+    _lib.LIB_PATH = os.path.abspath(os.environ["D2T_PROBE_LIB"])
 
 group = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 kernel = sys.argv[2] if len(sys.argv) > 2 else "pipelined"

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Go / no-go study (CPU emulation): Winograd F(2x2, 3x3) with split-bf16 operands on the sixteen
+512 -> 512 3x3 convolutions of the backbone, against direct split-bf16 convolutions, on the reference-generated fixtures.
+
+What is emulated (fp32 torch on the CPU; a product of two bf16 values is exact in fp32, sums are fp32 like the MFMA's):
+  direct    x = hi + lo, w = hi + lo (hi = upper 16 bits, lo = bf16_rne(rest)); y = conv(x_hi, w_hi) + conv(x_hi, w_lo) +
+            conv(x_lo, w_hi)                                    -- what the engine's convolution kernels compute
+  winograd  V = B^T d B per 4x4 input tile (fp32), U = G g G^T (float64, rounded once), both split as above;
+            M = V_hi U_hi + V_hi U_lo + V_lo U_hi per tile component (16 batched [tiles x 512 x 512] products);
+            Y = A^T M A (fp32) + bias                           -- what a fused Winograd kernel would compute
+Every convolution with Cin >= 32 runs "direct" in both arms (as in the engine); the sixteen 512 -> 512 3x3 / stride 1 /
+pad 1 layers switch to "winograd" in the second arm.  Reported per fixture: greedy tokens equal to the reference's, and
+max |logit - reference logit| over the stored logit samples.  "Go" = tokens exact everywhere and max |dlogit| <= 2e-4.
+
+usage: python tools/winograd_study.py [fixture ...]      (default: c2_greedy c2_small_crop c4_greedy_160 c4_greedy_96)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLD, oracle_state_dict
+from doc2tex_amd import synth
+from oracle import restatement as R
+
+
+def split(x):
+    hi = (x.view(torch.int32) & -65536).view(torch.float32)
+    lo = (x - hi).to(torch.bfloat16).to(torch.float32)
+    return hi, lo
+
+
+def conv_direct(x, w, b, stride, padding):
+    xh, xl = split(x.contiguous())
+    wh, wl = split(w.contiguous())
+    y = F.conv2d(xl, wh, None, stride, padding) + F.conv2d(xh, wl, None, stride, padding)
+    return y + F.conv2d(xh, wh, b, stride, padding)
+
+
+BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+STATS = {"winograd_layers": 0}
+
+
+def conv_winograd(x, w, b):
+    Bn, C, H, W = x.shape
+    K = w.shape[0]
+    H2, W2 = (H + 1) // 2 * 2, (W + 1) // 2 * 2  # output padded to whole 2x2 tiles
+    xp = F.pad(x, (1, 1 + W2 - W, 1, 1 + H2 - H))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)  # [B, C, th, tw, 4, 4]
+    V = torch.einsum("ij,bcxyjk,lk->bcxyil", BT, d, BT)  # B^T d B
+    U = torch.einsum("ij,kcjl,ml->kcim", G, w.double(), G).float()  # G g G^T, rounded once
+    Vh, Vl = split(V.contiguous())
+    Uh, Ul = split(U.contiguous())
+    M = torch.einsum("bcxyil,kcil->bkxyil", Vl, Uh) + torch.einsum("bcxyil,kcil->bkxyil", Vh, Ul)
+    M = M + torch.einsum("bcxyil,kcil->bkxyil", Vh, Uh)
+    Y = torch.einsum("pi,bkxyil,ql->bkxpyq", AT, M, AT)  # A^T M A -> [B, K, th, 2, tw, 2]
+    Y = Y.reshape(Bn, K, H2, W2)[:, :, :H, :W]
+    STATS["winograd_layers"] += 1
+    return Y + b.view(1, -1, 1, 1)
+
+
+def make_conv_bn(arm):
+    def _conv_bn(x, sd, conv, bn, stride=1, padding=0, faithful=True, bn_train=None):
+        w = sd[conv + ".weight"]
+        wf, bf = R.fold_bn(w, sd, bn)
+        if w.shape[1] < 32 or arm == "fp32":
+            return F.conv2d(x, wf, bf, stride, padding)
+        s = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        if arm == "winograd" and tuple(w.shape) == (512, 512, 3, 3) and s == (1, 1) and pd == (1, 1):
+            return conv_winograd(x, wf, bf)
+        return conv_direct(x, wf, bf, stride, padding)
+    return _conv_bn
+
+
+def main():
+    names = sys.argv[1:] or ["c2_greedy", "c2_small_crop", "c4_greedy_160", "c4_greedy_96"]
+    with open(os.path.join(GOLD, "cases.json")) as f:
+        cases = json.load(f)
+    with open(os.path.join(GOLD, "manifests.json")) as f:
+        man = json.load(f)
+    torch.set_num_threads(os.cpu_count() or 1)
+    orig = R._conv_bn
+    rows = []
+    for name in names:
+        c = next(q for q in cases["greedy"] if q["case"] == name)
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        cfg, sd = oracle_state_dict(c["config"], man[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+        img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+        text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
+        steps = z["logit_steps"].tolist()
+        for arm in ("fp32", "direct", "winograd"):
+            R._conv_bn = make_conv_bn(arm)
+            STATS["winograd_layers"] = 0
+            t0 = time.time()
+            try:
+                with torch.no_grad():
+                    p, l, _ = R.forward(cfg, sd, img, text, is_test=c["is_test"], faithful=False)
+            finally:
+                R._conv_bn = orig
+            same = p.shape == tuple(z["tokens"].shape) and bool(np.array_equal(p.numpy(), z["tokens"]))
+            dl = float(np.abs(l[:, steps].numpy() - z["logits_sample"]).max()) if p.shape[1] == z["tokens"].shape[1] else float("nan")
+            gap = float(z["top2_gap"].min()) if "top2_gap" in z.files else float("nan")
+            rows.append((name, arm, same, dl, gap, STATS["winograd_layers"], time.time() - t0))
+            print(f"{name:16s} {arm:9s} tokens exact: {same}  max |dlogit| {dl:.3e}  (smallest top-2 gap of the fixture {gap:.2e}; "
+                  f"{STATS['winograd_layers']} Winograd layers; {time.time() - t0:.0f} s)", flush=True)
+    wino = [r for r in rows if r[1] == "winograd"]
+    go = all(r[2] for r in wino) and max(r[3] for r in wino) <= 2e-4
+    print("verdict on numerics:", "GO" if go else "NO-GO", f"(worst winograd |dlogit| {max(r[3] for r in wino):.3e}, "
+          f"worst direct {max(r[3] for r in rows if r[1] == 'direct'):.3e})")
+
+
+if __name__ == "__main__":
+    main()
