@@ -269,6 +269,8 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
     model.reserved_cus = args.reserve_cus
     if args.conv_kernel:
         model.conv_kernel = args.conv_kernel
+    if args.winograd is not None:
+        model.conv_winograd = args.winograd
     host_img = synth.synth_images(B, H, W, seed=1000 + rank).pin_memory()  # each rank its own shard
     img = host_img.to(dev)
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
@@ -543,6 +545,8 @@ def main():
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16"],
                     help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
+    ap.add_argument("--winograd", type=int, default=None,
+                    help="Winograd F(2x2,3x3) for the 3x3 layers with at least this many channels (0 = off)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
     ap.add_argument("--chains", type=int, default=2, choices=[1, 2],

@@ -33,6 +33,7 @@ struct RawW {
 struct ConvW {
   float* w = nullptr;
   uint16_t *w_hi = nullptr, *w_lo = nullptr;  // bf16 split of w for the bf16x3 kernel
+  uint16_t *u_hi = nullptr, *u_lo = nullptr;  // Winograd-domain weights [16][Cout][Cin] (3x3 layers the Winograd kernel takes)
   float* bias = nullptr;
   int Cout = 0, Cin = 0, KH = 0, KW = 0;
 };
@@ -138,6 +139,10 @@ struct d2t_ctx {
   // d_model 256 / 8 heads: the decode attends over the encoder memory itself (absorbed K / V projections); the slots then
   // hold a COPY OF THE MEMORY [B][T][d] instead of the projected K / V of every layer [layers*2][B][heads][T][hd]
   bool dec_absorbed = false;
+  // Winograd F(2x2,3x3) for the 3x3 / stride 1 / pad 1 split-record layers with Cin, Cout >= wino_min_channels
+  // (d2t_set_conv_winograd; 0 = off): workspace for the transformed input tiles
+  int wino_min_channels = 0;
+  float* wino_ws = nullptr; size_t wino_ws_cap = 0;
   hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
   bool ev_done_valid[2] = {false, false};
   unsigned decode_seq = 0;

@@ -35,6 +35,16 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
     out->w_hi = (uint16_t*)ph;
     out->w_lo = (uint16_t*)pl;
     HIPCHK(c, launch_split_bf16(out->w, out->w_hi, out->w_lo, w->numel, s));
+    if (out->KH == 3 && out->KW == 3 && out->Cout % 32 == 0 && out->Cin >= 256) {  // Winograd-domain copy (16 / 9 of the weights)
+      void *uh, *ul;
+      const size_t nu = (size_t)16 * out->Cout * out->Cin;
+      if ((rc = dev_alloc(c, &uh, nu * 2)) || (rc = dev_alloc(c, &ul, nu * 2))) return rc;
+      c->owned.push_back(uh);
+      c->owned.push_back(ul);
+      out->u_hi = (uint16_t*)uh;
+      out->u_lo = (uint16_t*)ul;
+      HIPCHK(c, launch_wino_weights(out->w, out->u_hi, out->u_lo, out->Cout, out->Cin, s));
+    }
   }
   return D2T_OK;
 }
@@ -120,7 +130,21 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
   p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
-  hipError_t e = conv_timed(c, p, s);
+  hipError_t e;
+  if (c->conv_bf16x3 && c->wino_min_channels > 0 && w.u_hi && x.C >= c->wino_min_channels && w.Cout >= c->wino_min_channels &&
+      wino_applicable(p)) {
+    // Winograd form (same ProfRec shape as the direct kernel: the bench rates it in direct-convolution FLOPs)
+    if (ensure(c, &c->wino_ws, &c->wino_ws_cap, wino_workspace_bytes(x.B, x.H, x.W, x.C))) e = hipErrorOutOfMemory;
+    else {
+      d2t_ctx::ProfRec r{p.M, p.Cout, p.K, nullptr, nullptr};
+      const bool prof = c->profiling && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
+      if (prof) hipEventRecord(r.a, s);
+      e = launch_conv_winograd(p, w.u_hi, w.u_lo, reinterpret_cast<uint16_t*>(c->wino_ws), s);
+      if (prof) { hipEventRecord(r.b, s); c->prof.push_back(r); }
+    }
+  } else {
+    e = conv_timed(c, p, s);
+  }
   if (e != hipSuccess && *err == hipSuccess) *err = e;
   return y;
 }
@@ -331,6 +355,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->skv) hipFree(c->skv);
   if (c->skv_alt) hipFree(c->skv_alt);
   if (c->beam_ws) hipFree(c->beam_ws);
+  if (c->wino_ws) hipFree(c->wino_ws);
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -1923,6 +1948,14 @@ int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   return D2T_OK;
 }
 
+int d2t_set_conv_winograd(d2t_ctx* c, int32_t min_channels) {
+  DevGuard dg_(c);
+  if (!c || min_channels < 0) return fail(c, D2T_EINVAL, "bad argument");
+  if (min_channels > 0 && min_channels < 256) return fail(c, D2T_EINVAL, "Winograd-domain weights are kept for layers with >= 256 input channels");
+  c->wino_min_channels = min_channels;
+  return D2T_OK;
+}
+
 int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
   DevGuard dg_(c);
   if (!c || chains < 1 || chains > 2) return fail(c, D2T_EINVAL, "decode chains must be 1 or 2");
@@ -2022,7 +2055,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 3 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;
+  if (kind < 0 || kind > 4 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;
@@ -2061,10 +2094,22 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   if (e == hipSuccess) e = launch_split_bf16(wp, whi, wlo, nw, s);
   if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s);
   if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s);
-  if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
+  void* wbuf = nullptr;
+  if (e == hipSuccess && g_op_conv_kind == 4 && wino_applicable(p)) {
+    const size_t nu = (size_t)16 * Cout * Cin * 2, nv = wino_workspace_bytes(B, H, W, Cin);
+    if (hipMalloc(&wbuf, 2 * nu + nv) != hipSuccess) { hipFree(buf); return D2T_ENOMEM; }
+    uint16_t* uh = (uint16_t*)wbuf;
+    uint16_t* ul = (uint16_t*)((char*)wbuf + nu);
+    e = launch_wino_weights(wp, uh, ul, Cout, Cin, s);
+    if (e == hipSuccess) e = launch_conv_winograd(p, uh, ul, (uint16_t*)((char*)wbuf + 2 * nu), s);
+  } else if (e == hipSuccess) {
+    if (g_op_conv_kind == 4) p.pipelined = 3;
+    e = launch_conv_bf16x3(p, s);
+  }
   if (e == hipSuccess) e = launch_merge_act(ys, y, ry, Cout, s);
   hipStreamSynchronize(s);
   hipFree(buf);
+  if (wbuf) hipFree(wbuf);
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 

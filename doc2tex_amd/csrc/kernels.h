@@ -63,6 +63,12 @@ hipError_t launch_conv(const ConvP& p, hipStream_t s);         // fp32 MFMA, or 
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s);
 hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s);  // 256x128 tile, 3 LDS stages, one block per CU
 hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s);  // 128-row LDS-DMA kernel over rows [m_base, M)
+// Winograd F(2x2, 3x3) form of the split-bf16 3x3 / stride 1 / pad 1 convolution (conv_winograd.hip): u_hi / u_lo
+// [16][Cout][Cin] from launch_wino_weights (once per layer, from the packed folded weights), v_ws >= wino_workspace_bytes
+size_t wino_workspace_bytes(int B, int H, int W, int Cin);
+bool wino_applicable(const ConvP& p);
+hipError_t launch_wino_weights(const float* w_packed, uint16_t* u_hi, uint16_t* u_lo, int Cout, int Cin, hipStream_t s);
+hipError_t launch_conv_winograd(const ConvP& p, const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* v_ws, hipStream_t s);
 // hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 

@@ -256,6 +256,11 @@ int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
  * and 16x16 output block): same three products per element in the same order, but the sum inside an MFMA spans 32 k, so
  * results agree with kinds 0-2 to fp32 rounding, not bit for bit; all rows of a layer stay on this kernel. */
 int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
+/* Winograd F(2x2, 3x3) form of the split-bf16 3x3 / stride 1 / pad 1 convolutions (inference; conv_winograd.hip) for the
+ * layers with at least `min_channels` (>= 256) input and output channels; 0 switches it off.  2.25 x fewer matrix
+ * products for 4 x the activation traffic of those layers; results agree with the direct kernels to the accuracy of
+ * the split-bf16 arithmetic (tools/winograd_study.py: tokens exact on every fixture), not bit for bit. */
+int d2t_set_conv_winograd(d2t_ctx* ctx, int32_t min_channels);
 int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
 /* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
  * its own stream, self-attention cache and workspace, so with 2 the step loops of two consecutive batches

@@ -301,3 +301,47 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     e16 = float((y16.permute(0, 3, 1, 2) - ref).abs().max())
     assert e32 <= 4e-4 and e16 <= 4e-4 and e16 <= 1.5 * e32 + 1e-6, (e32, e16)
     assert torch.isfinite(y16).all() and torch.equal(y16[B - 1:], y16_0)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, residual
+    (2, 16, 129, 512, 512, True),    # the dominant layer's geometry (odd width: the last tile column is half outside)
+    (3, 7, 37, 128, 384, True),      # odd height and width, three column tiles
+    (1, 5, 9, 64, 128, False),       # a single block tile, mostly padding
+    (5, 13, 50, 96, 128, False),     # three channel chunks, tiles that straddle images
+])
+def test_winograd_convolution_vs_float64(shape):
+    """The Winograd F(2x2, 3x3) form (conv_winograd.hip; off by default -- DESIGN.md: the numerics hold, the speed does not):
+    input transform, the sixteen split-bf16 GEMMs with the output transform in registers, and the direct kernels' epilogue
+    (bias, residual, ReLU, split records).  As close to float64 as the direct kernel, and a sample's rows do not depend on
+    the batch."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout, use_res = shape
+    x = _rand(B, Cin, H, W, seed=41)
+    w = _rand(Cout, Cin, 3, 3, seed=42, scale=(2.0 / (Cin * 9)) ** 0.5)
+    b = _rand(Cout, seed=43, scale=0.1)
+    res = _rand(B, Cout, H, W, seed=44) if use_res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = b.to(DEV)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
+    out = {}
+    try:
+        for kind in (3, 4):
+            assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
+            y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+            assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
+                                                  Cin, Cout, 3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+            out[kind] = y.cpu()
+        y1 = torch.full((1, H, W, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
+                                              _lib.ptr(y1), 1, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.d2t_op_set_conv_kernel(3, 0)
+    ref = _ref_conv(x, w, b, res, (1, 1), (1, 1), 1)
+    e_direct = float((out[3].permute(0, 3, 1, 2) - ref).abs().max())
+    e_wino = float((out[4].permute(0, 3, 1, 2) - ref).abs().max())
+    assert torch.isfinite(out[4]).all()
+    assert e_wino <= 4e-4 and e_wino <= 3 * e_direct + 1e-6, (e_direct, e_wino)
+    assert torch.equal(out[4][B - 1:], y1.cpu())

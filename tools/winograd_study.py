@@ -94,6 +94,7 @@ def main():
         c = next(q for q in cases["greedy"] if q["case"] == name)
         z = np.load(os.path.join(GOLD, name + ".npz"))
         cfg, sd = oracle_state_dict(c["config"], man[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+        cfg["beam_size"] = c.get("beam_size") or 1  # the greedy fixtures of config C4 were taken with beam_size 1
         img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
         text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
         steps = z["logit_steps"].tolist()
