@@ -854,6 +854,249 @@ __device__ __forceinline__ void conv3x3_patch_body(const ConvP& p, unsigned char
   }
 }
 
+// The patch-resident 3x3 kernel on v_mfma_f32_16x16x32_bf16 (round 3).  With the 16x16x32 build the pipelined kernel above is
+// no longer power-bound: its K-step takes ~2150 cycles against 1536 of MFMA work, and what it waits for are the loader
+// waves -- twelve LDS-DMA pieces per loader and K-step at the 130-180 cycles an LDS-DMA instruction costs its issuing wave
+// (the same limit kept the Winograd form, conv_winograd.hip, from paying off).  Keeping a tile's input patch in LDS for all
+// nine taps cuts that to 23 KB (six pieces per loader) per K-step.  Same structure as conv3x3_patch_body; fragments are the
+// 16 x 32 ones of conv_bf16x3p16_body, patch records are XOR-swizzled with (record & 7) -- conflict-free for the 16-row
+// fragment pattern at ANY tap shift (tools/probe/lds_swizzle_check.py; the 32-row pattern wanted (record >> 1) & 7) --
+// and the stagger splits a K-step by row blocks.  Per output element the same three products per K-step in the same order as
+// conv_bf16x3p16_body: bit-identical to it (tests), so a layer may take either.
+template <bool STG>
+__device__ __forceinline__ void conv3x3_patch16_body(const ConvP& p, unsigned char* smem) {
+  constexpr int BM = 256, BN = 128, WN = 2, NW = 8, NL = 4, NT = (NW + NL) * 64, MI = 4, NJ = 4, MH = 2;
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + QROWS - 1) / QROWS);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool loader = wave >= NW;
+  const int nchunks = p.Cin / 32, KT = 9 * nchunks;
+  const int W1 = p.W + 1;
+  unsigned char* const bst = smem + 2 * QPATCH;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * QROWS;
+    const int n0 = (tile % nt) * BN;
+    if (loader) {
+      const int lw = wave - NW;
+      int a_off[16];
+      unsigned a_ok = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int rec = (lw + 4 * j) * 8 + (lane >> 3);
+        const int g = m0 - W1 + rec;  // input pixel (linear index) held by patch record `rec`
+        const int c = (lane & 7) ^ (rec & 7);
+        a_off[j] = g * p.Cin * 2 + c * 8;
+        if (g >= 0 && g < p.M) a_ok |= 1u << j;
+      }
+      const uint16_t* b_hi[2];
+      const uint16_t* b_lo[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (lw * 2 + j) * 16 + (lane >> 2);
+        const int n = n0 + row;
+        const int c = pswz16(row, lane & 3);
+        b_hi[j] = n < p.Cout ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
+        b_lo[j] = n < p.Cout ? p.w_lo + (size_t)n * p.K + c * 8 : nullptr;
+      }
+      auto issue_b = [&](int kt) {
+        unsigned char* bh = bst + (kt & 1) * QBST;
+        unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int piece = (lw * 2 + j) * 1024;
+          __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bh + piece), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bl + piece), 16, 0, 0);
+        }
+      };
+      auto issue_a = [&](int chunk, int j) {
+        unsigned char* dst = smem + (chunk & 1) * QPATCH + (lw + 4 * j) * 1024;
+        const uint16_t* src = ((a_ok >> j) & 1u) ? p.in_hi + (a_off[j] + chunk * 64) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+      };
+#pragma unroll
+      for (int j = 0; j < 16; ++j) issue_a(0, j);
+      issue_b(0);
+      wait_vm<0>();
+      int chunk = 0, tap = 0;
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        int na = 0;
+        if (kt + 1 < KT) issue_b(kt + 1);
+        if (chunk + 1 < nchunks && tap < 8) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j == 2 * tap || j == 2 * tap + 1) issue_a(chunk + 1, j);
+          na = 2;
+        }
+        if (tap == 7 || na == 0) wait_vm<0>(); else wait_vm<2>();
+        if (++tap == 9) { tap = 0; ++chunk; }
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT, QROWS>(p, smem, m0, n0, tid);
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    unsigned tmask[MI];
+    int rbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * 64 + i * 16 + r;
+      rbase[i] = row + W1;
+      const int m = m0 + row;
+      tmask[i] = 0;
+      if (row < QROWS && m < p.M) {
+        const int rem = m % (p.H * p.W), oh = rem / p.W, ow = rem - oh * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y = oh + t / 3 - 1, x = ow + t % 3 - 1;
+          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tmask[i] |= 1u << t;
+        }
+      }
+    }
+    int offb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wn * 64 + j * 16 + r;
+      offb[j] = row * PROW + pswz16(row, q) * 16;
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto read_b = [&](const unsigned char* bh, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
+      const unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[j]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[j]);
+      }
+    };
+    auto read_a = [&](const unsigned char* patch, int shift, int tap, auto half_c, bf16x8 (&fah)[MH], bf16x8 (&fal)[MH]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i) {
+        const int rec = rbase[half * MH + i] + shift;
+        const int off = rec * 128 + ((q ^ (rec & 7)) << 4);
+        const unsigned keep = ((tmask[half * MH + i] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
+        u4 a = *reinterpret_cast<const u4*>(patch + off), b = *reinterpret_cast<const u4*>(patch + (off ^ 64));
+        a &= keep;
+        b &= keep;
+        fah[i] = __builtin_bit_cast(bf16x8, a);
+        fal[i] = __builtin_bit_cast(bf16x8, b);
+      }
+    };
+    auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          f32x4v c = acc[half * MH + i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
+          acc[half * MH + i][j] = c;
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    const bool late = STG && wave >= NW / 2;
+    int chunk = 0, tap = 0;
+    auto step_refs = [&](const unsigned char*& patch, const unsigned char*& bh, int& shift, int kt) {
+      patch = smem + (chunk & 1) * QPATCH;
+      bh = bst + (kt & 1) * QBST;
+      shift = (tap / 3 - 1) * p.W + (tap % 3 - 1);
+    };
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *patch, *bh;
+        int shift;
+        step_refs(patch, bh, shift, kt);
+        bf16x8 fbh[NJ], fbl[NJ];
+        read_b(bh, fbh, fbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(patch, shift, tap, H0{}, fah, fal);
+          mma(H0{}, fah, fal, fbh, fbl);
+        }
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(patch, shift, tap, H1{}, fah, fal);
+          mma(H1{}, fah, fal, fbh, fbl);
+        }
+        if (++tap == 9) { tap = 0; ++chunk; }
+      }
+    } else {
+      bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
+      auto step = [&](auto carried_c, int kt) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char *patch, *bh;
+        int shift;
+        step_refs(patch, bh, shift, kt);
+        if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(bh, gbh, gbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(patch, shift, tap, H0{}, fah, fal);
+          mma(H0{}, fah, fal, gbh, gbl);
+        }
+        read_a(patch, shift, tap, H1{}, gah, gal);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the next barrier
+        if (++tap == 9) { tap = 0; ++chunk; }
+      };
+      step(H0{}, 0);
+      for (int kt = 1; kt < KT; ++kt) step(H1{}, kt);
+      mma(H1{}, gah, gal, gbh, gbl);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the patches: they become the epilogue's fp32 tile
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = wm * 64 + i * 16 + 4 * q + reg;
+            const int col = (wn * 64 + j * 16 + r) ^ (((row >> 2) & 1) << 5);
+            tile_f[row * BN + col] = acc[i][j][reg];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      epilogue_rows<BM, BN, NT, QROWS>(p, smem, m0, n0, tid);
+    } else {
+      __builtin_amdgcn_s_barrier();
+      ConvP qq = p;  // (the narrow epilogue writes whole wave tiles: mask the eight surplus rows by shrinking M for the last row block)
+      if (m0 + QROWS < qq.M) qq.M = m0 + QROWS;
+      conv_epilogue16<MI, NJ>(qq, acc, m0 + wm * 64, n0 + wn * 64, r, q);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+__global__ __launch_bounds__(768, 3) void conv_bf16x3q16_3x3_patch(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
+  conv3x3_patch16_body<true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3q16_3x3_patch_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
+  conv3x3_patch16_body<true>(p, smem);
+}
+
 __global__ __launch_bounds__(768, 3) void conv_bf16x3q_3x3_patch(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
   conv3x3_patch_body<true>(p, smem);
@@ -957,7 +1200,17 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
     else hipLaunchKernelGGL(conv_bf16x3q_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
     return hipGetLastError();
   }
-  if (p.pipelined == 3) {  // the 16x16x32 build: all rows of a layer on ONE MFMA shape (no hand-over of tail rows to the 32x32x16 kernels)
+  if (p.pipelined == 3 || p.pipelined == 5) {  // the 16x16x32 builds: all rows of a layer on ONE MFMA shape (no hand-over of tail rows to the 32x32x16 kernels)
+    // 5: 3x3 / stride 1 / pad 1 layers on narrow maps take the patch-resident form (half the LDS-DMA pieces per K-step);
+    // bit-identical to the plain 16x16x32 kernel, so the choice never shows in the values
+    if (p.pipelined == 5 && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PH == 1 && p.PW == 1 && p.OH == p.H && p.OW == p.W &&
+        p.W + 1 <= (QREC - QROWS) / 2 && p.Cin % 32 == 0 && p.M >= QROWS) {
+      const int qtiles = ((p.M + QROWS - 1) / QROWS) * nt;
+      if (grid > qtiles) grid = qtiles;
+      if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3q16_3x3_patch_k4608, dim3(grid), dim3(768), 0, s, p2);
+      else hipLaunchKernelGGL(conv_bf16x3q16_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
+      return hipGetLastError();
+    }
     if (grid > tiles) grid = tiles;
     static const int stagger16 = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
     if (!stagger16) hipLaunchKernelGGL(conv_bf16x3p16_256x128, dim3(grid), dim3(768), 0, s, p2);

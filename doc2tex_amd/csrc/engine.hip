@@ -1942,8 +1942,8 @@ int d2t_set_reserved_cus(d2t_ctx* c, int32_t cus) {
 
 int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   DevGuard dg_(c);
-  if (!c || kind < 0 || kind > 3)
-    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) or 3 (pipelined 256x128 on 16x16x32 MFMAs)");
+  if (!c || kind < 0 || kind > 5 || kind == 4)
+    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs) or 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps)");
   c->conv_pipelined = kind;
   return D2T_OK;
 }
@@ -2055,7 +2055,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 4 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
+  if (kind < 0 || kind > 5 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;

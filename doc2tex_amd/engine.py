@@ -291,7 +291,7 @@ class Engine:
     def set_conv_kernel(self, kind):
         """'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs), 'pipelined' (32x32x16 MFMAs),
         'patch' (pipelined + patch-resident 3x3 kernel) or 'classic' (128x128, two blocks per CU)."""
-        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3}[kind]), "set_conv_kernel")
+        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3, "patch16": 5}[kind]), "set_conv_kernel")
 
     def set_conv_winograd(self, min_channels):
         """Winograd F(2x2,3x3) for the 3x3 layers with at least `min_channels` channels on both sides (0 = off)."""

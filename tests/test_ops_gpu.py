@@ -290,8 +290,14 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
         assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
                                               _lib.ptr(y16_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
                                               _lib.stream_of(xd)) == 0
+        # kind 5: the patch-resident 16x16x32 kernel where the layer qualifies -- bit-identical to kind 3
+        assert lib.d2t_op_set_conv_kernel(5, 0) == 0
+        y16p = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16p), B, H, W,
+                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
         torch.cuda.synchronize()
         y16, y16_0 = y16.cpu(), y16_0.cpu()
+        assert torch.equal(y16p.cpu(), y16)
     finally:
         lib.d2t_op_set_conv_kernel(3, 0)
     assert torch.isfinite(outs[0]).all()

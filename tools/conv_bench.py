@@ -39,7 +39,7 @@ for name, B, H, W, Cin, Cout, k, st, pd, use_res in LAYERS:
     res = torch.randn(B, OH, OW, Cout, generator=g).cuda() if use_res else None
     outs = {}
     for rep in range(reps):
-        for kind, rc_ in [(0, 0)] + [(1, r) for r in reserves] + [(3, r) for r in reserves] + [(4, 0)]:
+        for kind, rc_ in [(0, 0)] + [(1, r) for r in reserves] + [(3, r) for r in reserves] + [(4, 0), (5, 0)]:
             assert lib.d2t_op_set_conv_kernel(kind, rc_) == 0
             y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
             t0 = time.perf_counter()
@@ -62,6 +62,7 @@ for name, B, H, W, Cin, Cout, k, st, pd, use_res in LAYERS:
         err[f"p16/reserve{r}"] = float((outs[(3, r)].double() - ref64).abs().max()) / scale
         assert torch.isfinite(outs[(3, r)]).all()
         assert err[f"p16/reserve{r}"] <= 3 * max(err["128x128"], 1e-7), (name, err)
+    assert torch.equal(outs[(5, 0)], outs[(3, reserves[0])]), f"{name}: the patch-resident 16x16x32 kernel must be bit-identical to the plain one"
     err["winograd (3x3 s1 p1) / p16"] = float((outs[(4, 0)].double() - ref64).abs().max()) / scale
     assert torch.isfinite(outs[(4, 0)]).all() and err["winograd (3x3 s1 p1) / p16"] <= 4 * max(err["128x128"], 1e-7), (name, err)
     print(f"{name}: M={B * OH * OW} N={Cout} K={k[0] * k[1] * Cin}  bit-identical to the 128x128 kernel: {same}; "

@@ -51,4 +51,11 @@ ok &= check("A lo 16x16", lambda l, b: (b + (l & 15)) * 128 + aswz(b + (l & 15),
 check("B 16x16 with the 32x32 swizzle (expected to conflict)", lambda l, b: (b + (l & 15)) * 64 + pswz32(b + (l & 15), l >> 4) * 16, range(0, 128, 16))
 ok &= check("B    16x16 pswz16", lambda l, b: (b + (l & 15)) * 64 + pswz16(b + (l & 15), l >> 4) * 16, range(0, 128, 16)) == 1
 print("ok" if ok else "CONFLICTS")
-raise SystemExit(0 if ok else 1)
+
+# patch-resident 3x3 kernel on 16x16x32 fragments: lane -> record (base + lane & 15) for ANY base (the tap shift dy * W + dx is arbitrary),
+# chunk q = lane >> 4 (hi) / 4 + q (lo), XOR-ed with (record >> 1) & 7
+ok2 = True
+for lo in (0, 4):
+    ok2 &= check(f"patch A 16x16 chunk+{lo}, any base", lambda l, b: (b + (l & 15)) * 128 + ((lo + (l >> 4)) ^ (((b + (l & 15)) >> 1) & 7)) * 16, range(0, 300)) == 1
+print("patch ok" if ok2 else "patch CONFLICTS")
+raise SystemExit(0 if ok and ok2 else 1)
