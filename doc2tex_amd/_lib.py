@@ -75,6 +75,7 @@ SIGNATURES = {
     "d2t_set_decode_chains": (_I, [_P, _I]),
     "d2t_set_conv_kernel": (_I, [_P, _I]),
     "d2t_set_conv_winograd": (_I, [_P, _I]),
+    "d2t_set_beam_shared_tile": (_I, [_P, _I]),
     "d2t_set_reserved_cus": (_I, [_P, _I]),
     "d2t_train_forward": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "d2t_train_backward": (_I, [_P, _P, _P]),

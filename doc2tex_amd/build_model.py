@@ -161,6 +161,8 @@ class Model(nn.Module):
         # pipelined serving: compute units the pipelined kernel's grid leaves to the decode streams
         self.conv_kernel = os.environ.get("D2T_CONV_KERNEL_NAME", "pipelined16")
         self.reserved_cus = 0
+        # beam search (TFM, d_model 256, beam <= 6): one cross-attention block per sample for all its hypotheses (default: per row)
+        self.beam_shared_tile = False
         # Winograd F(2x2,3x3) for the 3x3 backbone layers with at least this many channels on both sides (0 = direct only)
         self.conv_winograd = int(os.environ.get("D2T_CONV_WINOGRAD", "0"))
         # pipelined mode: decode loops in flight side by side (1 or 2)
@@ -263,6 +265,9 @@ class Model(nn.Module):
         if getattr(self._engine, "_conv_kernel", None) != self.conv_kernel:
             self._engine.set_conv_kernel(self.conv_kernel)
             self._engine._conv_kernel = self.conv_kernel
+        if getattr(self._engine, "_beam_shared", None) != bool(self.beam_shared_tile):
+            self._engine.set_beam_shared_tile(self.beam_shared_tile)
+            self._engine._beam_shared = bool(self.beam_shared_tile)
         if getattr(self._engine, "_winograd", None) != self.conv_winograd:
             self._engine.set_conv_winograd(self.conv_winograd)
             self._engine._winograd = self.conv_winograd

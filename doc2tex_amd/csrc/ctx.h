@@ -157,6 +157,10 @@ struct d2t_ctx {
   float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
   float* beam_ws = nullptr; size_t beam_ws_cap = 0;  // beam logits / scores / tokens / top-k
+  // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
+  // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
+  int beam_shared_tile = 0;
+  float* beam_qp = nullptr; size_t beam_qp_cap = 0;  // beam, absorbed cross-attention: q' / context rows + LN1 rows (decode.hip)
   float* dws = nullptr; size_t dws_cap = 0;
   int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]
   size_t dstate_cap = 0;

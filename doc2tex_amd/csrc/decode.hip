@@ -730,6 +730,9 @@ struct DecRow2P {
   const float* wk;      // [D][D] cross-attention key projection as stored (rows = output feature h*hd + e)
   const float* wv_t;    // [D (c)][D (o)] value projection, transposed
   const float* bv;      // [D]
+  // beam search (MODE 1 / 2): the row kernel split around the per-SAMPLE cross-attention kernel
+  float* qp;            // [rows][8][D]: MODE 1 writes the absorbed queries, beam_cross_kernel replaces them with the context rows
+  float* x1;            // [rows][D]: LN1 output (the residual of the cross-attention block), MODE 1 -> MODE 2
 };
 
 #ifdef D2T_PROBES
@@ -737,7 +740,9 @@ struct DecRow2P {
 #else
 #define ROW_PROBE(bit) 0
 #endif
-template <int NTH>  // D = 256, 8 heads of 32
+// MODE 0: the whole row step (greedy).  MODE 1: up to the absorbed queries, which go to q.qp (+ x1 to q.x1).  MODE 2: from
+// the context rows in q.qp on (value projection, output projection, residual) -- the two halves around beam_cross_kernel.
+template <int NTH, int MODE>  // D = 256, 8 heads of 32
 __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecRow2P q) {
   constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
   const DecRowP& p = q.r;
@@ -757,6 +762,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   const int b = blockIdx.x;
   const int t = *p.step_ptr;
   const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
+  if (MODE != 2) {
   // ---- self-attention over the cache (as decoder_row_kernel) ----
 #pragma unroll
   for (int hp = 0; hp < (ROW_PROBE(1) ? 0 : HPW); ++hp) {
@@ -825,12 +831,25 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
         accq.x = fmaf(a, w4.x, accq.x); accq.y = fmaf(a, w4.y, accq.y);
         accq.z = fmaf(a, w4.z, accq.z); accq.w = fmaf(a, w4.w, accq.w);
       }
-      *reinterpret_cast<float4*>(qp_s + h * D + ((((c4 >> 2) ^ h)) << 2)) = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
+      const float4 qv = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
+      if (MODE == 1) *reinterpret_cast<float4*>(q.qp + ((size_t)b * 8 + h) * D + c4) = qv;
+      else *reinterpret_cast<float4*>(qp_s + h * D + ((((c4 >> 2) ^ h)) << 2)) = qv;
     }
   }
   __syncthreads();
+  }
+  if (MODE == 1) {
+    if (tid < D) q.x1[(size_t)b * D + tid] = x1_s[tid];
+    return;
+  }
+  if (MODE == 2) {  // the context rows of this hypothesis and its LN1 output come back from global memory
+    for (int idx = tid; idx < 8 * (D / 4); idx += NTH)
+      *reinterpret_cast<float4*>(ctx_s + idx * 4) = *reinterpret_cast<const float4*>(q.qp + (size_t)b * 8 * D + idx * 4);
+    if (tid < D) x1_s[tid] = q.x1[(size_t)b * D + tid];
+    __syncthreads();
+  }
   // ---- cross-attention over the memory rows of this row's sample ----
-  if (!ROW_PROBE(4)) {
+  if (MODE == 0 && !ROW_PROBE(4)) {
     const int cb = p.c_row_map ? p.c_row_map[b] : b;
     float m_run, l_run;
     f32x4 acc[4][4];
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < (ROW_PROBE(4) ? 0 : 8 * (D / 4)); idx += NTH) {  // merge the waves' partial softmaxes (log-sum-exp combine)
+  for (int idx = tid; idx < (MODE != 0 || ROW_PROBE(4) ? 0 : 8 * (D / 4)); idx += NTH) {  // merge the waves' partial softmaxes (log-sum-exp combine)
     const int h = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
     float M = -INFINITY;
 #pragma unroll
@@ -906,10 +925,192 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
 hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
                                        const float* bv, hipStream_t s) {
   if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
-  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv};
+  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, nullptr, nullptr};
   static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
   q.r.probe = probe;
-  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256>), dim3(r.M), dim3(256), 0, s, q);
+  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Beam search: ONE block per SAMPLE runs the cross-attention of all its live hypotheses (north_star's "K/V resident in LDS
+// per wavefront", in the absorbed form: the sample's memory rows are staged in LDS ONCE per layer and step and serve every
+// hypothesis and head; the reference repeats the memory per hypothesis, tfm.py:163, and the per-row kernel re-read it per
+// hypothesis).  M <= 6 hypotheses x 8 heads = up to 48 query rows = three 16-row MFMA tiles (83 % filled at beam 5 against
+// 50 % for a single row).  The four waves work through the key tiles TOGETHER: a ring of four 16 KB tile buffers with the
+// LDS-DMA three tiles ahead; per tile wave w multiplies channel quarter w of the tile with the same slice of every q' row
+// (the A fragment is read once for all row tiles), the partial score tiles are summed through LDS, each wave runs the online
+// softmax of all rows and accumulates channel quarter w of the weighted memory rows.  (For ONE row this cooperative form
+// lost to independent waves -- two block barriers per tile; with three row tiles per barrier pair it is the better split,
+// and it needs no merge.)  In: q.qp = absorbed queries [rows][8][256] (from decoder_row_absorbed_kernel MODE 1); out: the
+// normalised context rows in their place.
+struct BeamCrossP {
+  const float* mem; long long mem_stride; int T;
+  float* qp;            // [rows][8][256]
+  const int* seg;       // [samples][3]: first row, live hypotheses, (unused) per sample; nullptr: one sample, rows [0, M)
+  int M;                // seg == nullptr: live hypotheses
+  const int* step_ptr; const int* stop_at;
+};
+
+__global__ __launch_bounds__(256, 1) void beam_cross_kernel(const BeamCrossP p) {
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;
+  constexpr int NR = 3, D = 256;
+  int off = 0, M = p.M;
+  if (p.seg) { off = p.seg[blockIdx.x * 3]; M = p.seg[blockIdx.x * 3 + 1]; }
+  if (M <= 0) return;  // block-uniform (a finished sample)
+  decode_wave_priority();
+  __shared__ __attribute__((aligned(1024))) unsigned char stage[4 * 16384];
+  __shared__ __attribute__((aligned(1024))) float qp_s[NR * 16 * D];
+  __shared__ __attribute__((aligned(16))) float part[4 * 16 * NR * 16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, g = lane >> 4;
+  const int R = 8 * M, nrt = (R + 15) >> 4;
+  const float* mem = p.mem + (size_t)blockIdx.x * p.mem_stride;
+  float* qrows = p.qp + (size_t)off * 8 * D;
+  for (int idx = tid; idx < nrt * 16 * (D / 4); idx += 256) {  // q' rows, 16-byte chunks of row r XOR-ed with r & 15; rows >= R zero
+    const int row = idx / (D / 4), c4 = idx % (D / 4);
+    const float4 v = row < R ? *reinterpret_cast<const float4*>(qrows + (size_t)row * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(qp_s + row * D + ((c4 ^ (row & 15)) << 2)) = v;
+  }
+  float m_run[NR], l_run[NR];
+  f32x4 acc[NR][4];
+#pragma unroll
+  for (int rt = 0; rt < NR; ++rt) {
+    m_run[rt] = -INFINITY;
+    l_run[rt] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[rt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int T = p.T, ntiles = (T + 15) >> 4;
+  auto issue = [&](int tile) {  // this wave's four rows of the tile: row i -> buffer + i * 1024, physical chunk c holds logical c ^ i
+    unsigned char* buf = stage + (tile & 3) * 16384;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = wave * 4 + k;
+      const int j = (tile << 4) + i < T ? (tile << 4) + i : T - 1;  // rows past the end: a valid row, its probability is forced to zero
+      __builtin_amdgcn_global_load_lds(mem + (size_t)j * D + ((lane ^ i) << 2), (lds_ptr_dec)(buf + i * 1024), 16, 0, 0);
+    }
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the q' loads above are done: from here on vmcnt counts tile pieces only
+  issue(0);
+  if (ntiles > 1) issue(1);
+  if (ntiles > 2) issue(2);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int j0 = tile << 4;
+    const int ahead = ntiles - 1 - tile;  // block-uniform
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the tile has landed for everyone (and, at tile 0, the q' rows are in LDS); nobody reads tile - 1 any more
+    if (tile + 3 < ntiles) issue(tile + 3);
+    const unsigned char* buf = stage + (tile & 3) * 16384;
+    // ---- partial S^T[key = 4g' + reg][row = 16 rt + col] over this wave's channel quarter ----
+    f32x4 sacc[NR];
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) sacc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+      const int u = wave * 4 + uu;
+      const float4 a4 = *reinterpret_cast<const float4*>(buf + col * 1024 + (((4 * u + g) ^ col) << 4));
+#pragma unroll
+      for (int rt = 0; rt < NR; ++rt) {
+        if (rt < nrt) {
+          const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(qp_s) + (rt * 16 + col) * 1024 +
+                                                              (((4 * u + g) ^ col) << 4));
+          sacc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, q4.x, sacc[rt], 0, 0, 0);
+          sacc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, q4.y, sacc[rt], 0, 0, 0);
+          sacc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, q4.z, sacc[rt], 0, 0, 0);
+          sacc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, q4.w, sacc[rt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt)
+      if (rt < nrt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) part[(wave * 16 + 4 * g + reg) * (NR * 16) + rt * 16 + col] = sacc[rt][reg];
+      }
+    __syncthreads();
+    // ---- online softmax of every row (all waves, identically): this lane holds keys j0 + 4g + reg of row 16 rt + col ----
+    float pv[NR][4];
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) {
+      if (rt < nrt) {
+        float sv[4], mx = -INFINITY;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = (4 * g + reg) * (NR * 16) + rt * 16 + col;
+          const float sc = (part[o] + part[16 * NR * 16 + o]) + (part[2 * 16 * NR * 16 + o] + part[3 * 16 * NR * 16 + o]);
+          sv[reg] = (j0 + 4 * g + reg < T) ? sc : -INFINITY;
+          mx = fmaxf(mx, sv[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[rt], mx);
+        const float alpha = expf(m_run[rt] - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          pv[rt][reg] = expf(sv[reg] - m_new);
+          ps += pv[rt][reg];
+        }
+        l_run[rt] = l_run[rt] * alpha + ps;
+        m_run[rt] = m_new;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {  // the accumulators hold ctx[row 16 rt + 4g + reg]: lane 4g + reg has that row's alpha
+          const float ar = __shfl(alpha, 4 * g + reg, 64);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[rt][e][reg] *= ar;
+        }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) pv[rt][reg] = 0.f;
+      }
+    }
+    // ---- ctx[row][64 wave + 4 col + e] += sum_keys P[row][key] m[key][chan]; k-step sk <-> keys 4g + sk ----
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {
+      const int key = 4 * g + sk;
+      const float4 b4 = *reinterpret_cast<const float4*>(buf + key * 1024 + (((16 * wave + col) ^ key) << 4));
+#pragma unroll
+      for (int rt = 0; rt < NR; ++rt)
+        if (rt < nrt) {
+          acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[rt][sk], b4.x, acc[rt][0], 0, 0, 0);
+          acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[rt][sk], b4.y, acc[rt][1], 0, 0, 0);
+          acc[rt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[rt][sk], b4.z, acc[rt][2], 0, 0, 0);
+          acc[rt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[rt][sk], b4.w, acc[rt][3], 0, 0, 0);
+        }
+    }
+  }
+  // ---- normalise and hand the context rows back in the queries' place ----
+#pragma unroll
+  for (int rt = 0; rt < NR; ++rt) {
+    if (rt < nrt) {
+      float l = l_run[rt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float inv = 1.f / __shfl(l, 4 * g + reg, 64);  // lane 4g + reg holds the denominator of row 16 rt + 4g + reg
+        const int row = rt * 16 + 4 * g + reg;
+        if (row < R)
+          *reinterpret_cast<float4*>(qrows + (size_t)row * D + 64 * wave + 4 * col) =
+              make_float4(acc[rt][0][reg] * inv, acc[rt][1][reg] * inv, acc[rt][2][reg] * inv, acc[rt][3][reg] * inv);
+      }
+    }
+  }
+}
+
+// one beam step of a layer's row work: pre (per hypothesis) -> cross (per sample) -> post (per hypothesis).
+// seg / nsamples: the samples' row segments (batched beam), or nullptr / 1 for a single sample whose rows are [0, r.M).
+hipError_t launch_decoder_row_beam(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
+                                   const float* bv, float* qp, float* x1, const int* seg, int nsamples, hipStream_t s) {
+  if (r.heads != 8 || r.D != 256 || r.T < 1 || !qp || !x1 || nsamples < 1) return hipErrorInvalidValue;
+  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, qp, x1};
+  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 1>), dim3(r.M), dim3(256), 0, s, q);
+  BeamCrossP c{mem, mem_stride, r.T, qp, seg, r.M, r.step_ptr, r.stop_at};
+  hipLaunchKernelGGL(beam_cross_kernel, dim3(nsamples), dim3(256), 0, s, c);
+  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 2>), dim3(r.M), dim3(256), 0, s, q);
   return hipGetLastError();
 }
 

@@ -356,6 +356,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->skv_alt) hipFree(c->skv_alt);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->wino_ws) hipFree(c->wino_ws);
+  if (c->beam_qp) hipFree(c->beam_qp);
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -905,6 +906,8 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   const size_t per = (size_t)B * (8 * d + 3 * d + g.dec_ff);
   if ((rc = ensure(c, &c->dws, &c->dws_cap, per * 4))) return rc;
   if ((rc = ensure(c, &c->dstate, &c->dstate_cap, (size_t)(4 + B + GRP_WORDS) * 4))) return rc;
+  // beam search, absorbed form: absorbed queries / context rows [B][8][d] and LN1 outputs [B][d] between the row kernel's halves
+  if (c->dec_absorbed && (rc = ensure(c, &c->beam_qp, &c->beam_qp_cap, (size_t)B * 9 * d * 4))) return rc;
   float* p = c->dws;
   float** six[] = {&bufs->x, &bufs->y1, &bufs->x1, &bufs->y2, &bufs->x2, &bufs->y3, &bufs->q2, &bufs->a};
   for (float** q : six) { *q = p; p += (size_t)B * d; }
@@ -959,9 +962,11 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 //   | [LN2] ff1+ReLU GEMM | ff2+res GEMM
 // All position-dependent values come from the device step counter (graph-replayable).
 // shared_mem: cross K/V of sample 0 shared by every row (beam search over one sample).
+// beam > 0 (beam search with at most 6 hypotheses per sample, absorbed form): the row work runs as pre / per-SAMPLE cross /
+// post (launch_decoder_row_beam) with the samples' row segments in `seg` (nullptr: one sample, rows [0, M)).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
                        float* logits, long long logit_row_stride, long long logit_step_stride, int ckvB = -1,
-                       const int* row_map = nullptr, const int* stop = nullptr) {
+                       const int* row_map = nullptr, const int* stop = nullptr, int beam = 0, const int* seg = nullptr) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
@@ -990,7 +995,10 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
     r.trace = trace_slot(c);
     r.stop_at = stop;
-    if (c->dec_absorbed) TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s));
+    if (c->dec_absorbed && c->beam_shared_tile && beam > 0 && beam <= 6 && c->beam_qp && (shared_mem || row_map))
+      TRY(launch_decoder_row_beam(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, c->beam_qp,
+                                  c->beam_qp + (size_t)kvB * 8 * d, seg, shared_mem ? 1 : ckvB, s));
+    else if (c->dec_absorbed) TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s));
     else TRY(launch_decoder_row(r, s));
     TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c), stop, step));
     TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c), stop, step));
@@ -1720,7 +1728,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
     BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)M * 8, hipMemcpyHostToDevice, s));
     BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)M * 4, hipMemcpyHostToDevice, s));
     BCHK(launch_embed_tokens(c->word_embed, c->word_pe, d_tok, c->dstate, bf.x, M, d, s));
-    BCHK(decode_step(c, s, bf, M, T, cap, true, d_logits, V, 0));
+    BCHK(decode_step(c, s, bf, M, T, cap, true, d_logits, V, 0, -1, nullptr, nullptr, beam_size));
     const int live = beam_size - (int)completed.size();
     BCHK(launch_beam_topk(d_logits, d_scores, M, V, live, d_topv, d_topi, s));
     BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)live * 4, hipMemcpyDeviceToHost, s));
@@ -1856,7 +1864,7 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
     BCHK(hipMemcpyAsync(d_map, h_map, (size_t)rows * 4, hipMemcpyHostToDevice, s));
     BCHK(hipMemcpyAsync(d_seg, h_seg, (size_t)N * 12, hipMemcpyHostToDevice, s));
     BCHK(launch_embed_tokens(c->word_embed, c->word_pe, d_tok, c->dstate, bf.x, rows, d, s));
-    BCHK(decode_step(c, s, bf, rows, T, cap, false, d_logits, V, 0, N, d_map));
+    BCHK(decode_step(c, s, bf, rows, T, cap, false, d_logits, V, 0, N, d_map, nullptr, beam_size, d_seg));
     BCHK(launch_beam_topk_batch(d_logits, d_scores, d_seg, N, V, beam_size, d_topv, d_topi, s));
     BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
     BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
@@ -1945,6 +1953,13 @@ int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   if (!c || kind < 0 || kind > 5 || kind == 4)
     return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs) or 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps)");
   c->conv_pipelined = kind;
+  return D2T_OK;
+}
+
+int d2t_set_beam_shared_tile(d2t_ctx* c, int32_t on) {
+  DevGuard dg_(c);
+  if (!c) return D2T_EINVAL;
+  c->beam_shared_tile = on != 0;
   return D2T_OK;
 }
 

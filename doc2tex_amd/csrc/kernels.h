@@ -226,6 +226,11 @@ hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 // mem [samples][T][256] (row b attends over sample c_row_map[b] or b), wk [256][256] as stored, wv_t [c][o], bv [256]
 hipError_t launch_decoder_row_absorbed(const DecRowP& p, const float* mem, long long mem_stride, const float* wk,
                                        const float* wv_t, const float* bv, hipStream_t s);
+// beam search (at most 6 live hypotheses per sample): the row step split around ONE cross-attention block per sample that
+// stages the sample's memory tiles once for all its hypotheses; qp [rows][8][256] and x1 [rows][256] are scratch;
+// seg [nsamples][3] = (first row, live hypotheses, -) per sample, or nullptr / 1 for a single sample (rows [0, p.M))
+hipError_t launch_decoder_row_beam(const DecRowP& p, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
+                                   const float* bv, float* qp, float* x1, const int* seg, int nsamples, hipStream_t s);
 hipError_t launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t s);  // dst[c][r] = src[r][c]
 
 // x[b] = emb[tok]*sqrt(d) + pe[t];  tok = (t == 0) ? start[b] : tokens[b*tok_stride + t - 1]

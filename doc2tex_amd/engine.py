@@ -293,6 +293,10 @@ class Engine:
         'patch' (pipelined + patch-resident 3x3 kernel) or 'classic' (128x128, two blocks per CU)."""
         self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3, "patch16": 5}[kind]), "set_conv_kernel")
 
+    def set_beam_shared_tile(self, on):
+        """Beam search: one cross-attention block per sample serving all its hypotheses from one staged memory tile (beam <= 6)."""
+        self._check(self.lib.d2t_set_beam_shared_tile(self.ctx, int(bool(on))), "set_beam_shared_tile")
+
     def set_conv_winograd(self, min_channels):
         """Winograd F(2x2,3x3) for the 3x3 layers with at least `min_channels` channels on both sides (0 = off)."""
         self._check(self.lib.d2t_set_conv_winograd(self.ctx, int(min_channels)), "set_conv_winograd")

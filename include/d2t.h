@@ -261,6 +261,10 @@ int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
  * products for 4 x the activation traffic of those layers; results agree with the direct kernels to the accuracy of
  * the split-bf16 arithmetic (tools/winograd_study.py: tokens exact on every fixture), not bit for bit. */
 int d2t_set_conv_winograd(d2t_ctx* ctx, int32_t min_channels);
+/* Beam search of the d_model-256 TFM decoder, cross-attention: 0 (default) one block per hypothesis row, each reading its
+ * sample's memory rows; 1: one block per SAMPLE that stages the sample's memory tiles in LDS once per layer and step for
+ * all its live hypotheses (beam <= 6; decode.hip beam_cross_kernel).  Same results to fp32 summation order. */
+int d2t_set_beam_shared_tile(d2t_ctx* ctx, int32_t on);
 int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
 /* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
  * its own stream, self-attention cache and workspace, so with 2 the step loops of two consecutive batches

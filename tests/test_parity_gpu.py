@@ -312,6 +312,33 @@ def test_config_c4_batched_beam_at_full_size(cases):
             assert len({len(b[0][0]) for b in batch}) > 1  # both kinds of sample present (checked with the oracle: rows 24 / 31)
 
 
+def test_beam_with_one_cross_attention_block_per_sample(cases):
+    """Model.beam_shared_tile: the cross-attention of all live hypotheses of a sample in ONE block that stages the sample's
+    memory tiles once per layer and step (north_star's LDS-resident K/V, in the absorbed form).  Same sequences as the
+    per-row path on the reference fixtures (single-sample API) and in the batched API, scores within the beam bar."""
+    for name in ("t2_beam5", "c2_beam5", "c4_beam5_96"):
+        c = _case(cases, "beam", name)
+        cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c["beam_size"])
+        m.beam_shared_tile = True
+        img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"]).cuda()
+        text = torch.full((1, 1), R.GO, dtype=torch.long, device="cuda")
+        with torch.no_grad():
+            seq, score, _ = m(img, text, is_train=False, is_test=True)
+        assert seq[0].tolist() == c["seq"], (name, seq, c["seq"])
+        assert abs(score - c["score"]) <= max(1e-3, 2e-5 * len(c["seq"]))
+    c = _case(cases, "beam", "t2_beam5")
+    for eb, beam in [(1.8, 5), (1.75, 3), (0.0, 6)]:
+        cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], eb, beam_size=beam)
+        img = synth.synth_images(7, c["H"], c["W"], seed=c["iseed"]).cuda()
+        with torch.no_grad():
+            ref = m.beam_search_batch(img)
+            m.beam_shared_tile = True
+            got = m.beam_search_batch(img)
+        for (s1, v1), (s2, v2) in zip(ref, got):
+            assert torch.equal(s1, s2), (eb, beam)
+            assert abs(v1 - v2) <= max(1e-3, 2e-5 * s1.shape[1])
+
+
 def test_batched_attn_beam_equals_per_sample_beam(cases):
     """The same for the LSTM-attention head (Attnv2 on the ViT encoder, Attn on VGG + BiLSTM)."""
     for cname, H, W, L, eb, beam in [("TS0", 48, 64, 14, 0.3, 5), ("TS0", 48, 64, 8, 0.0, 3), ("C0", 32, 320, 12, 0.17, 4)]:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] on one GPU: HybridViT + TFM-6, beam width 5, 160x640 crops.  The encoder runs on the whole
 shard at once, beam search per sample (the reference's forward_beam is single-sample, tfm.py:146-148).
-usage: beam_bench.py [n_samples] [beam]"""
+usage: beam_bench.py [n_samples] [beam] [batched|both] [shared]"""
 import os
 import sys
 import time
@@ -13,11 +13,13 @@ from doc2tex_amd import Model, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 beam = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+only_batched = len(sys.argv) > 3 and sys.argv[3] == "batched"
 cfg = synth.make_config("C4", device="cuda", beam_size=beam)
 H, W = synth.crop_shape("C4")
 m = Model(cfg)
 m.load_state_dict(synth.synth_state_dict({k: v for k, v in m.state_dict().items()}), strict=False)
 m = m.cuda().eval()
+m.beam_shared_tile = len(sys.argv) > 4 and sys.argv[4] == "shared"
 img = synth.synth_images(n, H, W, seed=11).cuda()
 go = torch.ones(1, 1, dtype=torch.long, device="cuda")
 
@@ -34,6 +36,8 @@ def run_batched():
 
 
 for name, fn in (("per sample (reference API)", run), ("batched (Model.beam_search_batch)", run_batched)):
+    if only_batched and fn is run:
+        continue
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
