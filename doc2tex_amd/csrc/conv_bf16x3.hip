@@ -304,8 +304,8 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
     a_off[j] = 0;
     a_mask[j] = 0;
     if (m < p.M) {
-      const int b = m / ohow, rem = m - b * ohow;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      int b, oh, ow;
+      conv_row_coords(p, m, b, oh, ow);
       const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
       a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cin * 2 + c * 8;
       for (int kh = 0; kh < p.KH; ++kh)
@@ -410,7 +410,8 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
   }
   if (wide_epilogue_ok(p)) {  // block-uniform
     static_assert(BM * BN * 4 <= 2 * STAGE, "the fp32 tile must fit in the staging area");
-    conv_epilogue_wide<BM, BN, NW * 64, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+    if (p.pool2) conv_epilogue_wide_pool<BM, BN, NW * 64, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
+    else conv_epilogue_wide<BM, BN, NW * 64, MI, NJ>(p, acc, smem, m0, n0, wm * WTM, wn * WTN, r, h, tid);
   } else {
     conv_epilogue<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, h);
   }
@@ -450,6 +451,12 @@ hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s) {
 
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0) return hipSuccess;
+  if (p.pool2) {  // fused 2x2 max-pool: split-record LDS-DMA kernels with the wide epilogue only (g body, 16x16x32 pipelined body)
+    const bool wide = p.store_mode == STORE_ROWS && p.rows_per_img == 0 && !p.row_add && (p.Cout & 31) == 0;
+    if (!p.in_hi || !wide || p.res || p.res_hi || (p.M & 3) || p.M != 4 * p.B * (p.OH / 2) * (p.OW / 2) ||
+        (p.Cout >= 128 && p.pipelined != 3) || (p.Cout > 64 && p.Cout < 128))
+      return hipErrorInvalidValue;
+  }
   if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin || p.m_base != 0) return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes

@@ -113,6 +113,60 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
   }
 }
 
+// The fused 2x2 max-pool form of epilogue_rows (ConvP::pool2): tile rows 4r .. 4r+3 are one pooling window (pooled row order of
+// the GEMM's rows); a thread owns eight channels of one POOLED row.  max, then bias, then activation -- the pool of the
+// activated outputs, bit for bit (both monotone); no residual (the layers in front of a pool have none).
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void epilogue_rows_pool(const ConvP& p, const unsigned char* smem, int m0, int n0, int tid) {
+  const float* tile = reinterpret_cast<const float*>(smem);
+  constexpr int OPR = BN / 8;
+  const float* __restrict__ bias = p.bias;
+  uint16_t* __restrict__ out_hi = p.out_hi;
+  float* __restrict__ out = p.out;
+  for (int idx = tid; idx < (BM / 4) * OPR; idx += NT) {
+    const int pr = idx / OPR, o = idx % OPR;
+    const int m = m0 + 4 * pr, n = n0 + o * 8;
+    if (m >= p.M || n >= p.Cout) continue;
+    const int col = (o * 8) ^ ((pr & 1) << 5);  // rows 4 pr .. 4 pr + 3 share (row >> 2) & 1 = pr & 1
+    float v[8];
+    {
+      const float4 a0 = *reinterpret_cast<const float4*>(tile + (4 * pr) * BN + col);
+      const float4 a1 = *reinterpret_cast<const float4*>(tile + (4 * pr) * BN + col + 4);
+      v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+    }
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 a0 = *reinterpret_cast<const float4*>(tile + (4 * pr + k) * BN + col);
+      const float4 a1 = *reinterpret_cast<const float4*>(tile + (4 * pr + k) * BN + col + 4);
+      v[0] = fmaxf(v[0], a0.x), v[1] = fmaxf(v[1], a0.y), v[2] = fmaxf(v[2], a0.z), v[3] = fmaxf(v[3], a0.w);
+      v[4] = fmaxf(v[4], a1.x), v[5] = fmaxf(v[5], a1.y), v[6] = fmaxf(v[6], a1.z), v[7] = fmaxf(v[7], a1.w);
+    }
+    if (bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + n), b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+      v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w, v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+    const size_t mp = (size_t)(m >> 2);
+    const size_t pi = plane_idx(mp, n, p.Cout);
+    if (out_hi) {
+      uint16_t hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint4 oh, ol;
+      oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      oh.z = (unsigned)hi[4] | ((unsigned)hi[5] << 16), oh.w = (unsigned)hi[6] | ((unsigned)hi[7] << 16);
+      ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+      ol.z = (unsigned)lo[4] | ((unsigned)lo[5] << 16), ol.w = (unsigned)lo[6] | ((unsigned)lo[7] << 16);
+      *reinterpret_cast<uint4*>(out_hi + pi) = oh;
+      *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;
+    } else {
+      *reinterpret_cast<float4*>(out + mp * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + mp * p.Cout + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 // Element-wise epilogue of one wave's MI x NJ grid of 16x16 accumulators (the layers the wide epilogue does not take: row
 // remap, positional add, Cout % 32 != 0): same arithmetic per element as conv_epilogue.
 template <int MI, int NJ>
@@ -193,8 +247,8 @@ struct DmaIssuer {
       a_off[j] = 0;
       a_mask[j] = 0;
       if (m < p.M) {
-        const int b = m / ohow, rem = m - b * ohow;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int b, oh, ow;
+        conv_row_coords(p, m, b, oh, ow);
         const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
         a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cin * 2 + c * 8;
         for (int y = 0; y < p.KH; ++y)
@@ -486,7 +540,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_barrier();
-      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      if (wide_epilogue_ok(p)) { if (p.pool2) epilogue_rows_pool<BM, BN, NT>(p, smem, m0, n0, tid); else epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid); }
       __builtin_amdgcn_s_barrier();
       continue;
     }
@@ -600,7 +654,8 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      if (p.pool2) epilogue_rows_pool<BM, BN, NT>(p, smem, m0, n0, tid);
+      else epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
     } else {
       __builtin_amdgcn_s_barrier();
       conv_epilogue16<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, q);

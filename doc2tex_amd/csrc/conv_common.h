@@ -28,6 +28,23 @@ __device__ __forceinline__ size_t plane_idx(size_t row, int c, int C) {
   return (row * C + (size_t)(c & ~31)) * 2 + (c & 31);
 }
 
+// GEMM row m -> output pixel (b, oh, ow): row-major, or pooled order when a 2x2 max-pool is fused (ConvP::pool2)
+__device__ __forceinline__ void conv_row_coords(const ConvP& p, int m, int& b, int& oh, int& ow) {
+  if (p.pool2) {
+    const int q = m >> 2, sb = m & 3, pw2 = p.OW >> 1, ph2 = p.OH >> 1;
+    const int t = q / pw2;
+    ow = 2 * (q - t * pw2) + (sb & 1);
+    b = t / ph2;
+    oh = 2 * (t - b * ph2) + (sb >> 1);
+  } else {
+    const int ohow = p.OH * p.OW;
+    b = m / ohow;
+    const int rem = m - b * ohow;
+    oh = rem / p.OW;
+    ow = rem - oh * p.OW;
+  }
+}
+
 // XCD-aware tile order: consecutive logical tiles (same A rows, neighbouring pixels) run on the
 // same XCD so they share its L2 (bijective remap, cdna guide T1).
 __device__ __forceinline__ int xcd_logical_tile() {
@@ -163,6 +180,60 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvP& p, f32x16 (&acc)
     }
   }
   __syncthreads();  // the tile is staging memory again (next tile's LDS-DMA)
+}
+
+// The fused 2x2 max-pool form (ConvP::pool2): tile rows 4r .. 4r+3 are one pooling window; a thread owns four channels of one
+// POOLED row.  max, then bias, then activation = the pool of the activated convolution outputs (both monotone), bit for bit.
+template <int BM, int BN, int NT, int MI, int NJ>
+__device__ __forceinline__ void conv_epilogue_wide_pool(const ConvP& p, f32x16 (&acc)[MI][NJ], unsigned char* smem, int m0, int n0,
+                                                        int wrow, int wcol, int r, int h, int tid) {
+  float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wrow + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int col = (wcol + j * 32 + r) ^ (((row >> 2) & 1) << 5);
+        tile[row * BN + col] = acc[i][j][reg];
+      }
+  __syncthreads();
+  constexpr int QPR = BN / 4;
+  for (int idx = tid; idx < (BM / 4) * QPR; idx += NT) {
+    const int pr = idx / QPR, q = idx % QPR;
+    const int m = m0 + 4 * pr, n = n0 + q * 4;
+    if (m >= p.M || n >= p.Cout) continue;
+    const int col = (q * 4) ^ ((pr & 1) << 5);  // rows 4 pr .. 4 pr + 3 share (row >> 2) & 1 = pr & 1
+    float4 a = *reinterpret_cast<const float4*>(tile + (4 * pr) * BN + col);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(tile + (4 * pr + k) * BN + col);
+      a.x = fmaxf(a.x, t.x); a.y = fmaxf(a.y, t.y); a.z = fmaxf(a.z, t.z); a.w = fmaxf(a.w, t.w);
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x, v[1] += b.y, v[2] += b.z, v[3] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    const size_t mp = (size_t)(m >> 2);
+    const size_t pi = plane_idx(mp, n, p.Cout);
+    if (p.out_hi) {
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      uint2 oh, ol;
+      oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
+      ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
+      *reinterpret_cast<uint2*>(p.out_hi + pi) = oh;
+      *reinterpret_cast<uint2*>(p.out_hi + pi + 32) = ol;
+    } else {
+      *reinterpret_cast<float4*>(p.out + mp * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();
 }
 
 // The same with the row remap (rows_per_img), the positional-table add and the head-split K/V store, for the kernels whose

@@ -160,6 +160,7 @@ struct d2t_ctx {
   // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
   // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
   int beam_shared_tile = 0;
+  int no_pool_fusion = 0;  // debug / A-B: 1 = the two 2x2 max-pools as their own kernels (D2T_NO_POOL_FUSION at context creation)
   float* beam_qp = nullptr; size_t beam_qp_cap = 0;  // beam, absorbed cross-attention: q' / context rows + LN1 rows (decode.hip)
   float* dws = nullptr; size_t dws_cap = 0;
   int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]

@@ -113,8 +113,9 @@ hipError_t conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) {
 
 // One convolution of the backbone.  `res` may be nullptr; `out_split` asks for split-bf16 output planes
 // (only meaningful on the bf16x3 path; the consumer must be another bf16x3 convolution or the split pool).
+// pool2: fuse the 2x2 / stride 2 max-pool that follows (split-record path only: see ConvP::pool2); y is then the POOLED map.
 Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& w, int sh, int sw, int ph, int pw,
-         int act, const Act* res, float* outbuf, const ConvP* extra = nullptr, bool out_split = false) {
+         int act, const Act* res, float* outbuf, const ConvP* extra = nullptr, bool out_split = false, bool pool2 = false) {
   Act y{outbuf, x.B, (x.H + 2 * ph - w.KH) / sh + 1, (x.W + 2 * pw - w.KW) / sw + 1, w.Cout};
   y.split = out_split;
   ConvP p{};
@@ -130,6 +131,12 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
   p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
+  if (pool2) {  // rows in pooled order (floor: a last odd row / column belongs to no window and is never computed)
+    p.pool2 = 1;
+    p.M = 4 * y.B * (y.H / 2) * (y.W / 2);
+    y.H /= 2;
+    y.W /= 2;
+  }
   hipError_t e;
   if (c->conv_bf16x3 && c->wino_min_channels > 0 && w.u_hi && x.C >= c->wino_min_channels && w.Cout >= c->wino_min_channels &&
       wino_applicable(p)) {
@@ -193,7 +200,10 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   x.split = sp;
   if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s));
   else HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
-  x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
+  // the two 2x2 / stride 2 max-pools (resnet.py:94,106) run inside the epilogue of the convolution in front of them on the
+  // split-record path with the 16x16x32 kernels: conv0_2 writes 268 MB instead of 1.07 GB and no pool kernel re-reads it
+  const bool fuse_pool = sp && c->conv_pipelined == 3 && !c->no_pool_fusion;
+  x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, fuse_pool);
   auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
     Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
     y.split = a.split;
@@ -221,10 +231,11 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
     const int rc = ensure(c, &c->gc_ws, &c->gc_ws_cap, ((size_t)B * (H / 2) * (W / 2) + 2 * (size_t)B * 512 + 64) * 4);
     if (rc) return rc;
   }
-  x = pool(x, 2, 2, 0, 0);
+  if (!fuse_pool) x = pool(x, 2, 2, 0, 0);
   stage(0);
-  x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
-  x = pool(x, 2, 2, 0, 0);
+  const bool fuse_pool2 = fuse_pool && c->conv1.Cout >= 128;  // (the pipelined 16x16x32 kernel takes layers with >= 128 channels)
+  x = conv(c, s, &err, x, c->conv1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, fuse_pool2);
+  if (!fuse_pool2) x = pool(x, 2, 2, 0, 0);
   stage(1);
   x = conv(c, s, &err, x, c->conv2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = pool(x, 2, 1, 0, 1);
@@ -322,6 +333,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
   if (const char* e = getenv("D2T_CONV_KERNEL")) c->conv_pipelined = atoi(e) != 0;
+  if (const char* e = getenv("D2T_NO_POOL_FUSION")) c->no_pool_fusion = atoi(e) != 0;  // results are bit-identical either way
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;

@@ -42,6 +42,11 @@ struct ConvP {
   int wave_prio;         // pipelined kernel: s_setprio of its waves (experiments; 0 = default)
   int pipelined;         // != 0: take the pipelined 256x128 kernel (conv_bf16x3p.hip) when the layer qualifies
   int split_tail;        // pipelined kernel: hand the rows of a sparsely filled last round of tiles to the 128-row kernel
+  // != 0: a 2x2 / stride 2 max-pool (resnet.py:94,106) fused into the epilogue of the split-record LDS-DMA kernels
+  // (conv_bf16x3g_body, conv_bf16x3p16_body): the GEMM's rows are the convolution's output pixels in POOLED ORDER --
+  // row m = 4 * pooled pixel + (oh & 1) * 2 + (ow & 1), M = 4 * B * (OH / 2) * (OW / 2) -- and the wide epilogue writes one
+  // record row per four tile rows (their maximum) at the pooled pixel.  Needs the wide epilogue (no remap, no residual).
+  int pool2;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation

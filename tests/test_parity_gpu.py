@@ -555,6 +555,34 @@ def test_odd_crop_shapes_and_batch_sizes(manifests, cname, H, W, B, precision):
     assert float((logits.cpu() - ologits).abs().max()) <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("cname,H,W,B", [("T2", 48, 64, 3), ("T2", 45, 63, 2), ("T1", 63, 130, 2), ("C2", 128, 512, 2)])
+def test_fused_max_pools_equal_the_pool_kernels(monkeypatch, cname, H, W, B):
+    """The two 2x2 / stride 2 max-pools of the backbone (resnet.py:94,106) run inside the epilogue of the convolution in
+    front of them (pooled-order GEMM rows, ConvP::pool2).  Every pooled VALUE equals the separate pool kernel's
+    (D2T_NO_POOL_FUSION=1 at context creation): max and the fp32 -> (hi, lo) split are both monotone.  The stored record
+    can differ in representation only -- where lo rounds up to the next hi step the pool kernel re-splits hi + lo as
+    (hi', 0) while the fused epilogue keeps (hi, lo) -- which moves a consumer's products by the dropped lo*lo term
+    (2^-16 relative): tokens equal, memory and logits within 1e-5.  Odd crop sizes (a last row / column that belongs to
+    no window) included."""
+    L = 6
+    img = synth.synth_images(B, H, W, seed=4200 + H).cuda()
+    text = torch.full((B, 1), R.GO, dtype=torch.long, device="cuda")
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("D2T_NO_POOL_FUSION", off)
+        cfg, m = engine_model(cname, L)
+        with torch.no_grad():
+            mem, _, _ = m.forward_encoder(img)
+            p, l, _ = m(img, text, is_train=False)
+        torch.cuda.synchronize()
+        outs.append((mem.cpu(), p.cpu(), l.cpu()))
+    assert torch.isfinite(outs[0][0]).all()
+    scale = max(1.0, float(outs[1][0].abs().max()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-5 * scale
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5 * max(1.0, float(outs[1][2].abs().max()))
+
+
 def test_error_paths_raise_instead_of_crashing():
     """Misuse is reported through status codes / Python exceptions (the library never aborts): a crop larger than the
     positional table, a CPU tensor, a wrong channel count, a missing weight, a second backward without a forward."""
