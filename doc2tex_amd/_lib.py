@@ -95,6 +95,7 @@ SIGNATURES = {
     "d2t_op_conv2d": (_I, [_P] * 5 + [_I] * 12 + [_P]),
     "d2t_op_conv2d_bf16x3": (_I, [_P] * 5 + [_I] * 12 + [_P]),
     "d2t_op_conv2d_bf16x3_split": (_I, [_P] * 5 + [_I] * 12 + [_P]),
+    "d2t_op_conv2d_bf16x3_split_pool": (_I, [_P] * 4 + [_I] * 12 + [_P]),
     "d2t_op_set_conv_kernel": (_I, [_I, _I]),
     "d2t_op_linear": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "d2t_op_maxpool2x2": (_I, [_P, _P] + [_I] * 8 + [_P]),

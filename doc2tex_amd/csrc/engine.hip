@@ -2140,6 +2140,51 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
+int d2t_op_conv2d_bf16x3_split_pool(const float* x, const float* w, const float* bias, float* y,
+                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                               int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream) {
+  // test entry for the fused 2x2 / stride 2 max-pool (ConvP::pool2): y is the POOLED map [B][OH/2][OW/2][Cout]
+  const float* residual = nullptr;
+  if (!x || !w || !y || SH < 1 || SW < 1 || Cin % 32 || Cout % 32 || (Cout > 64 && Cout < 128)) return D2T_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int OH = (H + 2 * PH - KH) / SH + 1, OW = (W + 2 * PW - KW) / SW + 1;
+  const size_t nw = (size_t)Cout * KH * KW * Cin, rx = (size_t)B * H * W, ry = (size_t)B * OH * OW;
+  const size_t nx = rx * Cin, ny = ry * Cout;
+  void* buf = nullptr;
+  const size_t bytes = nw * 4 + nw * 4 + nx * 4 + ny * 4 + (residual ? ny * 4 : 0) + 256;
+  if (hipMalloc(&buf, bytes) != hipSuccess) return D2T_ENOMEM;
+  char* q = (char*)buf;
+  float* wp = (float*)q; q += nw * 4;
+  uint16_t* whi = (uint16_t*)q; q += nw * 2;
+  uint16_t* wlo = (uint16_t*)q; q += nw * 2;
+  uint16_t* xs = (uint16_t*)q; q += nx * 4;
+  uint16_t* ys = (uint16_t*)q; q += ny * 4;
+  uint16_t* rs = nullptr;
+  if (residual) { rs = (uint16_t*)q; q += ny * 4; }
+  void* zero = q;
+  ConvP p{};
+  p.w = wp; p.w_hi = whi; p.w_lo = wlo; p.bias = bias;
+  p.in_hi = xs; p.out_hi = ys; p.res_hi = rs; p.zero16 = zero;
+  p.reserved_cus = g_op_reserved_cus;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
+  p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
+  p.M = 4 * B * (OH / 2) * (OW / 2); p.K = KH * KW * Cin; p.act = act;
+  p.pool2 = 1; p.pipelined = 3;
+  const size_t rp = (size_t)B * (OH / 2) * (OW / 2);
+  hipError_t e = hipMemsetAsync(zero, 0, 256, s);
+  if (e == hipSuccess) e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
+  if (e == hipSuccess) e = launch_split_bf16(wp, whi, wlo, nw, s);
+  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s);
+  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s);
+  void* wbuf = nullptr;
+  if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
+  if (e == hipSuccess) e = launch_merge_act(ys, y, rp, Cout, s);
+  hipStreamSynchronize(s);
+  hipFree(buf);
+  if (wbuf) hipFree(wbuf);
+  return e == hipSuccess ? D2T_OK : D2T_EHIP;
+}
+
 int d2t_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int32_t M,
                   int32_t K, int32_t N, int32_t act, d2t_stream stream) {
   if (!x || !w || !y || K % 16) return D2T_EINVAL;

@@ -349,6 +349,11 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 /* which split-bf16 kernel d2t_op_conv2d_bf16x3_split launches (d2t_set_conv_kernel / d2t_set_reserved_cus of a context,
  * but process-wide: tests and tools only) */
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus);
+/* the same with the 2x2 / stride 2 max-pool that follows fused into the epilogue (ConvP::pool2; no residual): y is the pooled
+ * map [B][OH/2][OW/2][Cout].  Layers with <= 64 or >= 128 output channels (the two kernels that carry the fused form). */
+int d2t_op_conv2d_bf16x3_split_pool(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
+                                    int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t PH,
+                                    int32_t PW, int32_t act, d2t_stream stream);
 int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
                                int32_t SH, int32_t SW, int32_t PH, int32_t PW, int32_t act, d2t_stream stream);

@@ -310,6 +310,39 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
 
 
 @pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout
+    (2, 64, 96, 32, 64),      # conv0_2's kernel (128x64 tile, Cout = 64)
+    (3, 33, 47, 32, 64),      # odd height and width: the last row / column belongs to no window
+    (2, 32, 64, 64, 128),     # conv1's kernel (pipelined 16x16x32, Cout = 128)
+    (1, 45, 63, 128, 256),    # odd sizes, two column tiles
+])
+def test_convolution_with_the_max_pool_fused(shape):
+    """ConvP::pool2: the 2x2 / stride 2 max-pool inside the convolution's epilogue (pooled-order GEMM rows).  Every pooled
+    VALUE equals max_pool2d of the unfused kernel's output exactly (max and the (hi, lo) split are monotone), and float64."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout = shape
+    x = _rand(B, Cin, H, W, seed=51)
+    w = _rand(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
+    b = _rand(Cout, seed=53, scale=0.1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = b.to(DEV)
+    full = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+    pooled = torch.full((B, H // 2, W // 2, Cout), float("nan"), device=DEV)
+    assert lib.d2t_op_set_conv_kernel(3, 0) == 0
+    assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), None, _lib.ptr(full), B, H, W, Cin, Cout,
+                                          3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+    assert lib.d2t_op_conv2d_bf16x3_split_pool(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(pooled), B, H, W, Cin, Cout,
+                                               3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+    torch.cuda.synchronize()
+    want = torch.nn.functional.max_pool2d(full.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.isfinite(pooled).all()
+    assert torch.equal(pooled, want), float((pooled - want).abs().max())
+    ref = torch.nn.functional.max_pool2d(_ref_conv(x, w, b, None, (1, 1), (1, 1), 1), 2, 2)
+    assert float((pooled.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= 4e-4
+
+
+@pytest.mark.parametrize("shape", [
     # B, H, W, Cin, Cout, residual
     (2, 16, 129, 512, 512, True),    # the dominant layer's geometry (odd width: the last tile column is half outside)
     (3, 7, 37, 128, 384, True),      # odd height and width, three column tiles
