@@ -33,7 +33,6 @@ struct RawW {
 struct ConvW {
   float* w = nullptr;
   uint16_t *w_hi = nullptr, *w_lo = nullptr;  // bf16 split of w for the bf16x3 kernel
-  uint16_t *u_hi = nullptr, *u_lo = nullptr;  // Winograd-domain weights [16][Cout][Cin] (3x3 layers the Winograd kernel takes)
   float* bias = nullptr;
   int Cout = 0, Cin = 0, KH = 0, KW = 0;
 };
@@ -143,6 +142,7 @@ struct d2t_ctx {
   // (d2t_set_conv_winograd; 0 = off): workspace for the transformed input tiles
   int wino_min_channels = 0;
   float* wino_ws = nullptr; size_t wino_ws_cap = 0;
+  std::map<const float*, std::pair<uint16_t*, uint16_t*>> wino_u;  // Winograd-domain weights [16][Cout][Cin] per layer, made on first use
   hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
   bool ev_done_valid[2] = {false, false};
   unsigned decode_seq = 0;

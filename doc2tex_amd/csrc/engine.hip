@@ -35,16 +35,6 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
     out->w_hi = (uint16_t*)ph;
     out->w_lo = (uint16_t*)pl;
     HIPCHK(c, launch_split_bf16(out->w, out->w_hi, out->w_lo, w->numel, s));
-    if (out->KH == 3 && out->KW == 3 && out->Cout % 32 == 0 && out->Cin >= 256) {  // Winograd-domain copy (16 / 9 of the weights)
-      void *uh, *ul;
-      const size_t nu = (size_t)16 * out->Cout * out->Cin;
-      if ((rc = dev_alloc(c, &uh, nu * 2)) || (rc = dev_alloc(c, &ul, nu * 2))) return rc;
-      c->owned.push_back(uh);
-      c->owned.push_back(ul);
-      out->u_hi = (uint16_t*)uh;
-      out->u_lo = (uint16_t*)ul;
-      HIPCHK(c, launch_wino_weights(out->w, out->u_hi, out->u_lo, out->Cout, out->Cin, s));
-    }
   }
   return D2T_OK;
 }
@@ -83,6 +73,7 @@ int get_ln(d2t_ctx* c, const std::string& k, LNW* out, int D) {
 void free_packed(d2t_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   c->owned.clear();
+  c->wino_u.clear();
   for (int i = 0; i < 4; ++i) c->layers[i].clear();
   c->vit.clear();
   c->dec.clear();
@@ -138,15 +129,27 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
     y.W /= 2;
   }
   hipError_t e;
-  if (c->conv_bf16x3 && c->wino_min_channels > 0 && w.u_hi && x.C >= c->wino_min_channels && w.Cout >= c->wino_min_channels &&
-      wino_applicable(p)) {
-    // Winograd form (same ProfRec shape as the direct kernel: the bench rates it in direct-convolution FLOPs)
+  if (c->conv_bf16x3 && c->wino_min_channels > 0 && w.w_hi && w.KH == 3 && w.KW == 3 && x.C >= c->wino_min_channels &&
+      w.Cout >= c->wino_min_channels && wino_applicable(p)) {
+    // Winograd form (same ProfRec shape as the direct kernel: the bench rates it in direct-convolution FLOPs).  The
+    // Winograd-domain weights (16 / 9 of the layer's) are made on first use and live until the weights are re-packed.
+    auto it = c->wino_u.find(w.w);
+    if (it == c->wino_u.end()) {
+      void *uh = nullptr, *ul = nullptr;
+      const size_t nu = (size_t)16 * w.Cout * w.Cin;
+      if (dev_alloc(c, &uh, nu * 2) || dev_alloc(c, &ul, nu * 2)) { if (*err == hipSuccess) *err = hipErrorOutOfMemory; return y; }
+      c->owned.push_back(uh);
+      c->owned.push_back(ul);
+      hipError_t we = launch_wino_weights(w.w, (uint16_t*)uh, (uint16_t*)ul, w.Cout, w.Cin, s);
+      if (we != hipSuccess && *err == hipSuccess) *err = we;
+      it = c->wino_u.emplace(w.w, std::make_pair((uint16_t*)uh, (uint16_t*)ul)).first;
+    }
     if (ensure(c, &c->wino_ws, &c->wino_ws_cap, wino_workspace_bytes(x.B, x.H, x.W, x.C))) e = hipErrorOutOfMemory;
     else {
       d2t_ctx::ProfRec r{p.M, p.Cout, p.K, nullptr, nullptr};
       const bool prof = c->profiling && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
       if (prof) hipEventRecord(r.a, s);
-      e = launch_conv_winograd(p, w.u_hi, w.u_lo, reinterpret_cast<uint16_t*>(c->wino_ws), s);
+      e = launch_conv_winograd(p, it->second.first, it->second.second, reinterpret_cast<uint16_t*>(c->wino_ws), s);
       if (prof) { hipEventRecord(r.b, s); c->prof.push_back(r); }
     }
   } else {

@@ -99,8 +99,8 @@ pool_grids = [int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) for r in row
 FIRST_POOL_GRID = max(pool_grids) if pool_grids else 1 << 60
 stem = {}
 for key, match in (("stem_split_kernel (conv0_1 + BN + ReLU, 1 -> 32 channels @128x512)", lambda n, r: "stem_split_kernel" in n),
-                   ("conv_bf16x3g_128x64 (conv0_2, 32 -> 64 channels @128x512)", lambda n, r: "conv_bf16x3g_128x64" in n),
-                   ("maxpool_split_kernel, first pool (64 channels 128x512 -> 64x256)", first_pool)):
+                   ("conv_bf16x3g_128x64 (conv0_2, 32 -> 64 channels @128x512, with the first 2x2 max-pool in its epilogue since round 3)", lambda n, r: "conv_bf16x3g_128x64" in n),
+                   ("maxpool_split_kernel, largest pool launch of a forward (round 3: the third pool, k2 s(2,1) p(0,1), 256 channels 32x128 -> 16x129; the first two are fused into conv0_2 / conv1)", first_pool)):
     tr = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows("trace", "*kernel_trace.csv")
           if match(r["Kernel_Name"], r)]
     fv, nf = per_kernel("pmc_fetch", "FETCH_SIZE", match)
