@@ -457,7 +457,11 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
         (p.Cout >= 128 && p.pipelined != 3) || (p.Cout > 64 && p.Cout < 128))
       return hipErrorInvalidValue;
   }
-  if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin || p.m_base != 0) return hipErrorInvalidValue;
+  if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin + p.Cin2 || p.m_base != 0) return hipErrorInvalidValue;
+  // a second (1x1) input along K: the DMA issuer of the pipelined 16x16x32 kernel only (no tail hand-over, not the patch forms)
+  if (p.Cin2 && (!p.in_hi || !p.in2_hi || p.Cin2 % XBK || p.Cout < 128 || p.pipelined != 3 || p.pool2 ||
+                 p.OH != p.H || p.OW != p.W))
+    return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes
     if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;

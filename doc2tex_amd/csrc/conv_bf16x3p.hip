@@ -229,6 +229,7 @@ struct DmaIssuer {
   static_assert(AJ >= 1 && BJ >= 1, "tile too small for the issuing waves");
   static_assert(PER_STEP <= 31, "two K-steps of pieces must fit the 6-bit vmcnt");
   int a_off[AJ];
+  int a_off2[AJ];  // second input (ConvP::in2_hi): element offset of this lane's chunk of the row's first record, -1 = no row
   unsigned a_mask[AJ];
   const uint16_t* b_hi[BJ];
   const uint16_t* b_lo[BJ];
@@ -245,8 +246,10 @@ struct DmaIssuer {
       const int c = aswz(row, lane & 7);  // the chunk of the record that belongs at LDS position lane & 7 of this row
       const int m = m0 + row;
       a_off[j] = 0;
+      a_off2[j] = -1;
       a_mask[j] = 0;
       if (m < p.M) {
+        if (p.Cin2) a_off2[j] = m * p.Cin2 * 2 + c * 8;
         int b, oh, ow;
         conv_row_coords(p, m, b, oh, ow);
         const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
@@ -272,12 +275,14 @@ struct DmaIssuer {
     unsigned char* bh = ah + 2 * PLANE_A;
     unsigned char* bl = bh + PLANE_B;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+    const bool second = c0 >= p.Cin;  // the K-steps behind the filter taps: the 1x1 second input (wave-uniform)
     const int tap = kh * p.KW + kw;
-    const int tapoff = ((kh * p.W + kw) * p.Cin + c0) * 2;
+    const int tapoff = second ? (c0 - p.Cin) * 2 : ((kh * p.W + kw) * p.Cin + c0) * 2;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const bool ok = (a_mask[j] >> tap) & 1u;
-      const uint16_t* src = ok ? p.in_hi + (a_off[j] + tapoff) : zero;
+      const uint16_t* src;
+      if (second) src = a_off2[j] >= 0 ? p.in2_hi + (a_off2[j] + tapoff) : zero;
+      else src = ((a_mask[j] >> tap) & 1u) ? p.in_hi + (a_off[j] + tapoff) : zero;
       const int piece = (lw * AJ + j) * 1024;
       if (ABL == 1) continue;
       __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(ah + piece), 16, 0, 0);
@@ -289,7 +294,9 @@ struct DmaIssuer {
       __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bh + piece), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bl + piece), 16, 0, 0);
     }
-    if (++kw == p.KW) {
+    if (second) {
+      c0 += 32;
+    } else if (++kw == p.KW) {
       kw = 0;
       if (++kh == p.KH) { kh = 0; c0 += 32; }
     }

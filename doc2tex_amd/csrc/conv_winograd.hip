@@ -356,7 +356,7 @@ size_t wino_workspace_bytes(int B, int H, int W, int Cin) {
 bool wino_applicable(const ConvP& p) {
   return p.in_hi && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PH == 1 && p.PW == 1 && p.OH == p.H && p.OW == p.W &&
          p.Cin % 32 == 0 && p.Cout % 32 == 0 && p.store_mode == STORE_ROWS && p.rows_per_img == 0 && !p.row_add && p.m_base == 0 &&
-         !p.pool2;
+         !p.pool2 && !p.Cin2;
 }
 
 hipError_t launch_conv_winograd(const ConvP& p, const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* v_ws, hipStream_t s) {

@@ -63,6 +63,9 @@ struct DecLayer {
 struct Block {
   ConvW c1, c2, down;
   bool has_down = false;
+  // blocks with a 1x1 shortcut: conv2 and the shortcut as ONE GEMM -- weights [Cout][9 Cmid + Cin] (K rows concatenated), bias
+  // b2 + b_down -- for the pipelined split-record kernel (ConvP::in2_hi); w == nullptr when the block has no shortcut
+  ConvW c2cat;
 };
 struct BiLstmW {
   float* wih_cat = nullptr;   // [2*4H][in]  forward rows then reverse rows
@@ -160,6 +163,7 @@ struct d2t_ctx {
   // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
   // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
   int beam_shared_tile = 0;
+  int no_shortcut_fusion = 0;  // debug / A-B: 1 = the 1x1 shortcuts as their own kernels (D2T_NO_SHORTCUT_FUSION at context creation)
   int no_pool_fusion = 0;  // debug / A-B: 1 = the two 2x2 max-pools as their own kernels (D2T_NO_POOL_FUSION at context creation)
   float* beam_qp = nullptr; size_t beam_qp_cap = 0;  // beam, absorbed cross-attention: q' / context rows + LN1 rows (decode.hip)
   float* dws = nullptr; size_t dws_cap = 0;

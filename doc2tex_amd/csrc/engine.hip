@@ -121,7 +121,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   }
   p.B = x.B; p.H = x.H; p.W = x.W; p.Cin = x.C; p.OH = y.H; p.OW = y.W; p.Cout = w.Cout;
   p.KH = w.KH; p.KW = w.KW; p.SH = sh; p.SW = sw; p.PH = ph; p.PW = pw;
-  p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C; p.act = act;
+  p.M = y.B * y.H * y.W; p.K = w.KH * w.KW * x.C + p.Cin2; p.act = act;  // (Cin2: a second 1x1 input from `extra`)
   if (pool2) {  // rows in pooled order (floor: a last odd row / column belongs to no window and is never computed)
     p.pool2 = 1;
     p.M = 4 * y.B * (y.H / 2) * (y.W / 2);
@@ -218,6 +218,14 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   auto stage = [&](int li) {
     for (const Block& b : c->layers[li]) {
       Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
+      if (b.has_down && b.c2cat.w && sp && c->conv_pipelined == 3 && b.c2.Cout >= 128 && !c->no_shortcut_fusion) {
+        // the 1x1 shortcut inside conv2's launch: K-steps over x appended behind the taps over t, one accumulator, no residual
+        ConvP ex{};
+        ex.in2_hi = x.planes();
+        ex.Cin2 = x.C;
+        x = conv(c, s, &err, t, b.c2cat, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p, t.p}), &ex, sp);
+        continue;
+      }
       Act r = x;
       if (b.has_down) r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}), nullptr, sp);
       x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &r, pick(c, {x.p, t.p, r.p}), nullptr, sp);
@@ -336,7 +344,8 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
   if (const char* e = getenv("D2T_CONV_KERNEL")) c->conv_pipelined = atoi(e) != 0;
-  if (const char* e = getenv("D2T_NO_POOL_FUSION")) c->no_pool_fusion = atoi(e) != 0;  // results are bit-identical either way
+  if (const char* e = getenv("D2T_NO_POOL_FUSION")) c->no_pool_fusion = atoi(e) != 0;  // (values equal either way)
+  if (const char* e = getenv("D2T_NO_SHORTCUT_FUSION")) c->no_shortcut_fusion = atoi(e) != 0;
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
@@ -455,6 +464,25 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
       if (find(c, p + ".downsample.0.weight")) {
         b.has_down = true;
         if ((rc = pack_conv(c, p + ".downsample.0", p + ".downsample.1", &b.down, s))) return rc;
+        if (b.c2.w_hi && b.down.w_hi && b.down.KH == 1 && b.down.KW == 1 && b.down.Cout == b.c2.Cout) {
+          // conv2 | shortcut concatenated along K (both already folded and in the kernels' K order: a 1x1 layer's is plain)
+          const int Co = b.c2.Cout, K2 = b.c2.KH * b.c2.KW * b.c2.Cin, Kd = b.down.Cin;
+          void *pw, *pb, *ph, *pl;
+          const size_t n = (size_t)Co * (K2 + Kd);
+          if ((rc = dev_alloc(c, &pw, n * 4)) || (rc = dev_alloc(c, &pb, (size_t)Co * 4)) || (rc = dev_alloc(c, &ph, n * 2)) ||
+              (rc = dev_alloc(c, &pl, n * 2)))
+            return rc;
+          for (void* q : {pw, pb, ph, pl}) c->owned.push_back(q);
+          b.c2cat = b.c2;
+          b.c2cat.w = (float*)pw; b.c2cat.bias = (float*)pb; b.c2cat.w_hi = (uint16_t*)ph; b.c2cat.w_lo = (uint16_t*)pl;
+          HIPCHK(c, hipMemcpy2DAsync(pw, (size_t)(K2 + Kd) * 4, b.c2.w, (size_t)K2 * 4, (size_t)K2 * 4, Co, hipMemcpyDeviceToDevice, s));
+          HIPCHK(c, hipMemcpy2DAsync((float*)pw + K2, (size_t)(K2 + Kd) * 4, b.down.w, (size_t)Kd * 4, (size_t)Kd * 4, Co,
+                                     hipMemcpyDeviceToDevice, s));
+          HIPCHK(c, launch_add_rows(b.c2.bias, b.down.bias, b.c2cat.bias, Co, s));
+          HIPCHK(c, launch_split_bf16(b.c2cat.w, b.c2cat.w_hi, b.c2cat.w_lo, n, s));
+        } else {
+          b.c2cat.w = nullptr;
+        }
       }
       c->layers[li].push_back(b);
     }

@@ -47,6 +47,12 @@ struct ConvP {
   // row m = 4 * pooled pixel + (oh & 1) * 2 + (ow & 1), M = 4 * B * (OH / 2) * (OW / 2) -- and the wide epilogue writes one
   // record row per four tile rows (their maximum) at the pooled pixel.  Needs the wide epilogue (no remap, no residual).
   int pool2;
+  // second input of the pipelined split-record kernels (conv_bf16x3p.hip DmaIssuer): a 1x1 / stride 1 convolution over
+  // `in2_hi` (split records [M][Cin2], the same pixels as the output) appended along K -- K = KH*KW*Cin + Cin2, the
+  // weights' K rows concatenated.  A BasicBlock's shortcut (resnet.py:181-192) computed inside its conv2's launch:
+  // conv2(t) + downsample(x) in ONE accumulator, no shortcut kernel, no residual round trip.
+  const uint16_t* in2_hi;
+  int Cin2;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation

@@ -586,6 +586,32 @@ def test_fused_max_pools_equal_the_pool_kernels(monkeypatch, cname, H, W, B):
     assert float((outs[0][2] - outs[1][2]).abs().max()) <= 5e-4
 
 
+@pytest.mark.parametrize("cname,H,W,B", [("T2", 48, 64, 3), ("T1", 63, 130, 2), ("C2", 128, 512, 2)])
+def test_shortcut_inside_conv2_equals_the_separate_shortcut_kernel(monkeypatch, cname, H, W, B):
+    """A BasicBlock's 1x1 shortcut (resnet.py:181-192) runs inside its conv2's launch: K-steps over the block input appended
+    behind the filter taps, weights concatenated along K, ONE accumulator (ConvP::in2_hi).  Against the path with its own
+    shortcut kernel and a residual add in the epilogue (D2T_NO_SHORTCUT_FUSION=1): the same sums in another order, and no
+    rounding of the shortcut to a record in between -- tokens equal, memory within 1e-4 relative, logits within 5e-4."""
+    L = 6
+    img = synth.synth_images(B, H, W, seed=4300 + H).cuda()
+    text = torch.full((B, 1), R.GO, dtype=torch.long, device="cuda")
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("D2T_NO_SHORTCUT_FUSION", off)
+        cfg, m = engine_model(cname, L)
+        with torch.no_grad():
+            mem, _, _ = m.forward_encoder(img)
+            p, l, _ = m(img, text, is_train=False)
+        torch.cuda.synchronize()
+        outs.append((mem.cpu(), p.cpu(), l.cpu()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert not torch.equal(outs[0][0], outs[1][0])  # (the two paths really differ: otherwise the switch is dead)
+    scale = max(1.0, float(outs[1][0].abs().max()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * scale
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 5e-4
+
+
 def test_error_paths_raise_instead_of_crashing():
     """Misuse is reported through status codes / Python exceptions (the library never aborts): a crop larger than the
     positional table, a CPU tensor, a wrong channel count, a missing weight, a second backward without a forward."""
