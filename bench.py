@@ -549,7 +549,7 @@ def main():
                     help="Winograd F(2x2,3x3) for the 3x3 layers with at least this many channels (0 = off)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
-    ap.add_argument("--chains", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--chains", type=int, default=3, choices=[1, 2, 3, 4],
                     help="pipelined mode: decode loops in flight side by side")
     ap.add_argument("--group", type=int, default=0,
                     help="pipelined mode: decode the rows of this many consecutive batches in one step loop "

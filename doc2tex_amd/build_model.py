@@ -165,7 +165,7 @@ class Model(nn.Module):
         self.beam_shared_tile = False
         # Winograd F(2x2,3x3) for the 3x3 backbone layers with at least this many channels on both sides (0 = direct only)
         self.conv_winograd = int(os.environ.get("D2T_CONV_WINOGRAD", "0"))
-        # pipelined mode: decode loops in flight side by side (1 or 2)
+        # pipelined mode: decode loops in flight side by side (1 .. 4)
         self.decode_chains = 1
         # pipelined mode: decode the rows of this many consecutive forward() calls in ONE step loop.  The decode step is a
         # chain of small latency-bound kernels whose duration barely depends on the row count, so two batches per loop halve

@@ -136,7 +136,8 @@ struct d2t_ctx {
   size_t act_cap = 0;
   std::map<std::pair<int, int>, float*> pe2d;  // PositionalEncoding2D crops [h*w][C]
   // decoder state
-  float* ckv2[2] = {nullptr, nullptr}; size_t ckv2_cap[2] = {0, 0};  // cross K/V, double-buffered across decodes
+  static constexpr int MAXC = 4;                                     // decode chains / memory slots at most
+  float* ckv2[MAXC] = {}; size_t ckv2_cap[MAXC] = {};                // memory copy (or projected cross K/V) per slot: a decode reads one
   float* ckv = nullptr;                                              // the slot the current decode reads
   // d_model 256 / 8 heads: the decode attends over the encoder memory itself (absorbed K / V projections); the slots then
   // hold a COPY OF THE MEMORY [B][T][d] instead of the projected K / V of every layer [layers*2][B][heads][T][hd]
@@ -146,8 +147,8 @@ struct d2t_ctx {
   int wino_min_channels = 0;
   float* wino_ws = nullptr; size_t wino_ws_cap = 0;
   std::map<const float*, std::pair<uint16_t*, uint16_t*>> wino_u;  // Winograd-domain weights [16][Cout][Cin] per layer, made on first use
-  hipEvent_t ev_done[2] = {nullptr, nullptr};                        // decode that used slot i has finished
-  bool ev_done_valid[2] = {false, false};
+  hipEvent_t ev_done[MAXC] = {};                                     // decode that used slot i has finished
+  bool ev_done_valid[MAXC] = {};
   unsigned decode_seq = 0;
   // serving tickets: every asynchronous decode gets the next ticket and records ticket_ev[ticket % N] on its decode stream
   // when its outputs are complete (d2t_decode_last_ticket / d2t_decode_wait_ticket / d2t_decode_query)
@@ -174,10 +175,10 @@ struct d2t_ctx {
   hipStream_t dstream = nullptr;
   // Second decode chain (own stream, self-attention cache, workspace, state): with two chains the decode
   // loops of consecutive async batches run side by side.  The members above are the ACTIVE chain; the
-  // inactive one is parked here (select_chain swaps them).
+  // inactive ones are parked here (select_chain swaps).
   struct Chain { hipStream_t stream = nullptr; float* skv = nullptr; size_t skv_cap = 0; float* dws = nullptr;
                  size_t dws_cap = 0; int* dstate = nullptr; size_t dstate_cap = 0;
-                 float* out = nullptr; size_t out_cap = 0; } parked;
+                 float* out = nullptr; size_t out_cap = 0; } chains[MAXC];  // chains[active_chain] is stale: its state lives in the members above
   // async decodes write tokens / logits here (fixed addresses, so one captured graph per chain serves every
   // caller buffer) and copy them out afterwards
   float* dout = nullptr; size_t dout_cap = 0;

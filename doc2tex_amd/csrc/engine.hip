@@ -351,10 +351,11 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(c, hipStreamCreateWithPriority(&c->dstream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
-    HIPCHK(c, hipStreamCreateWithPriority(&c->parked.stream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
+    for (int i = 1; i < d2t_ctx::MAXC; ++i)
+      HIPCHK(c, hipStreamCreateWithPriority(&c->chains[i].stream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
   }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-  for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+  for (int i = 0; i < d2t_ctx::MAXC; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault));
   HIPCHK(c, hipMalloc(&c->zero_page, 256));
   HIPCHK(c, hipMemset(c->zero_page, 0, 256));
@@ -372,7 +373,7 @@ void d2t_destroy(d2t_ctx* c) {
   for (auto& kv : c->raw) hipFree(kv.second.p);
   for (auto& kv : c->pe2d) hipFree(kv.second);
   for (int i = 0; i < 4; ++i) if (c->act[i]) hipFree(c->act[i]);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < d2t_ctx::MAXC; ++i) {
     if (c->ckv2[i]) hipFree(c->ckv2[i]);
     if (c->ev_done[i]) hipEventDestroy(c->ev_done[i]);
   }
@@ -390,12 +391,16 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->h_steps) hipHostFree(c->h_steps);
   for (hipEvent_t ev : c->ticket_ev) if (ev) hipEventDestroy(ev);
   if (c->dstream) hipStreamDestroy(c->dstream);
-  if (c->parked.skv) hipFree(c->parked.skv);
-  if (c->parked.dws) hipFree(c->parked.dws);
-  if (c->parked.dstate) hipFree(c->parked.dstate);
-  if (c->parked.out) hipFree(c->parked.out);
   if (c->dout) hipFree(c->dout);
-  if (c->parked.stream) hipStreamDestroy(c->parked.stream);
+  for (int i = 0; i < d2t_ctx::MAXC; ++i) {
+    if (i == c->active_chain) continue;  // (the active chain's buffers are the members freed around here)
+    d2t_ctx::Chain& o = c->chains[i];
+    if (o.skv) hipFree(o.skv);
+    if (o.dws) hipFree(o.dws);
+    if (o.dstate) hipFree(o.dstate);
+    if (o.out) hipFree(o.out);
+    if (o.stream) hipStreamDestroy(o.stream);
+  }
   delete c;
 }
 
@@ -930,20 +935,29 @@ struct DecBufs {
 // make chain i the active one (c->dstream / skv / dws / dstate)
 void select_chain(d2t_ctx* c, int i) {
   if (c->active_chain == i) return;
-  d2t_ctx::Chain cur{c->dstream, c->skv, c->skv_cap, c->dws, c->dws_cap, c->dstate, c->dstate_cap, c->dout, c->dout_cap};
-  const d2t_ctx::Chain& o = c->parked;
+  c->chains[c->active_chain] = d2t_ctx::Chain{c->dstream, c->skv, c->skv_cap, c->dws, c->dws_cap, c->dstate, c->dstate_cap, c->dout, c->dout_cap};
+  const d2t_ctx::Chain& o = c->chains[i];
   c->dstream = o.stream; c->skv = o.skv; c->skv_cap = o.skv_cap; c->dws = o.dws; c->dws_cap = o.dws_cap;
   c->dstate = o.dstate; c->dstate_cap = o.dstate_cap; c->dout = o.out; c->dout_cap = o.out_cap;
-  c->parked = cur;
   c->active_chain = i;
+}
+
+// every decode stream has drained (the active chain's stream lives in c->dstream)
+hipError_t sync_chains(d2t_ctx* c) {
+  hipError_t e = hipStreamSynchronize(c->dstream);
+  for (int i = 0; i < d2t_ctx::MAXC && e == hipSuccess; ++i)
+    if (i != c->active_chain && c->chains[i].stream) e = hipStreamSynchronize(c->chains[i].stream);
+  return e;
 }
 
 int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, Lmax = g.max_seq_len + 2;
   int rc;
-  for (int i = 0; i < 2; ++i)
-    if ((rc = ensure(c, &c->ckv2[i], &c->ckv2_cap[i], (size_t)g.dec_layers * 2 * B * T * d * 4))) return rc;
+  // a slot holds the encoder memory copy [B][T][d] (absorbed cross-attention) or the projected K/V of every layer
+  const size_t slot_bytes = c->dec_absorbed ? (size_t)B * T * d * 4 : (size_t)g.dec_layers * 2 * B * T * d * 4;
+  for (int i = 0; i < (c->n_chains > 2 ? c->n_chains : 2); ++i)
+    if ((rc = ensure(c, &c->ckv2[i], &c->ckv2_cap[i], slot_bytes))) return rc;
   if (!c->ckv) c->ckv = c->ckv2[0];
   if ((rc = ensure(c, &c->skv, &c->skv_cap, (size_t)g.dec_layers * 2 * B * Lmax * d * 4))) return rc;
   const size_t per = (size_t)B * (8 * d + 3 * d + g.dec_ff);
@@ -1064,9 +1078,11 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
                 int64_t* tokens, float* logits, int* steps_out, hipStream_t user, bool async, int rows_per_batch = 0) {
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab;
-  const int slot = (int)(c->decode_seq++ & 1u);
-  // async decodes alternate between the two chains (chain == K/V slot); everything else runs on chain 0
-  select_chain(c, (async && c->n_chains > 1) ? slot : 0);
+  // memory slots rotate (at least two: the next batch's copy is written while the previous decode still reads its own);
+  // async decodes rotate over the chains (chain == slot); everything else runs on chain 0
+  const int nslots = c->n_chains > 2 ? c->n_chains : 2;
+  const int slot = (int)(c->decode_seq++ % (unsigned)nslots);
+  select_chain(c, (async && c->n_chains > 1) ? slot % c->n_chains : 0);
   hipStream_t s = c->dstream;
   DecBufs bf;
   int rc = dec_prepare(c, B, T, &bf);
@@ -1150,9 +1166,8 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
       e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
       hipGraphDestroy(gr);
       if (e != hipSuccess) return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-      if (c->graphs.size() >= 16) {  // evict the least recently used; it may still be queued on a decode stream
-        HIPCHK(c, hipStreamSynchronize(c->dstream));
-        HIPCHK(c, hipStreamSynchronize(c->parked.stream));
+      if (c->graphs.size() >= 40) {  // evict the least recently used; it may still be queued on a decode stream
+        HIPCHK(c, sync_chains(c));
         hipGraphExecDestroy(c->graphs.front().exec);
         c->graphs.erase(c->graphs.begin());
       }
@@ -1622,11 +1637,10 @@ int d2t_decode_greedy_submit(d2t_ctx* c, const float* memory, int32_t B, int32_t
 int d2t_decode_wait(d2t_ctx* c, d2t_stream stream, int32_t host_sync) {
   DevGuard dg_(c);
   if (!c) return D2T_EINVAL;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < d2t_ctx::MAXC; ++i)
     if (c->ev_done_valid[i]) HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, c->ev_done[i], 0));
   if (host_sync) {
-    HIPCHK(c, hipStreamSynchronize(c->dstream));
-    HIPCHK(c, hipStreamSynchronize(c->parked.stream));
+    HIPCHK(c, sync_chains(c));
     c->decode_in_flight = false;
   }
   return D2T_OK;
@@ -2016,7 +2030,7 @@ int d2t_set_conv_winograd(d2t_ctx* c, int32_t min_channels) {
 
 int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
   DevGuard dg_(c);
-  if (!c || chains < 1 || chains > 2) return fail(c, D2T_EINVAL, "decode chains must be 1 or 2");
+  if (!c || chains < 1 || chains > d2t_ctx::MAXC) return fail(c, D2T_EINVAL, "decode chains must be 1 .. %d", d2t_ctx::MAXC);
   c->n_chains = chains;
   return D2T_OK;
 }

@@ -266,7 +266,7 @@ int d2t_set_conv_winograd(d2t_ctx* ctx, int32_t min_channels);
  * all its live hypotheses (beam <= 6; decode.hip beam_cross_kernel).  Same results to fp32 summation order. */
 int d2t_set_beam_shared_tile(d2t_ctx* ctx, int32_t on);
 int d2t_set_reserved_cus(d2t_ctx* ctx, int32_t cus);
-/* Number of decode chains (1 or 2, default 1) d2t_decode_greedy_async alternates between.  Each chain has
+/* Number of decode chains (1 .. 4, default 1) d2t_decode_greedy_async alternates between.  Each chain has
  * its own stream, self-attention cache and workspace, so with 2 the step loops of two consecutive batches
  * run side by side (the loop is a dependent chain of small kernels that cannot fill the chip alone). */
 int d2t_set_decode_chains(d2t_ctx* ctx, int32_t chains);

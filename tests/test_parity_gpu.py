@@ -117,9 +117,9 @@ def test_headline_shape_properties(cases):
 
 
 def test_headline_shape_in_the_benchmarked_serving_mode(cases):
-    """What bench.py times -- B=64, 128x512, pipelined, two decode chains, decode groups of SIX batches (384 rows per step
-    loop), no reserved block slots -- and the earlier serving configurations (groups of three / two; ungrouped with 64
-    reserved slots).  Seven batches: with groups of six one full 384-row group and an incomplete one (64 rows, launched by
+    """What bench.py times -- B=64, 128x512, pipelined, THREE decode chains, decode groups of SIX batches (384 rows per step
+    loop), no reserved block slots -- and the earlier serving configurations (two chains; groups of three / two; ungrouped
+    with 64 reserved slots).  Seven batches: with groups of six one full 384-row group and an incomplete one (64 rows, launched by
     synchronize()) both run.  Every batch comes back exactly as the synchronous path returns it, and the fixture rows
     (computed by the reference) stay exact."""
     c = _case(cases, "greedy", "c2_greedy")
@@ -136,13 +136,13 @@ def test_headline_shape_in_the_benchmarked_serving_mode(cases):
     with torch.no_grad():
         ref = [m(x, text, is_train=False) for x in imgs]
         ref = [(p.clone(), l.clone()) for p, l, _ in ref]
-        for group, reserve in ((6, 0), (3, 0), (2, 0), (1, 64)):
-            m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, group, reserve
+        for chains, group, reserve in ((3, 6, 0), (2, 6, 0), (4, 3, 0), (2, 2, 0), (2, 1, 64)):
+            m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, chains, group, reserve
             got = [m(x, text, is_train=False) for x in imgs]
             m.synchronize()
             torch.cuda.synchronize()
             for (p, l, extra), (rp, rl) in zip(got, ref):
-                assert torch.equal(p, rp) and torch.equal(l, rl), (group, reserve)
+                assert torch.equal(p, rp) and torch.equal(l, rl), (chains, group, reserve)
                 assert np.array_equal(p[: c["B"]].cpu().numpy(), z["tokens"])
                 assert float(np.abs(l[: c["B"], steps].cpu().numpy() - z["logits_sample"]).max()) <= LOGIT_TOL
                 hp, hl = extra["decode"].result()  # the documented way to consume a pipelined forward, at every group index
@@ -164,7 +164,7 @@ def test_all_64_rows_of_a_headline_batch_vs_the_oracle(cases, manifests):
     torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
     with torch.no_grad():
         op, ol, _ = R.forward(ocfg, sd, img, text, is_test=False, faithful=False)
-        m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 2, 6, 0
+        m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 3, 6, 0
         p, l, extra = m(img.cuda(), text.cuda(), is_train=False)
         p, l = extra["decode"].result()
         torch.cuda.synchronize()
