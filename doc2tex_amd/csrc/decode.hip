@@ -922,13 +922,215 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same step for TWO rows per block (greedy decode).  The five row GEMVs read 5 x 256 KB of weights per row, and with two
+// one-row blocks on a CU that is 2.56 MB through the CU's 64 B/clk L2 path per launch -- 18 of the kernel's 69 us (probe
+// build).  Here the block's 512 threads fetch every weight element ONCE and apply it to both rows' inputs (two
+// accumulators, eight K groups of 32 instead of four of 64), the absorbed-query product shares W_k the same way, and the
+// attention phases run as before: waves 0-3 on row 2b, waves 4-7 on row 2b + 1, each wave its own key tiles and 16 KB stage.
+// Per row the arithmetic and its order are those of decoder_row_absorbed_kernel (the K groups of a GEMV are summed in the
+// same ascending order: groups of 32 instead of 64 change the association) -- results agree to fp32 rounding.
+// 152 KB of LDS: one block per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void row2_gemv(const float* in0, const float* in1, const float* __restrict__ Wt, float* part_s, int tid) {
+  // part_s[row][g][n]; thread (lr = n / 4, g): k in [g KG, (g + 1) KG)
+  constexpr int LPR = D / 4, G = 512 / LPR, KG = D / G;
+  const int lr = tid % LPR, g = tid / LPR;
+  const float* w = Wt + (size_t)(g * KG) * D + lr * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+  for (int k = 0; k < KG; ++k) {
+    const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
+    const float x0 = in0[g * KG + k], x1 = in1[g * KG + k];
+    a0.x = fmaf(x0, w4.x, a0.x); a0.y = fmaf(x0, w4.y, a0.y); a0.z = fmaf(x0, w4.z, a0.z); a0.w = fmaf(x0, w4.w, a0.w);
+    a1.x = fmaf(x1, w4.x, a1.x); a1.y = fmaf(x1, w4.y, a1.y); a1.z = fmaf(x1, w4.z, a1.z); a1.w = fmaf(x1, w4.w, a1.w);
+  }
+  *reinterpret_cast<float4*>(part_s + (0 * G + g) * D + lr * 4) = a0;
+  *reinterpret_cast<float4*>(part_s + (1 * G + g) * D + lr * 4) = a1;
+}
+
+__global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_kernel(const DecRow2P q) {
+  constexpr int D = 256, HD = 32, G = 8;
+  const DecRowP& p = q.r;
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
+  __shared__ __attribute__((aligned(1024))) unsigned char stage_s[8 * 16384];
+  __shared__ __attribute__((aligned(1024))) float qp_s[2][8 * D];
+  __shared__ __attribute__((aligned(16))) float a_s[2][D], y_s[2][D], x1_s[2][D], q2_s[2][D];
+  __shared__ float wm_s[2][4][8], wl_s[2][4][8];
+  float* const part_s = reinterpret_cast<float*>(stage_s);  // [2][G][D] = 16 KB of the (then idle) staging area
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = wave >> 2, w4i = wave & 3;   // this wave's row of the pair, its index among the row's four waves
+  // an odd row count: the last block's second half repeats the last row (same kernel for EVERY row, so a row's result never
+  // depends on how many rows share the launch) and keeps its stores to itself
+  const bool valid = 2 * (int)blockIdx.x + half < p.M;
+  const int b = valid ? 2 * blockIdx.x + half : p.M - 1;
+  const int trow = tid >> 8, tcol = tid & 255;  // element-wise phases: thread -> (row of the pair, channel)
+  const bool tvalid = 2 * (int)blockIdx.x + trow < p.M;
+  const int brow = tvalid ? 2 * blockIdx.x + trow : p.M - 1;
+  const int t = *p.step_ptr;
+  // ---- self-attention over the cache, two heads per wave ----
+  {
+    const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+      const int head = w4i + hp * 4;
+      float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      const float* curk = qkv + D + head * HD;
+      const float* curv = qkv + 2 * D + head * HD;
+      if (lane < HD && valid) {
+        Kc[(size_t)t * HD + lane] = curk[lane];
+        Vc[(size_t)t * HD + lane] = curv[lane];
+      }
+      row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s[half] + head * HD, lane);
+    }
+  }
+  __syncthreads();
+  row2_gemv<D>(a_s[0], a_s[1], p.wo_t, part_s, tid);
+  __syncthreads();
+  {
+    float v = p.bo[tcol] + p.xres[(size_t)brow * D + tcol];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[(trow * G + g) * D + tcol];
+    y_s[trow][tcol] = v;
+  }
+  __syncthreads();
+  if (w4i == 0) {  // LN1, two-pass, one wave per row
+    constexpr int V = D / 64;
+    float v[V], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = y_s[half][i * 64 + lane]; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] -= mean; qq += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float rstd = 1.f / sqrtf(qq * (1.f / D) + p.eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = i * 64 + lane;
+      x1_s[half][c] = v[i] * rstd * p.ln1_g[c] + p.ln1_b[c];
+    }
+  }
+  __syncthreads();
+  row2_gemv<D>(x1_s[0], x1_s[1], p.wq_t, part_s, tid);
+  __syncthreads();
+  {
+    float v = p.bq[tcol];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[(trow * G + g) * D + tcol];
+    q2_s[trow][tcol] = v;
+  }
+  __syncthreads();
+  // ---- absorbed queries of both rows: q'[h][c] = scale * sum_e q2[h*32 + e] * W_k[h*32 + e][c]; thread -> (head, 4 channels) ----
+  {
+    const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+    const int h = tid / (D / 4), c4 = (tid % (D / 4)) * 4;
+    const float* w = q.wk + (size_t)(h * HD) * D + c4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll 8
+    for (int e = 0; e < HD; ++e) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)e * D);
+      const float x0 = q2_s[0][h * HD + e], x1 = q2_s[1][h * HD + e];
+      a0.x = fmaf(x0, w4.x, a0.x); a0.y = fmaf(x0, w4.y, a0.y); a0.z = fmaf(x0, w4.z, a0.z); a0.w = fmaf(x0, w4.w, a0.w);
+      a1.x = fmaf(x1, w4.x, a1.x); a1.y = fmaf(x1, w4.y, a1.y); a1.z = fmaf(x1, w4.z, a1.z); a1.w = fmaf(x1, w4.w, a1.w);
+    }
+    const int o = h * D + ((((c4 >> 2) ^ h)) << 2);
+    *reinterpret_cast<float4*>(qp_s[0] + o) = make_float4(a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale);
+    *reinterpret_cast<float4*>(qp_s[1] + o) = make_float4(a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale);
+  }
+  __syncthreads();
+  // ---- cross-attention over the memory rows of each row's sample: four waves per row ----
+  {
+    const int cb = p.c_row_map ? p.c_row_map[b] : b;
+    float m_run, l_run;
+    f32x4 acc[4][4];
+    unsigned char* stage = stage_s + wave * 16384;
+    cross_absorbed_wave<4>(q.mem + (size_t)cb * q.mem_stride, p.T, qp_s[half], stage, w4i, lane, m_run, l_run, acc);
+    const int col = lane & 15, g = lane >> 4;
+    if (g == 0 && col < 8) { wm_s[half][w4i][col] = m_run; wl_s[half][w4i][col] = l_run; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* mine = reinterpret_cast<float*>(stage);
+    if (g < 2) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
+              make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * 8 * (D / 4); idx += 512) {  // merge each row's four partial softmaxes (log-sum-exp combine)
+    const int row = idx / (8 * (D / 4)), rem = idx % (8 * (D / 4));
+    const int h = rem / (D / 4), c4 = (rem % (D / 4)) * 4;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, wm_s[row][w][h]);
+    float L = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = wl_s[row][w][h] > 0.f ? expf(wm_s[row][w][h] - M) : 0.f;
+      L += wl_s[row][w][h] * f;
+      const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(stage_s + (row * 4 + w) * 16384) + h * D + c4);
+      o.x += c.x * f; o.y += c.y * f; o.z += c.z * f; o.w += c.w * f;
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<float4*>(qp_s[row] + h * D + c4) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);  // ctx in the queries' place
+  }
+  __syncthreads();
+  // ---- a2[o] = b_v[o] + sum_c ctx[head(o)][c] * W_v^T[c][o], both rows ----
+  {
+    constexpr int LPR = D / 4, KG = D / G;
+    const int lr = tid % LPR, g = tid / LPR;
+    const float* w = q.wv_t + (size_t)(g * KG) * D + lr * 4;
+    const int hoff = ((lr * 4) / HD) * D + g * KG;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
+      const float x0 = qp_s[0][hoff + k], x1 = qp_s[1][hoff + k];
+      a0.x = fmaf(x0, w4.x, a0.x); a0.y = fmaf(x0, w4.y, a0.y); a0.z = fmaf(x0, w4.z, a0.z); a0.w = fmaf(x0, w4.w, a0.w);
+      a1.x = fmaf(x1, w4.x, a1.x); a1.y = fmaf(x1, w4.y, a1.y); a1.z = fmaf(x1, w4.z, a1.z); a1.w = fmaf(x1, w4.w, a1.w);
+    }
+    // (the merge above still reads the staging area of waves 0 .. 7: it is behind the barrier)
+    *reinterpret_cast<float4*>(part_s + (0 * G + g) * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_s + (1 * G + g) * D + lr * 4) = a1;
+  }
+  __syncthreads();
+  {
+    float v = q.bv[tcol];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[(trow * G + g) * D + tcol];
+    a_s[trow][tcol] = v;
+  }
+  __syncthreads();
+  row2_gemv<D>(a_s[0], a_s[1], p.wco_t, part_s, tid);
+  __syncthreads();
+  {
+    float v = p.bco[tcol] + x1_s[trow][tcol];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[(trow * G + g) * D + tcol];
+    if (tvalid) p.y2[(size_t)brow * D + tcol] = v;
+  }
+}
+
 hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
                                        const float* bv, hipStream_t s) {
   if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
   DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, nullptr, nullptr};
   static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
   q.r.probe = probe;
-  hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
+  static const bool one_row = getenv("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
+  if (one_row) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
   return hipGetLastError();
 }
 
