@@ -348,11 +348,15 @@ __global__ __launch_bounds__(512) void vit_attention_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ y,
                                                                   int N, int heads, int tiles) {
+  // Round 3: the score product is taken TRANSPOSED (S^T = K Q^T: rows = keys, columns = this wave's 32 queries), so a lane
+  // holds, for ONE query (its column), 16 of the tile's 32 keys in its accumulator registers -- and that is already the
+  // A-operand layout of the second product when MFMA step kk is made to mean "key (kk & 3) + 8 (kk >> 2) + 4 h" (the V rows are
+  // simply read in that order).  No LDS tile for P (113 -> 75 KB: two blocks per CU), the row maximum is 16 in-register
+  // maxima and one lane exchange instead of sixteen 5-step lane reductions, and the exps are 16 per lane as before.
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Np = tiles * 32;
   float* Ks = sm;                          // [Np][33]
   float* Vs = Ks + (size_t)Np * 33;        // [Np][32]
-  float* Pw = Vs + (size_t)Np * 32;        // [waves][32][33]
   const int b = blockIdx.x / heads, hh = blockIdx.x % heads, C = heads * 32;
   const float* base = qkv + (size_t)b * N * 3 * C;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthreads = blockDim.x;
@@ -369,55 +373,61 @@ __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* _
   }
   __syncthreads();
   const int r = lane & 31, h = lane >> 5, q0 = wave * 32;
-  // A operand of S: lane (r, h) supplies Q[q0 + r][h + 2 kk]
-  float qa[16];
+  // B operand of S^T: lane (k = h, column = query r) supplies scale * Q[q0 + r][2 kk + h]
+  float qb[16];
   {
-    const int row = q0 + r < N ? q0 + r : N - 1;  // clamp: rows beyond N are computed and discarded
+    const int row = q0 + r < N ? q0 + r : N - 1;  // clamp: queries beyond N are computed and discarded
     const float* qp = base + (size_t)row * 3 * C + hh * 32;
     const float scale = 0.17677669529663687f;     // 32^-0.5
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) qa[kk] = qp[2 * kk + h] * scale;
+    for (int kk = 0; kk < 16; ++kk) qb[kk] = qp[2 * kk + h] * scale;
   }
   f32x16 o;
-  float mrun[16], lrun[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { o[e] = 0.f; mrun[e] = -INFINITY; lrun[e] = 0.f; }
-  float* P = Pw + (size_t)wave * 32 * 33;
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;  // of query q0 + r (both lane halves hold the same values)
   for (int t = 0; t < tiles; ++t) {
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    const float* kb = Ks + (size_t)(t * 32 + r) * 33 + h;
+    // A operand: lane (row = key r of the tile, k = h) supplies K[t*32 + r][2 kk + h]
+    const float* ka = Ks + (size_t)(t * 32 + r) * 33 + h;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[kk], kb[2 * kk], sacc, 0, 0, 0);
-    // this lane's column is key t*32 + r; accumulator register e holds query row (e&3) + 8 (e>>2) + 4 h
-    const bool valid = t * 32 + r < N;
+    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * kk], qb[kk], sacc, 0, 0, 0);
+    // register e of this lane: key t*32 + (e & 3) + 8 (e >> 2) + 4 h, query q0 + r
+    float sv[16], mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float v = valid ? sacc[e] : -INFINITY;
-      float mx = v;
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));  // within the 32-lane half
-      const float mnew = fmaxf(mrun[e], mx);
-      const float corr = expf(mrun[e] - mnew);  // 0 on the first tile (mrun = -inf)
-      const float pe = expf(v - mnew);
-      lrun[e] = lrun[e] * corr + pe;
-      o[e] *= corr;
-      mrun[e] = mnew;
-      P[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = pe;  // P[m][n]
+      const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      sv[e] = key < N ? sacc[e] : -INFINITY;
+      mx = fmaxf(mx, sv[e]);
     }
-    // O += P V_t : A[i][k] = P[i][k], B[k][j] = V[t*32 + k][j]
-    const float* vb = Vs + (size_t)(t * 32 + h) * 32 + r;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other half of the tile's keys
+    const float mnew = fmaxf(mrun, mx);      // (every tile holds at least one valid key: finite)
+    const float corr = expf(mrun - mnew);    // 0 on the first tile
+    float pe[16], ps = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(P[r * 33 + 2 * kk + h], vb[(size_t)2 * kk * 32], o, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) {
+      pe[e] = expf(sv[e] - mnew);
+      ps += pe[e];
+    }
+    lrun = lrun * corr + ps;
+    mrun = mnew;
+    // O rows are queries (e & 3) + 8 (e >> 2) + 4 h: their correction lives in the lane of that query
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] *= __shfl(corr, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
+    // O += P V_t with MFMA step kk <-> key (kk & 3) + 8 (kk >> 2) + 4 h: A[query r][k = h] = pe[kk], B[k = h][d = r] = V[that key][r]
+    const float* vb = Vs + (size_t)(t * 32 + 4 * h) * 32 + r;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(pe[kk], vb[(size_t)((kk & 3) + 8 * (kk >> 2)) * 32], o, 0, 0, 0);
   }
-  // row sums: every lane holds a partial over its key columns
+  lrun += __shfl_xor(lrun, 32, 64);  // each half summed its own 16 keys per tile
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    float l = lrun[e];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-    const int row = q0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int qi = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const float l = __shfl(lrun, qi, 64);
+    const int row = q0 + qi;
     if (row < N) y[((size_t)b * N + row) * C + hh * 32 + r] = o[e] / l;
   }
 }
@@ -426,7 +436,7 @@ hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int he
   static const bool valu = getenv("D2T_VIT_ATTN_VALU") != nullptr;
   if (!valu && N <= 512) {
     const int tiles = (N + 31) / 32;
-    const size_t lds2 = ((size_t)tiles * 32 * 33 + (size_t)tiles * 32 * 32 + (size_t)tiles * 32 * 33) * sizeof(float);
+    const size_t lds2 = ((size_t)tiles * 32 * 33 + (size_t)tiles * 32 * 32) * sizeof(float);
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_mfma_kernel),
