@@ -447,7 +447,10 @@ hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s) {
 // ---------------------------------------------------------------------------
 template <int HD, int U>  // U key groups fetched together: 2*U 16-B loads in flight per lane
 __device__ __forceinline__ void row_attention(const float* q, const float* Kc, const float* Vc, const float* curk,
-                                              const float* curv, int t, int L, float* out, int lane) {
+                                              const float* curv, int t, int L, float* out, int lane,
+                                              const int* anc = nullptr, long long anc_stride = 0) {
+  // anc != nullptr (beam search, DecRowP::anc): position j < t of this hypothesis lives in cache row anc[j]; Kc / Vc then
+  // point at cache row 0 of the head and anc_stride is the cache's row stride
   constexpr int LPK = HD / 4, KPI = 64 / LPK;
   const int kig = lane / LPK, ch = lane % LPK;
   const float4 q4 = *reinterpret_cast<const float4*>(q + ch * 4);
@@ -461,8 +464,9 @@ __device__ __forceinline__ void row_attention(const float* q, const float* Kc, c
     for (int u = 0; u < U; ++u) {
       const int j = (it0 + u) * KPI + kig;
       const int jj = j < L ? j : 0;
-      const float* kr = (curk && jj == t) ? curk : Kc + (size_t)jj * HD;
-      const float* vr = (curv && jj == t) ? curv : Vc + (size_t)jj * HD;
+      const size_t ro = (anc && jj != t) ? (size_t)anc[jj] * (size_t)anc_stride : 0;
+      const float* kr = (curk && jj == t) ? curk : Kc + ro + (size_t)jj * HD;
+      const float* vr = (curv && jj == t) ? curv : Vc + ro + (size_t)jj * HD;
       k4[u] = *reinterpret_cast<const float4*>(kr + ch * 4);
       v4[u] = *reinterpret_cast<const float4*>(vr + ch * 4);
     }
@@ -742,6 +746,7 @@ struct DecRow2P {
 #endif
 // MODE 0: the whole row step (greedy).  MODE 1: up to the absorbed queries, which go to q.qp (+ x1 to q.x1).  MODE 2: from
 // the context rows in q.qp on (value projection, output projection, residual) -- the two halves around beam_cross_kernel.
+constexpr int ANC_MAX = 512;  // longest ancestry row held in LDS (DecRowP::anc needs s_Lmax <= ANC_MAX)
 template <int NTH, int MODE>  // D = 256, 8 heads of 32
 __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecRow2P q) {
   constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
@@ -763,6 +768,12 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   const int t = *p.step_ptr;
   const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
   if (MODE != 2) {
+  // beam search: the hypothesis' earlier positions stay in the cache rows they were written to (no cache copy per step)
+  __shared__ int anc_s[ANC_MAX];
+  if (p.anc) {
+    for (int j = tid; j < t; j += NTH) anc_s[j] = p.anc[(size_t)b * p.anc_stride + j];
+    __syncthreads();
+  }
   // ---- self-attention over the cache (as decoder_row_kernel) ----
 #pragma unroll
   for (int hp = 0; hp < (ROW_PROBE(1) ? 0 : HPW); ++hp) {
@@ -775,7 +786,11 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
       Kc[(size_t)t * HD + lane] = curk[lane];
       Vc[(size_t)t * HD + lane] = curv[lane];
     }
-    row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s + head * HD, lane);
+    if (p.anc)
+      row_attention<HD, 4>(qkv + head * HD, p.sk + (size_t)head * p.s_Lmax * HD, p.sv + (size_t)head * p.s_Lmax * HD, curk, curv,
+                           t, t + 1, a_s + head * HD, lane, anc_s, p.s_batch_stride);
+    else
+      row_attention<HD, 4>(qkv + head * HD, Kc, Vc, curk, curv, t, t + 1, a_s + head * HD, lane);
   }
   __syncthreads();
   if (!ROW_PROBE(2)) row_gemv<D, NTH>(a_s, p.wo_t, part_s, tid);
@@ -1129,7 +1144,8 @@ hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long 
   static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
   q.r.probe = probe;
   static const bool one_row = getenv("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
-  if (one_row) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
+  if (r.anc && (!r.one_row || r.s_Lmax > ANC_MAX)) return hipErrorInvalidValue;  // the two-row kernel reads the cache directly
+  if (one_row || r.one_row) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
   else hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
   return hipGetLastError();
 }
@@ -1439,6 +1455,27 @@ hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, in
                                int Lmax, int hd, int rows, hipStream_t s) {
   hipLaunchKernelGGL(cache_gather_kernel, dim3(slabs, M, heads), dim3(256), 0, s, src, dst, prev, cap, M, heads, Lmax,
                      hd, rows);
+  return hipGetLastError();
+}
+
+// Beam search without the cache copy: anc[row][j] = cache row that holds position j of hypothesis `row`.  Before step t
+// (read from the host's step pack) the survivors inherit their parent's ancestry and add the parent's row for position
+// t - 1; the kernel also publishes t in the engine's step counter.  One block per row.
+__global__ void beam_ancestry_kernel(const int* __restrict__ anc_old, int* __restrict__ anc_new, const int* __restrict__ prev,
+                                     int stride, const int* __restrict__ step_in, int* __restrict__ step_out) {
+  const int t = *step_in, row = blockIdx.x;
+  if (row == 0 && threadIdx.x == 0) *step_out = t;
+  if (!anc_new || t < 1) return;
+  const int p = prev[row];
+  const int* src = anc_old + (size_t)p * stride;
+  int* dst = anc_new + (size_t)row * stride;
+  for (int j = threadIdx.x; j < t - 1; j += blockDim.x) dst[j] = src[j];
+  if (threadIdx.x == 0) dst[t - 1] = p;
+}
+hipError_t launch_beam_ancestry(const int* anc_old, int* anc_new, const int* prev, int rows, int stride, const int* step_in,
+                                int* step_out, hipStream_t s) {
+  if (rows < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_ancestry_kernel, dim3(rows), dim3(64), 0, s, anc_old, anc_new, prev, stride, step_in, step_out);
   return hipGetLastError();
 }
 

@@ -1023,7 +1023,8 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 // post (launch_decoder_row_beam) with the samples' row segments in `seg` (nullptr: one sample, rows [0, M)).
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
                        float* logits, long long logit_row_stride, long long logit_step_stride, int ckvB = -1,
-                       const int* row_map = nullptr, const int* stop = nullptr, int beam = 0, const int* seg = nullptr) {
+                       const int* row_map = nullptr, const int* stop = nullptr, int beam = 0, const int* seg = nullptr,
+                       const int* anc = nullptr) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
@@ -1052,6 +1053,7 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.y2 = bf.y2; r.step_ptr = step; r.M = M; r.D = d; r.heads = heads;
     r.trace = trace_slot(c);
     r.stop_at = stop;
+    r.anc = anc; r.anc_stride = Lmax; r.one_row = beam > 0;
     if (c->dec_absorbed && c->beam_shared_tile && beam > 0 && beam <= 6 && c->beam_qp && (shared_mem || row_map))
       TRY(launch_decoder_row_beam(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, c->beam_qp,
                                   c->beam_qp + (size_t)kvB * 8 * d, seg, shared_mem ? 1 : ckvB, s));
@@ -1858,33 +1860,41 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
   DecBufs bf;
   int rc = dec_prepare(c, cap, T, &bf);
   if (rc) return rc;
+  // Round 3: with the absorbed row kernel the self-attention cache is never copied -- every hypothesis keeps an ancestry row
+  // (which cache row holds each of its earlier positions, launch_beam_ancestry); otherwise the survivors' caches are gathered
+  // into the other buffer as before.
+  const bool use_anc = c->dec_absorbed && !c->beam_shared_tile && Lmax <= 512 && getenv("D2T_BEAM_CACHE_COPY") == nullptr;
   const size_t skv_bytes = (size_t)g.dec_layers * 2 * cap * Lmax * d * 4;
-  if ((rc = ensure(c, &c->skv_alt, &c->skv_alt_cap, skv_bytes))) return rc;
-  // workspace: logits [cap][V] | scores [cap] | topv [cap] | tok [cap] i64 | topi [cap] | prev [cap] | rowmap [cap] | seg [N][3]
-  const size_t nf = (size_t)cap * V + 2 * (size_t)cap;
-  const size_t tok_off = (nf + 1) & ~(size_t)1;
-  const size_t ws_bytes = tok_off * 4 + (size_t)cap * 8 + (3 * (size_t)cap + 3 * (size_t)N) * 4 + 64;
+  if (!use_anc && (rc = ensure(c, &c->skv_alt, &c->skv_alt_cap, skv_bytes))) return rc;
+  // workspace: logits [cap][V] | topv [cap] | topi [cap] | step pack (one host -> device copy per step):
+  //   tok [cap] i64 | scores [cap] | rowmap [cap] | prev [cap] | seg [N][3] | step [4] | ancestry [2][cap][Lmax]
+  const size_t pack_off = (((size_t)cap * V + 2 * (size_t)cap) * 4 + 15) & ~(size_t)15;
+  const size_t pack_bytes = ((size_t)cap * (8 + 3 * 4) + (size_t)N * 12 + 16 + 15) & ~(size_t)15;
+  const size_t anc_words = use_anc ? 2 * (size_t)cap * Lmax : 0;
+  const size_t ws_bytes = pack_off + pack_bytes + anc_words * 4 + 64;
   if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, ws_bytes))) return rc;
   float* d_logits = c->beam_ws;
-  float* d_scores = d_logits + (size_t)cap * V;
-  float* d_topv = d_scores + cap;
-  int64_t* d_tok = reinterpret_cast<int64_t*>(d_logits + tok_off);
-  int* d_topi = reinterpret_cast<int*>(d_tok + cap);
-  int* d_prev = d_topi + cap;
-  int* d_map = d_prev + cap;
-  int* d_seg = d_map + cap;
+  float* d_topv = d_logits + (size_t)cap * V;
+  int* d_topi = reinterpret_cast<int*>(d_topv + cap);
+  char* d_pack = reinterpret_cast<char*>(c->beam_ws) + pack_off;
+  int64_t* d_tok = reinterpret_cast<int64_t*>(d_pack);
+  float* d_scores = reinterpret_cast<float*>(d_tok + cap);
+  int* d_map = reinterpret_cast<int*>(d_scores + cap);
+  int* d_prev = d_map + cap;
+  int* d_seg = d_prev + cap;
+  int* d_step = d_seg + 3 * (size_t)N;
+  int* d_anc[2] = {reinterpret_cast<int*>(d_pack + pack_bytes), reinterpret_cast<int*>(d_pack + pack_bytes) + (size_t)cap * Lmax};
   char* hp = nullptr;
-  const size_t hbytes = 16 + (size_t)cap * (8 + 4 * 5) + (size_t)N * 12 + 64;
-  if (hipHostMalloc(reinterpret_cast<void**>(&hp), hbytes, hipHostMallocDefault) != hipSuccess)
+  if (hipHostMalloc(reinterpret_cast<void**>(&hp), pack_bytes + 2 * (size_t)cap * 4 + 64, hipHostMallocDefault) != hipSuccess)
     return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
-  int* h_step = reinterpret_cast<int*>(hp);
-  int64_t* h_tok = reinterpret_cast<int64_t*>(hp + 16);
-  float* h_scores = reinterpret_cast<float*>(hp + 16 + (size_t)cap * 8);
-  float* h_topv = h_scores + cap;
+  int64_t* h_tok = reinterpret_cast<int64_t*>(hp);
+  float* h_scores = reinterpret_cast<float*>(h_tok + cap);
+  int* h_map = reinterpret_cast<int*>(h_scores + cap);
+  int* h_prev = h_map + cap;
+  int* h_seg = h_prev + cap;
+  int* h_step = h_seg + 3 * (size_t)N;
+  float* h_topv = reinterpret_cast<float*>(hp + pack_bytes);  // [topv | topi]: one device -> host copy per step
   int* h_topi = reinterpret_cast<int*>(h_topv + cap);
-  int* h_prev = h_topi + cap;
-  int* h_map = h_prev + cap;
-  int* h_seg = h_map + cap;
   auto done = [&](int code) { hipHostFree(hp); return code; };
 #define BCHK(expr)                                                                              \
   do {                                                                                          \
@@ -1899,83 +1909,90 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
   c->skv_cur = c->skv;
   float* skv_other = c->skv_alt;
 
-  struct Hyp { std::vector<int64_t> seq; float score; };
-  std::vector<std::vector<Hyp>> hyps((size_t)N, std::vector<Hyp>(1)), completed((size_t)N);
+  // Beam bookkeeping (tools/beam.py:68-105) on a token trie: a hypothesis is (score, node); its sequence is the path to the
+  // root, written out once at the end (the reference concatenates the sequences every step)
+  struct Node { int parent; int64_t tok; int len; };
+  struct Hyp { int node; float score; };
+  std::vector<Node> trie;
+  trie.reserve((size_t)cap * S);
+  auto seq_len = [&](int node) { return node < 0 ? 0 : trie[(size_t)node].len; };
+  std::vector<std::vector<Hyp>> hyps((size_t)N, std::vector<Hyp>(1, Hyp{-1, 0.f})), completed((size_t)N);
   std::vector<std::vector<int64_t>> last((size_t)N, std::vector<int64_t>{TOK_GO});
   std::vector<char> finished((size_t)N, 0);
-  for (int i = 0; i < N; ++i) hyps[i][0].score = 0.f;
+  int nprev = 0;  // survivors of the previous step, in this step's row order: h_prev[0 .. nprev)
   for (int step = 0; step < S; ++step) {
-    int rows = 0, live_samples = 0;
+    int rows = 0;
     for (int i = 0; i < N; ++i) {
       const int M = finished[i] ? 0 : (int)hyps[i].size();
       h_seg[3 * i] = rows; h_seg[3 * i + 1] = M; h_seg[3 * i + 2] = finished[i] ? 0 : beam_size - (int)completed[i].size();
       for (int j = 0; j < M; ++j) { h_tok[rows + j] = last[i][j]; h_scores[rows + j] = hyps[i][j].score; h_map[rows + j] = i; }
       rows += M;
-      live_samples += M > 0;
     }
     if (!rows) break;
+    if (step > 0 && nprev != rows) return done(fail(c, D2T_ESTATE, "beam bookkeeping: %d survivors, %d rows", nprev, rows));
     *h_step = step;
-    BCHK(hipMemcpyAsync(c->dstate, h_step, 4, hipMemcpyHostToDevice, s));
-    BCHK(hipMemcpyAsync(d_tok, h_tok, (size_t)rows * 8, hipMemcpyHostToDevice, s));
-    BCHK(hipMemcpyAsync(d_scores, h_scores, (size_t)rows * 4, hipMemcpyHostToDevice, s));
-    BCHK(hipMemcpyAsync(d_map, h_map, (size_t)rows * 4, hipMemcpyHostToDevice, s));
-    BCHK(hipMemcpyAsync(d_seg, h_seg, (size_t)N * 12, hipMemcpyHostToDevice, s));
+    BCHK(hipMemcpyAsync(d_pack, hp, pack_bytes, hipMemcpyHostToDevice, s));
+    if (use_anc) {
+      BCHK(launch_beam_ancestry(d_anc[(step + 1) & 1], d_anc[step & 1], d_prev, rows, Lmax, d_step, c->dstate, s));
+    } else {
+      BCHK(launch_beam_ancestry(nullptr, nullptr, d_prev, 1, 0, d_step, c->dstate, s));  // publishes the step only
+      if (step > 0) {  // the survivors' caches move to their new row positions
+        BCHK(launch_cache_gather(c->skv_cur, skv_other, d_prev, g.dec_layers * 2, cap, rows, heads, Lmax, hd, step, s));
+        std::swap(c->skv_cur, skv_other);
+      }
+    }
     BCHK(launch_embed_tokens(c->word_embed, c->word_pe, d_tok, c->dstate, bf.x, rows, d, s));
-    BCHK(decode_step(c, s, bf, rows, T, cap, false, d_logits, V, 0, N, d_map, nullptr, beam_size, d_seg));
+    BCHK(decode_step(c, s, bf, rows, T, cap, false, d_logits, V, 0, N, d_map, nullptr, beam_size, d_seg,
+                     use_anc ? d_anc[step & 1] : nullptr));
     BCHK(launch_beam_topk_batch(d_logits, d_scores, d_seg, N, V, beam_size, d_topv, d_topi, s));
-    BCHK(hipMemcpyAsync(h_topv, d_topv, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
-    BCHK(hipMemcpyAsync(h_topi, d_topi, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(h_topv, d_topv, 2 * (size_t)cap * 4, hipMemcpyDeviceToHost, s));
     BCHK(hipStreamSynchronize(s));
-    int nrows = 0;
+    nprev = 0;
     for (int i = 0; i < N; ++i) {  // Beam.advance (tools/beam.py:68-105) per sample
       if (finished[i]) continue;
       const int off = h_seg[3 * i], live = h_seg[3 * i + 2];
       std::vector<Hyp> next;
       std::vector<int64_t> nl;
-      std::vector<int> pv;
+      const int first_prev = nprev;
       for (int r = 0; r < live; ++r) {
         const int idx = h_topi[(size_t)i * beam_size + r], prev = idx / V, word = idx % V;
-        Hyp h;
-        h.seq = hyps[i][prev].seq;
-        h.seq.push_back(word);
-        h.score = h_topv[(size_t)i * beam_size + r];
+        const int parent = hyps[i][prev].node;
+        trie.push_back(Node{parent, (int64_t)word, seq_len(parent) + 1});
+        const Hyp h{(int)trie.size() - 1, h_topv[(size_t)i * beam_size + r]};
         if (word == TOK_END) {
-          completed[i].push_back(std::move(h));
+          completed[i].push_back(h);
         } else {
           nl.push_back(word);
-          pv.push_back(off + prev);
-          next.push_back(std::move(h));
+          h_prev[nprev++] = off + prev;
+          next.push_back(h);
         }
       }
       hyps[i].swap(next);
       last[i].swap(nl);
-      if ((int)completed[i].size() == beam_size) { finished[i] = 1; continue; }  // Beam.done: its rows drop out
-      for (int v : pv) h_prev[nrows++] = v;  // the survivors' caches move to their new row positions
+      if ((int)completed[i].size() == beam_size) { finished[i] = 1; nprev = first_prev; }  // Beam.done: its rows drop out
     }
-    if (nrows && step + 1 < S) {
-      BCHK(hipMemcpyAsync(d_prev, h_prev, (size_t)nrows * 4, hipMemcpyHostToDevice, s));
-      BCHK(launch_cache_gather(c->skv_cur, skv_other, d_prev, g.dec_layers * 2, cap, nrows, heads, Lmax, hd, step + 1, s));
-      std::swap(c->skv_cur, skv_other);
-    }
-    (void)live_samples;
   }
   BCHK(hipStreamSynchronize(s));
 #undef BCHK
   for (int i = 0; i < N; ++i) {
     std::vector<Hyp>& comp = completed[i];
-    if (comp.empty()) {  // Beam.set_hypothesis (beam.py:132-140)
-      Hyp h = hyps[i].empty() ? Hyp{} : hyps[i][0];
-      h.seq.resize((size_t)g.max_seq_len + 1, TOK_PAD);
-      comp.push_back(std::move(h));
+    bool padded = false;
+    if (comp.empty()) {  // Beam.set_hypothesis (beam.py:132-140): the first live hypothesis, padded to max_seq_len + 1
+      comp.push_back(hyps[i].empty() ? Hyp{-1, 0.f} : hyps[i][0]);
+      padded = true;
     }
+    auto len_of = [&](const Hyp& h) { return padded ? (size_t)g.max_seq_len + 1 : (size_t)seq_len(h.node); };
     size_t best = 0;
     for (size_t j = 1; j < comp.size(); ++j)
-      if ((double)comp[j].score / (double)std::max<size_t>(1, comp[j].seq.size()) >
-          (double)comp[best].score / (double)std::max<size_t>(1, comp[best].seq.size()))
+      if ((double)comp[j].score / (double)std::max<size_t>(1, len_of(comp[j])) >
+          (double)comp[best].score / (double)std::max<size_t>(1, len_of(comp[best])))
         best = j;
     const Hyp& bh = comp[best];
-    const int n = (int)std::min<size_t>(bh.seq.size(), (size_t)S);
-    for (int j = 0; j < n; ++j) seq_out[(size_t)i * S + j] = bh.seq[j];
+    const int have = seq_len(bh.node), n = (int)std::min<size_t>(len_of(bh), (size_t)S);
+    for (int j = 0; j < n; ++j) seq_out[(size_t)i * S + j] = TOK_PAD;
+    int node = bh.node;
+    for (int j = have - 1; j >= 0; --j, node = trie[(size_t)node].parent)
+      if (j < n) seq_out[(size_t)i * S + j] = trie[(size_t)node].tok;
     len_out[i] = n;
     score_out[i] = bh.score;
   }

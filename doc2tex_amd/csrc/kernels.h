@@ -231,6 +231,10 @@ struct DecRowP {
   unsigned long long* trace;          // debug (D2T_DECODE_TRACE), as SkinnyP::trace
   const int* stop_at;                 // early exit, as SkinnyP::stop_at (the step counter is step_ptr)
   int probe;                          // probe builds only (D2T_ROW_PROBE bit mask: 1 no self-attention, 2 no GEMVs, 4 no cross-attention)
+  // beam search (absorbed form only): anc[b * anc_stride + j] = cache row holding position j < step of hypothesis b
+  // (launch_beam_ancestry); nullptr = every hypothesis owns its cache row.  one_row: one row per block (the faster form at
+  // 5 x 128 hypothesis rows; also what keeps batched and per-sample beam search bit-identical)
+  const int* anc; int anc_stride; int one_row;
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 // the same step with the cross-attention taken over the encoder memory itself (absorbed K / V projections, decode.hip):
@@ -281,6 +285,8 @@ hipError_t launch_beam_topk_batch(const float* logits, const float* scores, cons
                                   float* topv, int* topi, hipStream_t s);
 // dst[slab][i][...] = src[slab][prev[i]][...] for the first `rows` positions of every head
 // (self-attention KV cache reorder after a beam step); caches are [slabs][cap][heads][Lmax][hd].
+hipError_t launch_beam_ancestry(const int* anc_old, int* anc_new, const int* prev, int rows, int stride, const int* step_in,
+                                int* step_out, hipStream_t s);
 hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, int slabs, int cap, int M, int heads,
                                int Lmax, int hd, int rows, hipStream_t s);
 
