@@ -543,7 +543,7 @@ def main():
                     help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
-    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16"],
+    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16", "band16", "wide16"],
                     help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
     ap.add_argument("--winograd", type=int, default=None,
                     help="Winograd F(2x2,3x3) for the 3x3 layers with at least this many channels (0 = off)")

@@ -454,12 +454,12 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.pool2) {  // fused 2x2 max-pool: split-record LDS-DMA kernels with the wide epilogue only (g body, 16x16x32 pipelined body)
     const bool wide = p.store_mode == STORE_ROWS && p.rows_per_img == 0 && !p.row_add && (p.Cout & 31) == 0;
     if (!p.in_hi || !wide || p.res || p.res_hi || (p.M & 3) || p.M != 4 * p.B * (p.OH / 2) * (p.OW / 2) ||
-        (p.Cout >= 128 && p.pipelined != 3) || (p.Cout > 64 && p.Cout < 128))
+        (p.Cout >= 128 && p.pipelined != 3 && p.pipelined != 6 && p.pipelined != 7) || (p.Cout > 64 && p.Cout < 128))
       return hipErrorInvalidValue;
   }
   if (!p.w_hi || !p.w_lo || p.Cin % XBK != 0 || p.K != p.KH * p.KW * p.Cin + p.Cin2 || p.m_base != 0) return hipErrorInvalidValue;
   // a second (1x1) input along K: the DMA issuer of the pipelined 16x16x32 kernel only (no tail hand-over, not the patch forms)
-  if (p.Cin2 && (!p.in_hi || !p.in2_hi || p.Cin2 % XBK || p.Cout < 128 || p.pipelined != 3 || p.pool2 ||
+  if (p.Cin2 && (!p.in_hi || !p.in2_hi || p.Cin2 % XBK || p.Cout < 128 || (p.pipelined != 3 && p.pipelined != 6 && p.pipelined != 7) || p.pool2 ||
                  p.OH != p.H || p.OW != p.W))
     return hipErrorInvalidValue;
   const int mt = (p.M + 127) / 128;

@@ -512,18 +512,19 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
 // waves 4-7 carry the B fragments and the second pair of A fragments across the barrier.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, int NL, bool STG>
+template <int BM, int BN, int WM, int WN, int NL, bool STG, int ABL = 0>  // ABL (probe builds): 1 no LDS-DMA, 2 no MFMA, 4 LDS-DMA never awaited
 __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned char* smem) {
   constexpr int NW = WM * WN, NT = (NW + NL) * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
+  constexpr bool UPFRONT = ABL != 8;  // (8: the reads as the compiler schedules them, for A/B timing in probe builds)
   static_assert(MI >= 2 && (MI & 1) == 0 && NJ >= 1 && NL > 0, "wave tile / loader configuration");
-  using Issuer = DmaIssuer<BM, BN, NL, 0, true>;
+  using Issuer = DmaIssuer<BM, BN, NL, ABL == 1 ? 1 : 0, true>;
   constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, PER_STEP = Issuer::PER_STEP;
   static_assert(BM * BN * 4 <= 3 * STAGE, "the fp32 epilogue tile must fit in the staging area");
 
   const int nt = (p.Cout + BN - 1) / BN;
-  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int ntiles = nt * ((p.M - p.m_base + BM - 1) / BM);  // rows [m_base, M): the rows a 256 x 256 launch left over
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool loader = wave >= NW;  // wave-uniform
   const int KT = p.K / PBK;
@@ -531,7 +532,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
   const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
 
   for (int tile = slot; tile < ntiles; tile += G) {
-    const int m0 = (tile / nt) * BM;
+    const int m0 = p.m_base + (tile / nt) * BM;
     const int n0 = (tile % nt) * BN;
     if (loader) {  // identical to conv_bf16x3p_body's loader (same barrier sequence)
       Issuer dma;
@@ -540,11 +541,12 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       if (KT > 1) dma.issue(p, smem, 1, 1);
       int nxt2 = 2;
       for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>();
+        if (ABL != 4) { if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < KT) dma.issue(p, smem, kt + 2, nxt2);
         nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
       }
+      if (ABL == 4) wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_barrier();
       if (wide_epilogue_ok(p)) { if (p.pool2) epilogue_rows_pool<BM, BN, NT>(p, smem, m0, n0, tid); else epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid); }
@@ -593,6 +595,10 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+          if (ABL == 2) {  // keep the reads alive, drop the matrix work
+            asm volatile("" ::"v"(fal[i]), "v"(fah[i]), "v"(fbh[j]), "v"(fbl[j]));
+            continue;
+          }
           f32x4v c = acc[half * MH + i][j];
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
@@ -608,18 +614,15 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       for (int kt = 0; kt < KT; ++kt) {
         __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
         const unsigned char* ah = smem + cur * STAGE;
-        bf16x8 fbh[NJ], fbl[NJ];
+        // all sixteen fragment reads of the K-step go out before the first MFMA (the SIMD partner's carried MFMAs cover
+        // their latency); left to itself the compiler interleaves them in three groups, each with its own wait
+        bf16x8 fbh[NJ], fbl[NJ], fah[MH], fal[MH], fch[MH], fcl[MH];
         read_b(ah, fbh, fbl);
-        {
-          bf16x8 fah[MH], fal[MH];
-          read_a(ah, H0{}, fah, fal);
-          mma(H0{}, fah, fal, fbh, fbl);
-        }
-        {
-          bf16x8 fah[MH], fal[MH];
-          read_a(ah, H1{}, fah, fal);
-          mma(H1{}, fah, fal, fbh, fbl);
-        }
+        read_a(ah, H0{}, fah, fal);
+        read_a(ah, H1{}, fch, fcl);
+        if (UPFRONT) __builtin_amdgcn_sched_barrier(0);
+        mma(H0{}, fah, fal, fbh, fbl);
+        mma(H1{}, fch, fcl, fbh, fbl);
         cur = cur == 2 ? 0 : cur + 1;
       }
     } else {
@@ -633,9 +636,13 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
         {
           bf16x8 fah[MH], fal[MH];
           read_a(ah, H0{}, fah, fal);
+          if (UPFRONT) {  // the carried half's fragments are requested before the first half's MFMAs, not after them
+            read_a(ah, H1{}, gah, gal);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           mma(H0{}, fah, fal, gbh, gbl);
         }
-        read_a(ah, H1{}, gah, gal);
+        if (!UPFRONT) read_a(ah, H1{}, gah, gal);
         // the reads have returned before this wave arrives at the next barrier (after it the stage may be overwritten)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur = cur == 2 ? 0 : cur + 1;
@@ -669,6 +676,164 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 block tile on eight compute waves (round 3).  Ablations of conv_bf16x3p16_body on the dominant layer (probe
+// build, tools/probe/conv_abl.sh): without MFMAs it still takes 0.91 of 1.5 ms, with the input band resident (conv3x3_band16_body,
+// 42 % less LDS-DMA) the same -- what runs beside the matrix pipe is the LDS itself: eight 64 x 64 wave tiles read 128 KB of
+// fragments per K-step (A twice, B four times) and the LDS-DMA writes 48 KB, ~1400 cycles at 128 B/clk against 1536 cycles of
+// MFMAs.  Here a wave owns 128 x 64 (accumulators: 128 VGPRs, which needs the 256-register budget of two waves per SIMD, so
+// there are no loader waves: every wave issues an eighth of the LDS-DMA), the block 256 x 256: per K-step 192 KB of fragment
+// reads + 64 KB of LDS-DMA for 3072 cycles of MFMAs -- two thirds of the LDS and L2 traffic per FLOP.  Two 64 KB stages; the
+// next stage's LDS-DMA is issued right after the barrier that frees it and has the whole K-step (~1.5 us) to land.
+// Same K order, same three MFMAs per product in the same order: bit-identical to conv_bf16x3p16_body, which takes the rows that
+// do not fill whole rounds of 256-row tiles (launch_conv_bf16x3p) and every layer this tile does not fit.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool STG, int ABL = 0>
+__device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned char* smem) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
+  using Issuer = DmaIssuer<BM, BN, NW, ABL == 1 ? 1 : 0, true>;
+  constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE;
+  static_assert(BM * (BN / 2) * 4 <= 2 * STAGE, "half of the fp32 epilogue tile must fit in the staging area");
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int KT = p.K / PBK;
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * BM;
+    const int n0 = (tile % nt) * BN;
+    Issuer dma;
+    dma.setup(p, m0, n0, wave, lane);
+    dma.issue(p, smem, 0, 0);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // fragment offsets: rows 16 apart share the swizzle (aswz: (row >> 1) & 7, pswz16: (row >> 2) & 2), lo = hi ^ 64
+    const int offa0 = (wm * WTM + r) * 128 + aswz(wm * WTM + r, q) * 16;
+    const int offb0 = (wn * WTN + r) * PROW + pswz16(wn * WTN + r, q) * 16;
+    auto read_b = [&](const unsigned char* ah, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
+      const unsigned char* bh = ah + 2 * PLANE_A + offb0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + j * 16 * PROW);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bh + PLANE_B + j * 16 * PROW);
+      }
+    };
+    auto read_a = [&](const unsigned char* ah, auto half_c, bf16x8 (&fah)[MH], bf16x8 (&fal)[MH]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i) {
+        fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa0 + (half * MH + i) * 16 * 128);
+        fal[i] = *reinterpret_cast<const bf16x8*>(ah + (offa0 ^ 64) + (half * MH + i) * 16 * 128);
+      }
+    };
+    auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (ABL == 2) {  // keep the reads alive, drop the matrix work
+            asm volatile("" ::"v"(fal[i]), "v"(fah[i]), "v"(fbh[j]), "v"(fbl[j]));
+            continue;
+          }
+          f32x4v c = acc[half * MH + i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
+          acc[half * MH + i][j] = c;
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    int cur = 0;
+    const bool late = STG && wave >= NW / 2;
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        if (ABL != 4) wait_vm<0>();      // this wave's pieces of stage kt have landed ...
+        __builtin_amdgcn_s_barrier();    // ... and everyone's; nobody reads stage kt - 1 (the other buffer) any more
+        if (kt + 1 < KT) dma.issue(p, smem, kt + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS-DMA issue ahead of the ds_reads / MFMAs
+        const unsigned char* ah = smem + cur * STAGE;
+        bf16x8 fbh[NJ], fbl[NJ];
+        read_b(ah, fbh, fbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H0{}, fah, fal);
+          mma(H0{}, fah, fal, fbh, fbl);
+        }
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H1{}, fah, fal);
+          mma(H1{}, fah, fal, fbh, fbl);
+        }
+        cur ^= 1;
+      }
+    } else {
+      bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
+      auto step = [&](auto carried_c, int kt) {
+        if (ABL != 4) wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* ah = smem + cur * STAGE;
+        if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);  // second half of the previous K-step (the SIMD partner issues its LDS-DMA meanwhile)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) dma.issue(p, smem, kt + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(ah, gbh, gbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(ah, H0{}, fah, fal);
+          mma(H0{}, fah, fal, gbh, gbl);
+        }
+        read_a(ah, H1{}, gah, gal);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the next barrier
+        cur ^= 1;
+      };
+      step(H0{}, 0);
+      for (int kt = 1; kt < KT; ++kt) step(H1{}, kt);
+      mma(H1{}, gah, gal, gbh, gbl);
+    }
+    if (ABL == 4) wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the stages: they become the epilogue's fp32 tile, one column half at a time
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc) {
+        if ((wn >> 1) == hc) {  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int row = wm * WTM + i * 16 + 4 * q + reg;
+                const int col = ((wn & 1) * WTN + j * 16 + r) ^ (((row >> 2) & 1) << 5);
+                tile_f[row * (BN / 2) + col] = acc[i][j][reg];
+              }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.pool2) epilogue_rows_pool<BM, BN / 2, NT>(p, smem, m0, n0 + hc * (BN / 2), tid);
+        else epilogue_rows<BM, BN / 2, NT>(p, smem, m0, n0 + hc * (BN / 2), tid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      conv_epilogue16<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, q);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 }
 
@@ -1150,6 +1315,295 @@ __device__ __forceinline__ void conv3x3_patch16_body(const ConvP& p, unsigned ch
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions of ANY width: a BAND of input records stays in LDS for the three taps of a filter row.
+//
+// Ablations of conv_bf16x3p16_body on the dominant layer (probe build, tools/probe/conv_abl.sh): without LDS-DMA 1.08 ms,
+// without MFMAs 0.91 ms, both 1.53 ms, LDS-DMA never awaited 1.55 ms -- the kernel is bound by how many bytes a CU can take in
+// per cycle (~33: 48 KB per K-step = 1470 cycles) next to 1536 cycles of MFMA work, not by latency.  Two thirds of those bytes
+// are the tile's 256 input records, fetched again for every tap.  With tiles that are linear in the pixel index, the taps
+// (kh, 0..2) of 256 consecutive output pixels read 258 consecutive input records: one band of 36 KiB (288 records, 36 LDS-DMA
+// pieces) per (32-channel chunk, kh) serves three K-steps -- 12 + 16 KB per K-step instead of 32 + 16.
+//   * LDS: three bands (the one in use and the next two, loaded 1/3 per K-step) + three 16 KB weight stages = 156 KB;
+//   * every loader wave issues 3 band pieces + 4 weight pieces per K-step (12 in conv_bf16x3p16_body);
+//   * fragment reads as in conv3x3_patch16_body: record (row + 1 + kw) of the band, chunk XOR-ed with (record & 7), taps
+//     outside the image zeroed per lane from the row's 9-bit mask.
+// Unlike the nine-tap patch kernel this needs no narrow map, keeps all 256 tile rows, and prefetches the weights two K-steps
+// ahead.  Same K order (channel chunk, kh, kw, channel) and the same three MFMAs per product: bit-identical to
+// conv_bf16x3p16_body (tests), so a layer may take either.  Not for the fused forms (pool2: rows are not linear in the pixel
+// index; Cin2: its K-steps are not taps).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RBREC = 288, RBAND = RBREC * 128, RBST = 2 * 128 * PROW;  // records per band, bytes per band / weight stage
+static_assert(3 * RBAND + 3 * RBST <= 160 * 1024, "three bands and three weight stages must fit a CU's LDS");
+
+template <bool STG, int ABL = 0>
+__device__ __forceinline__ void conv3x3_band16_body(const ConvP& p, unsigned char* smem) {
+  constexpr int BM = 256, BN = 128, WN = 2, NW = 8, NL = 4, NT = (NW + NL) * 64, MI = 4, NJ = 4, MH = 2;
+  static_assert(BM * BN * 4 <= 3 * RBAND + 3 * RBST, "the fp32 epilogue tile must fit in the staging area");
+  const int nt = (p.Cout + BN - 1) / BN;
+  const int ntiles = nt * ((p.M + BM - 1) / BM);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool loader = wave >= NW;
+  const int nchunks = p.Cin / 32, NB = 3 * nchunks, KT = 9 * nchunks;  // bands, K-steps
+  unsigned char* const bst = smem + 3 * RBAND;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
+  const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
+  const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+
+  for (int tile = slot; tile < ntiles; tile += G) {
+    const int m0 = (tile / nt) * BM;
+    const int n0 = (tile % nt) * BN;
+    if (loader) {
+      const int lw = wave - NW;
+      // band pieces of this loader: lw, lw + 4, ... (9 of 36); a piece = 8 records, lane -> (record, 16-byte position)
+      int a_g[9], a_off[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int rec = (lw + 4 * j) * 8 + (lane >> 3);
+        const int g = m0 - 1 + rec;  // input pixel (linear index) held by record `rec` of a kh = 1 band
+        const int c = (lane & 7) ^ (rec & 7);
+        a_g[j] = g;
+        a_off[j] = g * p.Cin * 2 + c * 8;
+      }
+      const uint16_t* b_hi[2];
+      const uint16_t* b_lo[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (lw * 2 + j) * 16 + (lane >> 2);
+        const int n = n0 + row;
+        const int c = pswz16(row, lane & 3);
+        b_hi[j] = n < p.Cout ? p.w_hi + (size_t)n * p.K + c * 8 : nullptr;
+        b_lo[j] = n < p.Cout ? p.w_lo + (size_t)n * p.K + c * 8 : nullptr;
+      }
+      auto issue_b = [&](int kt, int stage) {
+        unsigned char* bh = bst + stage * RBST;
+        unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int piece = (lw * 2 + j) * 1024;
+          if (ABL == 1) continue;
+          __builtin_amdgcn_global_load_lds(b_hi[j] ? b_hi[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bh + piece), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(b_lo[j] ? b_lo[j] + (size_t)kt * PBK : zero, (lds_ptr_t)(bl + piece), 16, 0, 0);
+        }
+      };
+      // pieces [3 * third, 3 * third + 3) of this loader's nine, band (chunk, kh) into ring slot `buf`
+      auto issue_a = [&](int chunk, int kh, int buf, int third) {
+        const int dg = (kh - 1) * p.W, doff = dg * p.Cin * 2 + chunk * 64;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          if (j / 3 != third) continue;
+          unsigned char* dst = smem + buf * RBAND + (lw + 4 * j) * 1024;
+          const uint16_t* src = (unsigned)(a_g[j] + dg) < (unsigned)p.M ? p.in_hi + (a_off[j] + doff) : zero;
+          if (ABL == 1) continue;
+          __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+      };
+      // prologue: bands 0 and 1 whole, weights of K-steps 0 and 1 (bands first: the wait before barrier 0 leaves only the
+      // second band and the second weight stage in flight)
+      for (int t3 = 0; t3 < 3; ++t3) issue_a(0, 0, 0, t3);
+      issue_b(0, 0);
+      for (int t3 = 0; t3 < 3; ++t3) issue_a(0, 1, 1, t3);  // (NB >= 3 always)
+      issue_b(1, 1);
+      int prev = 13;  // pieces issued after everything K-step kt needs: before barrier kt they may still be in flight
+      int b2c = 0, b2k = 2, b2buf = 2, third = 0, wst = 2;  // next band to load (chunk, kh, ring slot), its third, weight stage of kt + 2
+      for (int kt = 0; kt < KT; ++kt) {
+        if (ABL != 4) {
+          if (prev == 13) wait_vm<13>();
+          else if (prev == 7) wait_vm<7>();
+          else if (prev == 4) wait_vm<4>();
+          else if (prev == 3) wait_vm<3>();
+          else wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        prev = 0;
+        if (b2c < nchunks) {  // (wave-uniform) a third of band kt / 3 + 2
+          issue_a(b2c, b2k, b2buf, third);
+          prev += 3;
+          if (++third == 3) {
+            third = 0;
+            b2buf = b2buf == 2 ? 0 : b2buf + 1;
+            if (++b2k == 3) { b2k = 0; ++b2c; }
+          }
+        }
+        if (kt + 2 < KT) {
+          issue_b(kt + 2, wst);
+          prev += 4;
+        }
+        wst = wst == 2 ? 0 : wst + 1;
+      }
+      if (ABL == 4) wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      if (wide_epilogue_ok(p)) epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4v acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    unsigned tmask[MI];
+    int rbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * 64 + i * 16 + r;
+      rbase[i] = row;  // band record row + kw holds input pixel m0 + row + (kh - 1) W + kw - 1
+      const int m = m0 + row;
+      tmask[i] = 0;
+      if (m < p.M) {
+        const int rem = m % (p.H * p.W), oh = rem / p.W, ow = rem - oh * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y = oh + t / 3 - 1, x = ow + t % 3 - 1;
+          if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) tmask[i] |= 1u << t;
+        }
+      }
+    }
+    int offb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wn * 64 + j * 16 + r;
+      offb[j] = row * PROW + pswz16(row, q) * 16;
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto read_b = [&](const unsigned char* bh, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
+      const unsigned char* bl = bh + BN * PROW;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fbh[j] = *reinterpret_cast<const bf16x8*>(bh + offb[j]);
+        fbl[j] = *reinterpret_cast<const bf16x8*>(bl + offb[j]);
+      }
+    };
+    auto read_a = [&](const unsigned char* band, int shift, int tap, auto half_c, bf16x8 (&fah)[MH], bf16x8 (&fal)[MH]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i) {
+        const int rec = rbase[half * MH + i] + shift;
+        const int off = rec * 128 + ((q ^ (rec & 7)) << 4);
+        const unsigned keep = ((tmask[half * MH + i] >> tap) & 1u) ? 0xFFFFFFFFu : 0u;
+        u4 a = *reinterpret_cast<const u4*>(band + off), b = *reinterpret_cast<const u4*>(band + (off ^ 64));
+        a &= keep;
+        b &= keep;
+        fah[i] = __builtin_bit_cast(bf16x8, a);
+        fal[i] = __builtin_bit_cast(bf16x8, b);
+      }
+    };
+    auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
+      constexpr int half = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (ABL == 2) {  // keep the reads alive, drop the matrix work
+            asm volatile("" ::"v"(fal[i]), "v"(fah[i]), "v"(fbh[j]), "v"(fbl[j]));
+            continue;
+          }
+          f32x4v c = acc[half * MH + i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
+          acc[half * MH + i][j] = c;
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    const bool late = STG && wave >= NW / 2;
+    int tap = 0, kw = 0, bbuf = 0, wst = 0;  // tap = 3 kh + kw of this K-step, its band's ring slot, its weight stage
+    auto advance = [&]() {
+      wst = wst == 2 ? 0 : wst + 1;
+      if (++kw == 3) {
+        kw = 0;
+        bbuf = bbuf == 2 ? 0 : bbuf + 1;
+      }
+      if (++tap == 9) tap = 0;
+    };
+    if (!late) {
+      for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* band = smem + bbuf * RBAND;
+        const unsigned char* bh = bst + wst * RBST;
+        bf16x8 fbh[NJ], fbl[NJ];
+        read_b(bh, fbh, fbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(band, kw, tap, H0{}, fah, fal);
+          mma(H0{}, fah, fal, fbh, fbl);
+        }
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(band, kw, tap, H1{}, fah, fal);
+          mma(H1{}, fah, fal, fbh, fbl);
+        }
+        advance();
+      }
+    } else {
+      bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
+      auto step = [&](auto carried_c) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* band = smem + bbuf * RBAND;
+        const unsigned char* bh = bst + wst * RBST;
+        if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(bh, gbh, gbl);
+        {
+          bf16x8 fah[MH], fal[MH];
+          read_a(band, kw, tap, H0{}, fah, fal);
+          mma(H0{}, fah, fal, gbh, gbl);
+        }
+        read_a(band, kw, tap, H1{}, gah, gal);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the next barrier
+        advance();
+      };
+      step(H0{});
+      for (int kt = 1; kt < KT; ++kt) step(H1{});
+      mma(H1{}, gah, gal, gbh, gbl);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the bands: they become the epilogue's fp32 tile
+    if (wide_epilogue_ok(p)) {  // block-uniform
+      float* tile_f = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = wm * 64 + i * 16 + 4 * q + reg;
+            const int col = (wn * 64 + j * 16 + r) ^ (((row >> 2) & 1) << 5);
+            tile_f[row * BN + col] = acc[i][j][reg];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+    } else {
+      __builtin_amdgcn_s_barrier();
+      conv_epilogue16<MI, NJ>(p, acc, m0 + wm * 64, n0 + wn * 64, r, q);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+  }
+}
+
+__global__ __launch_bounds__(768, 3) void conv_bf16x3b16_3x3_band(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * RBAND + 3 * RBST];
+  conv3x3_band16_body<true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_bf16x3b16_3x3_band_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * RBAND + 3 * RBST];
+  conv3x3_band16_body<true>(p, smem);
+}
+#ifdef D2T_PROBES
+template <int ABL>
+__global__ __launch_bounds__(768, 3) void conv_bf16x3b16_probe(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * RBAND + 3 * RBST];
+  conv3x3_band16_body<true, ABL>(p, smem);
+}
+#endif
+
 __global__ __launch_bounds__(768, 3) void conv_bf16x3q16_3x3_patch(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[160 * 1024];
   conv3x3_patch16_body<true>(p, smem);
@@ -1203,6 +1657,28 @@ __global__ __launch_bounds__(768, 3) void conv_bf16x3p16_256x128(const ConvP p) 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
   conv_bf16x3p16_body<256, 128, 4, 2, 4, false>(p, smem);
 }
+
+// 256 x 256 tile, eight waves (two per SIMD, 256 VGPRs), p.pipelined == 7
+__global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 256 * PROW + 2 * 256 * PROW)];
+  conv_bf16x3w16_body<true>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 256 * PROW + 2 * 256 * PROW)];
+  conv_bf16x3w16_body<true>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256_ns(const ConvP p) {  // no stagger (A/B: D2T_CONV_STAGGER=0)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 256 * PROW + 2 * 256 * PROW)];
+  conv_bf16x3w16_body<false>(p, smem);
+}
+
+#ifdef D2T_PROBES  // ablation probes of the 16x16x32 kernel (D2T_CONV_ABL=1|2|4): results are garbage by construction
+template <int ABL>
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p16_probe(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 256 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, true, ABL>(p, smem);
+}
+#endif
 
 // the same without dedicated loader waves: 8 waves (2 per SIMD), the compute waves issue the LDS-DMA themselves
 __global__ __launch_bounds__(512, 2) void conv_bf16x3p_256x128_w8(const ConvP p) {
@@ -1262,7 +1738,35 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
     else hipLaunchKernelGGL(conv_bf16x3q_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
     return hipGetLastError();
   }
-  if (p.pipelined == 3 || p.pipelined == 5) {  // the 16x16x32 builds: all rows of a layer on ONE MFMA shape (no hand-over of tail rows to the 32x32x16 kernels)
+  if (p.pipelined == 7 && p.Cout >= 256 && p.m_base == 0) {
+    // 256 x 256 tiles on eight waves for the rows that fill whole rounds of them; a last round that would be less than half
+    // full goes, as whole 256-row tile rows, to the 256 x 128 kernel (same MFMA shape, K order and products: bit-identical)
+    const int ntw = (p.Cout + 255) / 256, mtw = (p.M + 255) / 256;
+    int tw = mtw * ntw, gw = grid < tw ? grid : tw;
+    const int rounds = tw / gw, rem = tw - rounds * gw;
+    int tail_from = -1;
+    static const float tail_frac = getenv("D2T_CONV_TAIL") ? (float)atof(getenv("D2T_CONV_TAIL")) : 0.5f;
+    if (rounds >= 1 && rem > 0 && rem < tail_frac * gw) {
+      const int main_mt = rounds * gw / ntw;
+      tail_from = main_mt * 256;
+      q.M = tail_from;
+      tw = main_mt * ntw;
+      if (gw > tw) gw = tw;
+    }
+    static const int stagger_w = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
+    if (!stagger_w) hipLaunchKernelGGL(conv_bf16x3w16_256x256_ns, dim3(gw), dim3(512), 0, s, p2);
+    else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3w16_256x256_k4608, dim3(gw), dim3(512), 0, s, p2);
+    else hipLaunchKernelGGL(conv_bf16x3w16_256x256, dim3(gw), dim3(512), 0, s, p2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || tail_from < 0) return e;
+    ConvP t = p;
+    t.wave_prio = prio;
+    t.m_base = tail_from;
+    const int tt = ((p.M - tail_from + 255) / 256) * nt;
+    hipLaunchKernelGGL(conv_bf16x3p16_256x128_s, dim3(tt < grid ? tt : grid), dim3(768), 0, s, t);
+    return hipGetLastError();
+  }
+  if (p.pipelined == 3 || p.pipelined == 5 || p.pipelined == 6 || p.pipelined == 7) {  // the 16x16x32 builds: all rows of a layer on ONE MFMA shape (no hand-over of tail rows to the 32x32x16 kernels)
     // 5: 3x3 / stride 1 / pad 1 layers on narrow maps take the patch-resident form (half the LDS-DMA pieces per K-step);
     // bit-identical to the plain 16x16x32 kernel, so the choice never shows in the values
     if (p.pipelined == 5 && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PH == 1 && p.PW == 1 && p.OH == p.H && p.OW == p.W &&
@@ -1273,8 +1777,37 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
       else hipLaunchKernelGGL(conv_bf16x3q16_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
       return hipGetLastError();
     }
+    tiles = ((p.M - p.m_base + 255) / 256) * nt;
     if (grid > tiles) grid = tiles;
+    // 6: 3x3 / stride 1 / pad 1 layers (any width) keep a band of input records in LDS for the three taps of a filter row
+    if (p.pipelined == 6 && p.m_base == 0 && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PH == 1 && p.PW == 1 && p.OH == p.H && p.OW == p.W &&
+        p.Cin % 32 == 0 && !p.pool2 && !p.Cin2) {
+#ifdef D2T_PROBES
+      if (abl_probe()) {
+        switch (abl_probe()) {
+          case 1: hipLaunchKernelGGL(conv_bf16x3b16_probe<1>, dim3(grid), dim3(768), 0, s, p2); break;
+          case 2: hipLaunchKernelGGL(conv_bf16x3b16_probe<2>, dim3(grid), dim3(768), 0, s, p2); break;
+          default: hipLaunchKernelGGL(conv_bf16x3b16_probe<4>, dim3(grid), dim3(768), 0, s, p2); break;
+        }
+        return hipGetLastError();
+      }
+#endif
+      if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3b16_3x3_band_k4608, dim3(grid), dim3(768), 0, s, p2);
+      else hipLaunchKernelGGL(conv_bf16x3b16_3x3_band, dim3(grid), dim3(768), 0, s, p2);
+      return hipGetLastError();
+    }
     static const int stagger16 = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
+#ifdef D2T_PROBES
+    if (abl_probe()) {
+      switch (abl_probe()) {
+        case 1: hipLaunchKernelGGL(conv_bf16x3p16_probe<1>, dim3(grid), dim3(768), 0, s, p2); break;
+        case 2: hipLaunchKernelGGL(conv_bf16x3p16_probe<2>, dim3(grid), dim3(768), 0, s, p2); break;
+        case 8: hipLaunchKernelGGL(conv_bf16x3p16_probe<8>, dim3(grid), dim3(768), 0, s, p2); break;
+        default: hipLaunchKernelGGL(conv_bf16x3p16_probe<4>, dim3(grid), dim3(768), 0, s, p2); break;
+      }
+      return hipGetLastError();
+    }
+#endif
     if (!stagger16) hipLaunchKernelGGL(conv_bf16x3p16_256x128, dim3(grid), dim3(768), 0, s, p2);
     else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_bf16x3p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);

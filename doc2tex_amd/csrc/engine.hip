@@ -205,7 +205,7 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   else HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
   // the two 2x2 / stride 2 max-pools (resnet.py:94,106) run inside the epilogue of the convolution in front of them on the
   // split-record path with the 16x16x32 kernels: conv0_2 writes 268 MB instead of 1.07 GB and no pool kernel re-reads it
-  const bool fuse_pool = sp && c->conv_pipelined == 3 && !c->no_pool_fusion;
+  const bool fuse_pool = sp && (c->conv_pipelined == 3 || c->conv_pipelined >= 6) && !c->no_pool_fusion;
   x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, fuse_pool);
   auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
     Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
@@ -218,7 +218,7 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   auto stage = [&](int li) {
     for (const Block& b : c->layers[li]) {
       Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
-      if (b.has_down && b.c2cat.w && sp && c->conv_pipelined == 3 && b.c2.Cout >= 128 && !c->no_shortcut_fusion) {
+      if (b.has_down && b.c2cat.w && sp && (c->conv_pipelined == 3 || c->conv_pipelined >= 6) && b.c2.Cout >= 128 && !c->no_shortcut_fusion) {
         // the 1x1 shortcut inside conv2's launch: K-steps over x appended behind the taps over t, one accumulator, no residual
         ConvP ex{};
         ex.in2_hi = x.planes();
@@ -2024,8 +2024,8 @@ int d2t_set_reserved_cus(d2t_ctx* c, int32_t cus) {
 
 int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   DevGuard dg_(c);
-  if (!c || kind < 0 || kind > 5 || kind == 4)
-    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs) or 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps)");
+  if (!c || kind < 0 || kind > 7 || kind == 4)
+    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs), 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps) 6 (3, with the band-resident 16x16x32 kernel for every 3x3 / stride 1 / pad 1 layer) or 7 (3, with 256x256 tiles on eight waves for layers of at least 256 output channels)");
   c->conv_pipelined = kind;
   return D2T_OK;
 }
@@ -2144,7 +2144,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 5 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
+  if (kind < 0 || kind > 7 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;

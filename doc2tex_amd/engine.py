@@ -291,7 +291,7 @@ class Engine:
     def set_conv_kernel(self, kind):
         """'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs), 'pipelined' (32x32x16 MFMAs),
         'patch' (pipelined + patch-resident 3x3 kernel) or 'classic' (128x128, two blocks per CU)."""
-        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3, "patch16": 5}[kind]), "set_conv_kernel")
+        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3, "patch16": 5, "band16": 6, "wide16": 7}[kind]), "set_conv_kernel")
 
     def set_beam_shared_tile(self, on):
         """Beam search: one cross-attention block per sample serving all its hypotheses from one staged memory tile (beam <= 6)."""

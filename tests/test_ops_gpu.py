@@ -252,6 +252,7 @@ def test_conv_bf16x3_large_tiles():
     (1, 5, 9, 64, 128, (2, 2), (2, 2), (0, 0), False),       # 8 output rows
     (3, 9, 131, 64, 256, (3, 3), (1, 1), (1, 1), True),      # the widest map the patch-resident kernel takes (W = 131)
     (5, 13, 50, 96, 128, (3, 3), (1, 1), (1, 1), False),     # three channel chunks, tiles that straddle images and rows
+    (33, 16, 129, 64, 512, (3, 3), (1, 1), (1, 1), True),    # 267 x 2 tiles of 256 x 256: one whole round + 11 tile rows left over
 ])
 def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     """The pipelined 256x128 kernel (default) and the 128x128 LDS-DMA kernel stage the same records and run the same three-MFMA
@@ -295,9 +296,31 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
         y16p = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
         assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16p), B, H, W,
                                               Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
+        # kind 6: the band-resident 16x16x32 kernel (every 3x3 / stride 1 / pad 1 layer) -- bit-identical to kind 3, whole
+        # batch and single sample
+        assert lib.d2t_op_set_conv_kernel(6, 0) == 0
+        y16b = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16b), B, H, W,
+                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
+        y16b_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
+                                              _lib.ptr(y16b_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
+                                              _lib.stream_of(xd)) == 0
+        # kind 7: 256 x 256 tiles on eight waves (layers of at least 256 output channels; leftover tile rows on the 256 x 128
+        # kernel) -- bit-identical to kind 3, whole batch and single sample
+        assert lib.d2t_op_set_conv_kernel(7, 0) == 0
+        y16w = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16w), B, H, W,
+                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
+        y16w_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
+                                              _lib.ptr(y16w_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
+                                              _lib.stream_of(xd)) == 0
         torch.cuda.synchronize()
         y16, y16_0 = y16.cpu(), y16_0.cpu()
         assert torch.equal(y16p.cpu(), y16)
+        assert torch.equal(y16b.cpu(), y16) and torch.equal(y16b_0.cpu(), y16_0)
+        assert torch.equal(y16w.cpu(), y16) and torch.equal(y16w_0.cpu(), y16_0)
     finally:
         lib.d2t_op_set_conv_kernel(3, 0)
     assert torch.isfinite(outs[0]).all()

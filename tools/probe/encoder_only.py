@@ -21,3 +21,23 @@ with torch.no_grad():
     torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"encoder alone: {dt * 1e3:.2f} ms per batch of 64 = {64 / dt:.0f} formulas/s")
+
+# per-layer table of the encoder's GEMM launches (HIP events on the launch stream, d2t_profile_*), encoder alone
+eng = m.engine()
+eng.profile(True)
+with torch.no_grad():
+    for _ in range(10):
+        m.forward_encoder(img)
+torch.cuda.synchronize()
+eng.profile(False)
+import collections
+acc = collections.OrderedDict()
+for M, N, K, ms in eng.profile_read(16384):
+    a = acc.setdefault((M, N, K), [0, 0.0])
+    a[0] += 1
+    a[1] += ms
+tot = sum(v[1] for v in acc.values()) / 10
+print(f"GEMM launches: {tot:.2f} ms per forward")
+print(f"{'M':>8} {'N':>5} {'K':>5} {'per fwd':>7} {'avg ms':>8} {'ms/fwd':>7} {'TFLOP/s':>8} {'of 2500':>7}")
+for (M, N, K), (n, ms) in acc.items():
+    print(f"{M:8d} {N:5d} {K:5d} {n / 10:7.1f} {ms / n:8.4f} {ms / 10:7.3f} {2.0 * M * N * K / (ms / n) / 1e9:8.1f} {2.0 * M * N * K / (ms / n) / 1e9 / 2500:7.3f}")

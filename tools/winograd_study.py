@@ -67,6 +67,15 @@ def conv_winograd(x, w, b):
     return Y + b.view(1, -1, 1, 1)
 
 
+def conv_fp16x2(x, w, b, stride, padding):
+    """What a two-MFMA form would compute: activations rounded ONCE to fp16 (11 significant bits), weights as fp16 hi + fp16 lo
+    (22 bits); products of fp16 values are exact in fp32, sums are fp32.  (`python tools/winograd_study.py --fp16x2 ...`)"""
+    xh = x.to(torch.float16).to(torch.float32)
+    wh = w.to(torch.float16).to(torch.float32)
+    wl = (w - wh).to(torch.float16).to(torch.float32)
+    return F.conv2d(xh, wl, None, stride, padding) + F.conv2d(xh, wh, b, stride, padding)
+
+
 def make_conv_bn(arm):
     def _conv_bn(x, sd, conv, bn, stride=1, padding=0, faithful=True, bn_train=None):
         w = sd[conv + ".weight"]
@@ -77,12 +86,16 @@ def make_conv_bn(arm):
         pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
         if arm == "winograd" and tuple(w.shape) == (512, 512, 3, 3) and s == (1, 1) and pd == (1, 1):
             return conv_winograd(x, wf, bf)
+        if arm == "fp16x2":
+            return conv_fp16x2(x, wf, bf, stride, padding)
         return conv_direct(x, wf, bf, stride, padding)
     return _conv_bn
 
 
 def main():
-    names = sys.argv[1:] or ["c2_greedy", "c2_small_crop", "c4_greedy_160", "c4_greedy_96"]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    arms = ("fp32", "direct", "fp16x2") if "--fp16x2" in sys.argv[1:] else ("fp32", "direct", "winograd")
+    names = args or ["c2_greedy", "c2_small_crop", "c4_greedy_160", "c4_greedy_96"]
     with open(os.path.join(GOLD, "cases.json")) as f:
         cases = json.load(f)
     with open(os.path.join(GOLD, "manifests.json")) as f:
@@ -98,24 +111,28 @@ def main():
         img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
         text = torch.full((c["B"], 1), R.GO, dtype=torch.long)
         steps = z["logit_steps"].tolist()
-        for arm in ("fp32", "direct", "winograd"):
+        for arm in arms:
             R._conv_bn = make_conv_bn(arm)
             STATS["winograd_layers"] = 0
             t0 = time.time()
+            relu = F.relu
+            if arm == "fp16x2":  # feature maps are STORED as fp16 records: residual sources and pool inputs are rounded too
+                F.relu = lambda x, *a, **k: relu(x, *a, **k).to(torch.float16).to(torch.float32) if x.dim() == 4 else relu(x, *a, **k)
             try:
                 with torch.no_grad():
                     p, l, _ = R.forward(cfg, sd, img, text, is_test=c["is_test"], faithful=False)
             finally:
                 R._conv_bn = orig
+                F.relu = relu
             same = p.shape == tuple(z["tokens"].shape) and bool(np.array_equal(p.numpy(), z["tokens"]))
             dl = float(np.abs(l[:, steps].numpy() - z["logits_sample"]).max()) if p.shape[1] == z["tokens"].shape[1] else float("nan")
             gap = float(z["top2_gap"].min()) if "top2_gap" in z.files else float("nan")
             rows.append((name, arm, same, dl, gap, STATS["winograd_layers"], time.time() - t0))
             print(f"{name:16s} {arm:9s} tokens exact: {same}  max |dlogit| {dl:.3e}  (smallest top-2 gap of the fixture {gap:.2e}; "
                   f"{STATS['winograd_layers']} Winograd layers; {time.time() - t0:.0f} s)", flush=True)
-    wino = [r for r in rows if r[1] == "winograd"]
+    wino = [r for r in rows if r[1] == arms[-1]]
     go = all(r[2] for r in wino) and max(r[3] for r in wino) <= 2e-4
-    print("verdict on numerics:", "GO" if go else "NO-GO", f"(worst winograd |dlogit| {max(r[3] for r in wino):.3e}, "
+    print("verdict on numerics:", "GO" if go else "NO-GO", f"(worst {arms[-1]} |dlogit| {max(r[3] for r in wino):.3e}, "
           f"worst direct {max(r[3] for r in rows if r[1] == 'direct'):.3e})")
 
 
