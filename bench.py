@@ -373,18 +373,21 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
         dom_flop = 2.0 * dom[0] * dom[1] * dom[2]
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(precision)
-        bf = precision == "bf16x3"
+        f16 = precision == "fp16x2"
+        bf = precision == "bf16x3" or f16  # (16-bit matrix-core operands: the bf16 / fp16 dense peak)
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
-            "kernel": (_PMC.get("kernel_short") or ("split-bf16 implicit-GEMM convolution, pipelined 256x128 kernel" if bf
+            "kernel": ("fp16x2 implicit-GEMM convolution (fp16 records x fp16 hi / lo weights), pipelined 256x128 kernel on "
+                       "v_mfma_f32_16x16x32_f16" if f16 else
+                       _PMC.get("kernel_short") or ("split-bf16 implicit-GEMM convolution, pipelined 256x128 kernel" if bf
                                                       else "conv_mfma_kernel<128,128>")) +
                       (" (512->512 3x3 conv @16x129 as implicit GEMM)" if tuple(dom) == (132096, 512, 4608)
                        else f" (the most expensive GEMM shape of the timed region, M x N x K = {dom[0]} x {dom[1]} x {dom[2]})"),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
             "traffic_source": traffic_src,
-            "peak_dtype": "bf16 dense MFMA" if bf else "fp32 MFMA",
+            "peak_dtype": ("fp16 dense MFMA" if f16 else "bf16 dense MFMA") if bf else "fp32 MFMA",
             "gemm_MNK": list(dom), "flop_per_launch": dom_flop, "avg_launch_ms": round(dom_ms, 4),
             "launches_timed": len(by_shape[dom]),
             "share_of_gemm_time": round(sum(by_shape[dom]) / total_ms, 4),
@@ -393,12 +396,13 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
         }
         if tuple(dom) != (132096, 512, 4608):  # the committed counter passes describe the headline shape only
             roofline["traffic"], roofline["traffic_source"] = None, None
-        elif _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
+        elif not f16 and _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
             roofline["mfma_busy_frac_pmc"] = round(_PMC["mfma_busy_frac"], 4)
             roofline["kernel_alone_ms_rocprof"] = round(_PMC.get("kernel_trace_avg_ms", 0.0), 4)
-        if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
-            roofline["mfma_issued_tflops"] = round(3 * achieved, 2)
-            roofline["mfma_issued_frac"] = round(3 * achieved / peak, 4)
+        if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi), or two fp16 ones (x*lo + x*hi)
+            per = 2 if f16 else 3
+            roofline["mfma_issued_tflops"] = round(per * achieved, 2)
+            roofline["mfma_issued_frac"] = round(per * achieved / peak, 4)
         if os.environ.get("D2T_BENCH_SHAPES"):  # per-shape table of the timed region (in situ: beside the decode streams)
             for shp, v in sorted(by_shape.items(), key=lambda kv: -sum(kv[1])):
                 log(f"  GEMM {shp}: {len(v) // max(1, steps)} launches/step, avg {sum(v) / len(v) * 1e3:.0f} us, "
@@ -436,6 +440,20 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
                     "what": "same workload and serving configuration with exact fp32 arithmetic on the fp32-input MFMA "
                             "(v_mfma_f32_32x32x2_f32) everywhere",
                     "roofline": roofline_of(r3, "fp32", k3)}
+            if name in ("C2", "C4"):  # fp16x2 arithmetic: validated on the HybridViT configs (tests), opt-in
+                model.conv_precision = "fp16x2"
+                e4, r4, o4 = timed(steps, 2)
+                model.conv_precision = args.precision
+                if rank == 0:
+                    secondary["fp16x2"] = {
+                        "value": round(world * B * steps / e4, 2), "unit": "formulas/s", "ms_per_step": round(e4 / steps * 1e3, 3),
+                        "steps": steps, "dtype": "fp16x2",
+                        "what": "same workload and serving configuration with the backbone's feature maps kept as fp16 records and "
+                                "its convolutions as x16 * w_lo + x16 * w_hi (two MFMAs per product instead of three); opt-in "
+                                "(Model.conv_precision = 'fp16x2'): tokens exact and logits within 1e-3 on the HybridViT fixtures, "
+                                "not on the ResNet-only configs",
+                        "roofline": roofline_of(r4, "fp16x2", steps),
+                        "_out": (o4[0], o4[1])}
 
     if rank == 0:
         T = model.engine().encoder_shape(H, W)[0]
@@ -453,7 +471,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3" if bf else "f32", "data": "synthetic",
+            "dtype": "bf16x3" if bf else ("fp16x2" if args.precision == "fp16x2" else "f32"), "data": "synthetic",
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
@@ -539,8 +557,9 @@ def main():
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="convolution arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product)")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "fp16x2"],
+                    help="convolution arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs per product), or fp16 feature maps x fp16 "
+                         "hi / lo weights in the backbone (2 MFMAs per product; HybridViT configs: see DESIGN.md)")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16", "band16", "wide16"],
@@ -655,6 +674,17 @@ def main():
                                     "what": f"rows 0..{n - 1} of the last batch of the timed region (pipelined, decode groups of "
                                             f"{result['config']['decode_group']}) against oracle/restatement.py (KV-cached mode) on the "
                                             "same crops and weights"}
+        f16s = result.get("secondary", {}).get("fp16x2")
+        if f16s:  # the fp16x2 run proves its answers the same way (or carries none)
+            o4 = f16s.pop("_out")
+            if "parity" in result:
+                n = args.cpu_sample
+                exact = bool(torch.equal(o4[0][:n].cpu(), answers[0]))
+                dl = float((o4[1][:n].cpu() - answers[1]).abs().max())
+                f16s["parity"] = {"rows": n, "tokens_exact": exact, "max_abs_dlogit": float(f"{dl:.3e}"), "tolerance": 1e-3,
+                                  "all_rows_equal_the_headline_tokens": bool(torch.equal(o4[0].cpu(), out[0].cpu()))}
+                if not (exact and dl <= 1e-3):
+                    f16s["value"] = None  # a number without its parity is not a measurement
         if world == 1 and name == "C2" and not early and not args.no_secondary:
             result.setdefault("secondary", {}).update(other_configs(args, dev))
         print(json.dumps(result), flush=True)

@@ -15,7 +15,7 @@ ENC_RESNET, ENC_HYBRID_VIT, ENC_VGG_BILSTM, ENC_RESNET_BILSTM = 0, 1, 2, 3
 DEC_TFM, DEC_ATTN = 0, 1
 ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-CONV_FP32, CONV_BF16X3 = 0, 1
+CONV_FP32, CONV_BF16X3, CONV_FP16X2 = 0, 1, 2
 ATTN_CELL_LOCATION, ATTN_CELL_BAHDANAU = 0, 1
 
 

@@ -267,7 +267,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 2) void conv_bf16x3_kerne
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-template <int BM, int BN, int WM>  // wave grid WM x 2
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 (ConvP::f16, fp16x2 mode): the A records hold fp16 in their hi half (no lo plane is staged or read), the weight planes
+// are fp16 hi / lo, a product is x * w_lo + x * w_hi on v_mfma_f32_32x32x16_f16
+template <int BM, int BN, int WM, bool F16 = false>  // wave grid WM x 2
 __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char* smem) {
   constexpr int NW = WM * 2;
   constexpr int WTM = BM / WM, WTN = BN / 2;
@@ -342,7 +346,7 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
       const uint16_t* src = ok ? p.in_hi + (a_off[j] + tapoff) : zero;
       const int piece = (wave * AJ + j) * 1024;
       __builtin_amdgcn_global_load_lds(src, (lds_ptr)(ah + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(ok ? src + 32 : zero, (lds_ptr)(al + piece), 16, 0, 0);
+      if (!F16) __builtin_amdgcn_global_load_lds(ok ? src + 32 : zero, (lds_ptr)(al + piece), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -387,7 +391,7 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
         const int row = wm * WTM + i * 32 + r;
         const int off = row * XROW + swz_chunk(row, c) * 16;
         fah[i] = *reinterpret_cast<const bf16x8*>(ah + off);
-        fal[i] = *reinterpret_cast<const bf16x8*>(al + off);
+        if (!F16) fal[i] = *reinterpret_cast<const bf16x8*>(al + off);
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -400,6 +404,12 @@ __device__ __forceinline__ void conv_bf16x3g_body(const ConvP& p, unsigned char*
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+          if (F16) {
+            const f16x8 xa = __builtin_bit_cast(f16x8, fah[i]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, __builtin_bit_cast(f16x8, fbl[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, __builtin_bit_cast(f16x8, fbh[j]), acc[i][j], 0, 0, 0);
+            continue;
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
@@ -438,6 +448,16 @@ __global__ __launch_bounds__(256, 3) void conv_bf16x3g_128x64(const ConvP p) {
   conv_bf16x3g_body<128, 64, 2>(p, smem);
 }
 
+// fp16x2 builds (ConvP::f16)
+__global__ __launch_bounds__(256, 3) void conv_f16x2g_128x64(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 64 * XROW)];
+  conv_bf16x3g_body<128, 64, 2, true>(p, smem);
+}
+__global__ __launch_bounds__(512, 4) void conv_f16x2g_128x128_w8(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * 128 * XROW + 2 * 128 * XROW)];
+  conv_bf16x3g_body<128, 128, 4, true>(p, smem);
+}
+
 // The 128-row LDS-DMA kernels over output rows [p.m_base, p.M) with a column tile of `bn` (64 | 128): the pipelined kernel
 // hands the rows of its last, partial round of tiles to this one (conv_bf16x3p.hip).
 hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s) {
@@ -462,6 +482,7 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
   if (p.Cin2 && (!p.in_hi || !p.in2_hi || p.Cin2 % XBK || p.Cout < 128 || (p.pipelined != 3 && p.pipelined != 6 && p.pipelined != 7) || p.pool2 ||
                  p.OH != p.H || p.OW != p.W))
     return hipErrorInvalidValue;
+  if (p.f16 && (!p.in_hi || (p.Cout >= 128 && p.pipelined != 3))) return hipErrorInvalidValue;  // fp16 records: split-record kernels only
   const int mt = (p.M + 127) / 128;
   if (p.in_hi) {  // split-bf16 input planes
     if (!p.zero16 || p.KH * p.KW > 16 || (long long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -476,11 +497,13 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
       // grid is not capped (no slots reserved for the decode stream): 1.35 -> 0.96 ms alone.  With a cap it stays at
       // the cap (three per CU measured 0.5 % slower end to end in pipelined serving).
       const int grid3 = grid;
-      hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid3), dim3(256), 0, s, p);
+      if (p.f16) hipLaunchKernelGGL(conv_f16x2g_128x64, dim3(grid3), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid3), dim3(256), 0, s, p);
     } else {
       // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
       static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
-      if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(grid), dim3(256), 0, s, p);
+      if (p.f16) hipLaunchKernelGGL(conv_f16x2g_128x128_w8, dim3(grid), dim3(512), 0, s, p);
+      else if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(grid), dim3(256), 0, s, p);
       else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3g_128x128_w8_k4608, dim3(grid), dim3(512), 0, s, p);
       else hipLaunchKernelGGL(conv_bf16x3g_128x128_w8, dim3(grid), dim3(512), 0, s, p);
     }
@@ -508,31 +531,39 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, uint16_t* __restr
     lo[i] = *reinterpret_cast<const uint16_t*>(&l);
   }
 }
-__global__ void split_act_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t rows, int C) {
+__global__ void split_f16_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = w[i];
+    const uint16_t h = f32_to_f16_bits(x);
+    hi[i] = h;
+    lo[i] = f32_to_f16_bits(x - f16_bits_to_f32(h));
+  }
+}
+__global__ void split_act_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t rows, int C, int f16) {
   const size_t n = rows * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint16_t hi, lo;
-    split_f32(x[i], hi, lo);
+    split_rec(x[i], hi, lo, f16);
     const size_t o = plane_idx(i / C, (int)(i % C), C);
     planes[o] = hi;
     planes[o + 32] = lo;
   }
 }
-__global__ void merge_act_kernel(const uint16_t* __restrict__ planes, float* __restrict__ x, size_t rows, int C) {
+__global__ void merge_act_kernel(const uint16_t* __restrict__ planes, float* __restrict__ x, size_t rows, int C, int f16) {
   const size_t n = rows * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t o = plane_idx(i / C, (int)(i % C), C);
-    x[i] = bf16_bits_to_f32(planes[o]) + bf16_bits_to_f32(planes[o + 32]);
+    x[i] = join_rec(planes[o], planes[o + 32], f16);
   }
 }
 // the same, eight channels per thread: two 16-byte loads, one 16-byte store into each half of the record (C % 32 == 0)
-__global__ void split_act8_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t n8) {
+__global__ void split_act8_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes, size_t n8, int f16) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint16_t hi[8], lo[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) split_f32(v[k], hi[k], lo[k]);
+    for (int k = 0; k < 8; ++k) split_rec(v[k], hi[k], lo[k], f16);
     // element e = 8 i of the row-major [rows][C] tensor lies in record e / 32 at position e % 32 (C % 32 == 0)
     const size_t rec = i >> 2, pos = (i & 3) * 8;
     uint16_t* dst = planes + rec * 64 + pos;
@@ -542,25 +573,30 @@ __global__ void split_act8_kernel(const float* __restrict__ x, uint16_t* __restr
                                                      lo[4] | (uint32_t)lo[5] << 16, lo[6] | (uint32_t)lo[7] << 16);
   }
 }
-hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s) {
+hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s, int f16) {
   const size_t n = rows * C;
   if (C % 32 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     const size_t n8 = n / 8;
     hipLaunchKernelGGL(split_act8_kernel, dim3((unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192)), dim3(256), 0, s, x,
-                       planes, n8);
+                       planes, n8, f16);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
-                     s, x, planes, rows, C);
+                     s, x, planes, rows, C, f16);
   return hipGetLastError();
 }
-hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s) {
+hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s, int f16) {
   const size_t n = rows * C;
   hipLaunchKernelGGL(merge_act_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
-                     s, planes, x, rows, C);
+                     s, planes, x, rows, C, f16);
   return hipGetLastError();
 }
 
+hipError_t launch_split_f16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
+                     s, w, hi, lo, n);
+  return hipGetLastError();
+}
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0,
                      s, w, hi, lo, n);

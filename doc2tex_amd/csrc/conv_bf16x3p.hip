@@ -85,12 +85,22 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
       v[0] += r0.x, v[1] += r0.y, v[2] += r0.z, v[3] += r0.w, v[4] += r1.x, v[5] += r1.y, v[6] += r1.z, v[7] += r1.w;
     }
     if (res_hi) {
-      const uint4 rh = *reinterpret_cast<const uint4*>(res_hi + pi), rl = *reinterpret_cast<const uint4*>(res_hi + pi + 32);
-      const unsigned h[4] = {rh.x, rh.y, rh.z, rh.w}, l[4] = {rl.x, rl.y, rl.z, rl.w};
+      const uint4 rh = *reinterpret_cast<const uint4*>(res_hi + pi);
+      const unsigned h[4] = {rh.x, rh.y, rh.z, rh.w};
+      if (p.f16) {  // fp16 records: the value is the hi half
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
-        v[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += f16_bits_to_f32((uint16_t)(h[e] & 0xFFFFu));
+          v[2 * e + 1] += f16_bits_to_f32((uint16_t)(h[e] >> 16));
+        }
+      } else {
+        const uint4 rl = *reinterpret_cast<const uint4*>(res_hi + pi + 32);
+        const unsigned l[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += __uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16);
+          v[2 * e + 1] += __uint_as_float(h[e] & 0xFFFF0000u) + __uint_as_float(l[e] & 0xFFFF0000u);
+        }
       }
     }
 #pragma unroll
@@ -98,14 +108,14 @@ __device__ __forceinline__ void epilogue_rows(const ConvP& p, const unsigned cha
     if (out_hi) {
       uint16_t hi[8], lo[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) split_f32(v[e], hi[e], lo[e]);
+      for (int e = 0; e < 8; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
       uint4 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       oh.z = (unsigned)hi[4] | ((unsigned)hi[5] << 16), oh.w = (unsigned)hi[6] | ((unsigned)hi[7] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
       ol.z = (unsigned)lo[4] | ((unsigned)lo[5] << 16), ol.w = (unsigned)lo[6] | ((unsigned)lo[7] << 16);
       *reinterpret_cast<uint4*>(out_hi + pi) = oh;
-      *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;
+      if (!p.f16) *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;  // (fp16 records: the lo half is never read)
     } else {
       *reinterpret_cast<float4*>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(out + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -152,14 +162,14 @@ __device__ __forceinline__ void epilogue_rows_pool(const ConvP& p, const unsigne
     if (out_hi) {
       uint16_t hi[8], lo[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) split_f32(v[e], hi[e], lo[e]);
+      for (int e = 0; e < 8; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
       uint4 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       oh.z = (unsigned)hi[4] | ((unsigned)hi[5] << 16), oh.w = (unsigned)hi[6] | ((unsigned)hi[7] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
       ol.z = (unsigned)lo[4] | ((unsigned)lo[5] << 16), ol.w = (unsigned)lo[6] | ((unsigned)lo[7] << 16);
       *reinterpret_cast<uint4*>(out_hi + pi) = oh;
-      *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;
+      if (!p.f16) *reinterpret_cast<uint4*>(out_hi + pi + 32) = ol;  // (fp16 records: the lo half is never read)
     } else {
       *reinterpret_cast<float4*>(out + mp * p.Cout + n) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(out + mp * p.Cout + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -195,13 +205,13 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP& p, float __attribut
         if (p.res) v += p.res[off];
         if (p.res_hi) {
           const size_t ri = plane_idx(row, n, p.Cout);
-          v += bf16_bits_to_f32(p.res_hi[ri]) + bf16_bits_to_f32(p.res_hi[ri + 32]);
+          v += join_rec(p.res_hi[ri], p.res_hi[ri + 32], p.f16);
         }
         v = apply_act(v, p.act);
         if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
         if (p.out_hi) {
           uint16_t hi, lo;
-          split_f32(v, hi, lo);
+          split_rec(v, hi, lo, p.f16);
           const size_t oi = plane_idx(row, n, p.Cout);
           p.out_hi[oi] = hi;
           p.out_hi[oi + 32] = lo;
@@ -221,10 +231,13 @@ __device__ __forceinline__ void conv_epilogue16(const ConvP& p, float __attribut
 // -- on the source side of the DMA and on the ds_read side -- so that the 16-lane groups of a ds_read_b128 hit every bank once.
 __device__ __forceinline__ int aswz(int row, int c) { return c ^ ((row >> 1) & 7); }
 
-template <int BM, int BN, int LW, int ABL, bool S16 = false>
+// F16 (ConvP::f16): only the hi half of a record (the fp16 activation) is staged -- a piece is 16 rows x 64 B, the A plane
+// BM x 64 B with the B planes' swizzle (pswz16)
+template <int BM, int BN, int LW, int ABL, bool S16 = false, bool F16 = false>
 struct DmaIssuer {
-  static constexpr int AJ = BM / (8 * LW), BJ = BN / (16 * LW);
-  static constexpr int PLANE_A = BM * PROW, PLANE_B = BN * PROW, STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  static constexpr int AJ = BM / ((F16 ? 16 : 8) * LW), BJ = BN / (16 * LW);
+  static constexpr int PLANE_A = BM * PROW, PLANE_B = BN * PROW, STAGE = (F16 ? 1 : 2) * PLANE_A + 2 * PLANE_B;
+  static constexpr int A_BYTES = (F16 ? 1 : 2) * PLANE_A;
   static constexpr int PER_STEP = AJ + 2 * BJ;  // LDS-DMA instructions per K-step
   static_assert(AJ >= 1 && BJ >= 1, "tile too small for the issuing waves");
   static_assert(PER_STEP <= 31, "two K-steps of pieces must fit the 6-bit vmcnt");
@@ -242,8 +255,8 @@ struct DmaIssuer {
     const int ohow = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int row = (lw * AJ + j) * 8 + (lane >> 3);
-      const int c = aswz(row, lane & 7);  // the chunk of the record that belongs at LDS position lane & 7 of this row
+      const int row = F16 ? (lw * AJ + j) * 16 + (lane >> 2) : (lw * AJ + j) * 8 + (lane >> 3);
+      const int c = F16 ? pswz16(row, lane & 3) : aswz(row, lane & 7);  // the chunk of the record that belongs at this lane's LDS position
       const int m = m0 + row;
       a_off[j] = 0;
       a_off2[j] = -1;
@@ -272,7 +285,7 @@ struct DmaIssuer {
   // K-steps must be issued in order (the tap / channel-chunk cursor advances)
   __device__ __forceinline__ void issue(const ConvP& p, unsigned char* smem, int kt, int buf) {
     unsigned char* ah = smem + buf * STAGE;
-    unsigned char* bh = ah + 2 * PLANE_A;
+    unsigned char* bh = ah + A_BYTES;
     unsigned char* bl = bh + PLANE_B;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(p.zero16);
     const bool second = c0 >= p.Cin;  // the K-steps behind the filter taps: the 1x1 second input (wave-uniform)
@@ -512,16 +525,20 @@ __device__ __forceinline__ void conv_bf16x3p_body(const ConvP& p, unsigned char*
 // waves 4-7 carry the B fragments and the second pair of A fragments across the barrier.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, int NL, bool STG, int ABL = 0>  // ABL (probe builds): 1 no LDS-DMA, 2 no MFMA, 4 LDS-DMA never awaited
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+
+// F16 (ConvP::f16, fp16x2 mode): A = the fp16 hi halves of the records only (12 instead of 16 fragment reads, 8 instead of
+// 12 LDS-DMA pieces per loader and K-step), B = fp16 hi / lo planes, 32 MFMAs (x * w_lo, x * w_hi) instead of 48
+template <int BM, int BN, int WM, int WN, int NL, bool STG, int ABL = 0, bool F16 = false>  // ABL (probe builds): 1 no LDS-DMA, 2 no MFMA, 4 LDS-DMA never awaited
 __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned char* smem) {
   constexpr int NW = WM * WN, NT = (NW + NL) * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
   constexpr bool UPFRONT = ABL != 8;  // (8: the reads as the compiler schedules them, for A/B timing in probe builds)
   static_assert(MI >= 2 && (MI & 1) == 0 && NJ >= 1 && NL > 0, "wave tile / loader configuration");
-  using Issuer = DmaIssuer<BM, BN, NL, ABL == 1 ? 1 : 0, true>;
-  constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, PER_STEP = Issuer::PER_STEP;
-  static_assert(BM * BN * 4 <= 3 * STAGE, "the fp32 epilogue tile must fit in the staging area");
+  using Issuer = DmaIssuer<BM, BN, NL, ABL == 1 ? 1 : 0, true, F16>;
+  constexpr int PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, PER_STEP = Issuer::PER_STEP, A_BYTES = Issuer::A_BYTES;
+  static_assert(F16 || BM * BN * 4 <= 3 * STAGE, "the fp32 epilogue tile must fit in the staging area");  // (F16: the kernel allocates the tile's 128 KB)
 
   const int nt = (p.Cout + BN - 1) / BN;
   const int ntiles = nt * ((p.M - p.m_base + BM - 1) / BM);  // rows [m_base, M): the rows a 256 x 256 launch left over
@@ -564,8 +581,8 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = wm * WTM + i * 16 + r;
-      offa[i] = row * 128 + aswz(row, q) * 16;
-      offal[i] = row * 128 + aswz(row, 4 + q) * 16;
+      offa[i] = F16 ? row * PROW + pswz16(row, q) * 16 : row * 128 + aswz(row, q) * 16;
+      offal[i] = row * 128 + aswz(row, 4 + q) * 16;  // (unused with F16)
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -573,7 +590,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       offb[j] = row * PROW + pswz16(row, q) * 16;
     }
     auto read_b = [&](const unsigned char* ah, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
-      const unsigned char* bh = ah + 2 * PLANE_A;
+      const unsigned char* bh = ah + A_BYTES;
       const unsigned char* bl = bh + PLANE_B;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -586,7 +603,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
 #pragma unroll
       for (int i = 0; i < MH; ++i) {
         fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa[half * MH + i]);
-        fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[half * MH + i]);
+        if (!F16) fal[i] = *reinterpret_cast<const bf16x8*>(ah + offal[half * MH + i]);
       }
     };
     auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
@@ -600,6 +617,13 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
             continue;
           }
           f32x4v c = acc[half * MH + i][j];
+          if (F16) {
+            const f16x8v xa = __builtin_bit_cast(f16x8v, fah[i]);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa, __builtin_bit_cast(f16x8v, fbl[j]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa, __builtin_bit_cast(f16x8v, fbh[j]), c, 0, 0, 0);
+            acc[half * MH + i][j] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
@@ -1672,6 +1696,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256_ns(const ConvP 
   conv_bf16x3w16_body<false>(p, smem);
 }
 
+// fp16x2 builds of the pipelined kernel (ConvP::f16): 32 KB stages; the 128 KB are the epilogue's fp32 tile
+__global__ __launch_bounds__(768, 3) void conv_f16x2p16_256x128_s(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[256 * 128 * 4];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, true, 0, true>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_f16x2p16_256x128_s_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[256 * 128 * 4];
+  conv_bf16x3p16_body<256, 128, 4, 2, 4, true, 0, true>(p, smem);
+}
+
 #ifdef D2T_PROBES  // ablation probes of the 16x16x32 kernel (D2T_CONV_ABL=1|2|4): results are garbage by construction
 template <int ABL>
 __global__ __launch_bounds__(768, 3) void conv_bf16x3p16_probe(const ConvP p) {
@@ -1736,6 +1770,13 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
     if (grid > qtiles) grid = qtiles;
     if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3q_3x3_patch_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_bf16x3q_3x3_patch, dim3(grid), dim3(768), 0, s, p2);
+    return hipGetLastError();
+  }
+  if (p.f16) {  // fp16x2 mode: the pipelined 16x16x32 kernel only
+    if (p.pipelined != 3) return hipErrorInvalidValue;
+    if (grid > tiles) grid = tiles;
+    if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_f16x2p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
+    else hipLaunchKernelGGL(conv_f16x2p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);
     return hipGetLastError();
   }
   if (p.pipelined == 7 && p.Cout >= 256 && p.m_base == 0) {

@@ -21,6 +21,35 @@ __device__ __forceinline__ void split_f32(float x, uint16_t& hi, uint16_t& lo) {
   lo = *reinterpret_cast<const uint16_t*>(&l);
 }
 
+// fp16x2 mode (ConvP::f16, round 3): a record holds the activation ONCE, as fp16, in its hi half (the lo half is unused);
+// the convolution is x16 * w_lo + x16 * w_hi with the weights as fp16 hi + fp16 lo -- two MFMAs per product instead of three.
+// Values beyond the fp16 range saturate (a feature map of a trained model stays far below 65504).
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float x) {
+  const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);  // v_cvt_f16_f32: round to nearest even
+  return *reinterpret_cast<const uint16_t*>(&h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)*reinterpret_cast<const _Float16*>(&b); }
+// one element of a record: (hi, lo) <-> fp32 in either mode
+__device__ __forceinline__ void split_rec(float x, uint16_t& hi, uint16_t& lo, int f16) {
+  if (f16) { hi = f32_to_f16_bits(x); lo = 0; }
+  else split_f32(x, hi, lo);
+}
+__device__ __forceinline__ float join_rec(uint16_t hi, uint16_t lo, int f16) {
+  return f16 ? f16_bits_to_f32(hi) : bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo);
+}
+// four consecutive elements: rh / rl = the 8-byte hi / lo words of the record
+__device__ __forceinline__ void add_rec4(float (&v)[4], const uint2 rh, const uint2 rl, int f16) {
+  if (f16) {
+    v[0] += f16_bits_to_f32((uint16_t)(rh.x & 0xFFFFu)); v[1] += f16_bits_to_f32((uint16_t)(rh.x >> 16));
+    v[2] += f16_bits_to_f32((uint16_t)(rh.y & 0xFFFFu)); v[3] += f16_bits_to_f32((uint16_t)(rh.y >> 16));
+  } else {
+    v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
+    v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
+    v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
+    v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+  }
+}
+
 // Split-activation layout ("planes"): per row and per 32-channel group one 128-byte record
 // [32 x hi | 32 x lo] (bf16), so both halves of a K-step's operand share a cache line.
 // Index (in uint16 units) of the hi part of element (row, c); the lo part sits 32 elements further.
@@ -93,13 +122,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][
         if (p.res) v += p.res[off];
         if (p.res_hi) {
           const size_t ri = plane_idx(row, n, p.Cout);
-          v += bf16_bits_to_f32(p.res_hi[ri]) + bf16_bits_to_f32(p.res_hi[ri + 32]);
+          v += join_rec(p.res_hi[ri], p.res_hi[ri + 32], p.f16);
         }
         v = apply_act(v, p.act);
         if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
         if (p.out_hi) {
           uint16_t hi, lo;
-          split_f32(v, hi, lo);
+          split_rec(v, hi, lo, p.f16);
           const size_t oi = plane_idx(row, n, p.Cout);
           p.out_hi[oi] = hi;
           p.out_hi[oi + 32] = lo;
@@ -159,17 +188,14 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvP& p, f32x16 (&acc)
     }
     if (p.res_hi) {
       const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
-      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
-      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
-      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
-      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+      add_rec4(v, rh, rl, p.f16);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
@@ -223,7 +249,7 @@ __device__ __forceinline__ void conv_epilogue_wide_pool(const ConvP& p, f32x16 (
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
@@ -296,10 +322,7 @@ __device__ __forceinline__ void conv_epilogue_wide_full(const ConvP& p, f32x16 (
     }
     if (p.res_hi) {
       const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
-      v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
-      v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
-      v[2] += __uint_as_float(rh.y << 16) + __uint_as_float(rl.y << 16);
-      v[3] += __uint_as_float(rh.y & 0xFFFF0000u) + __uint_as_float(rl.y & 0xFFFF0000u);
+      add_rec4(v, rh, rl, p.f16);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
@@ -310,7 +333,7 @@ __device__ __forceinline__ void conv_epilogue_wide_full(const ConvP& p, f32x16 (
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);

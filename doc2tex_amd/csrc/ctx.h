@@ -33,6 +33,7 @@ struct RawW {
 struct ConvW {
   float* w = nullptr;
   uint16_t *w_hi = nullptr, *w_lo = nullptr;  // bf16 split of w for the bf16x3 kernel
+  uint16_t *w_h16 = nullptr, *w_l16 = nullptr;  // fp16 hi / lo of w for the fp16x2 kernels (ConvP::f16)
   float* bias = nullptr;
   int Cout = 0, Cin = 0, KH = 0, KW = 0;
 };
@@ -102,6 +103,9 @@ struct d2t_ctx {
   bool finalized = false;
   bool decode_in_flight = false;  // a submitted decode loop may still be running (cleared by a host-synchronising wait)
   bool conv_bf16x3 = true;   // d2t_set_conv_precision: backbone / patch convolutions on the bf16x3 kernel
+  // D2T_CONV_FP16X2 (on top of conv_bf16x3): the backbone's feature maps are fp16 records and its split-record convolutions run
+  // x16 * w_lo + x16 * w_hi (two MFMAs per product); everything that takes fp32 input stays on the bf16x3 kernels
+  bool conv_f16 = false;
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
   int conv_pipelined = 3;    // d2t_set_conv_kernel: 3 = pipelined 256x128 split-bf16 kernel on 16x16x32 MFMAs (default), 1 = the same on 32x32x16, 2 = 1 + patch-resident 3x3, 0 = 128x128 (two per CU)

@@ -35,6 +35,13 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
     out->w_hi = (uint16_t*)ph;
     out->w_lo = (uint16_t*)pl;
     HIPCHK(c, launch_split_bf16(out->w, out->w_hi, out->w_lo, w->numel, s));
+    void *qh, *ql;  // fp16 hi / lo planes (fp16x2 mode)
+    if ((rc = dev_alloc(c, &qh, w->numel * 2)) || (rc = dev_alloc(c, &ql, w->numel * 2))) return rc;
+    c->owned.push_back(qh);
+    c->owned.push_back(ql);
+    out->w_h16 = (uint16_t*)qh;
+    out->w_l16 = (uint16_t*)ql;
+    HIPCHK(c, launch_split_f16(out->w, out->w_h16, out->w_l16, w->numel, s));
   }
   return D2T_OK;
 }
@@ -114,6 +121,10 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
+  if (c->conv_f16 && x.split && w.w_h16) {  // fp16 records in (and out, and as the residual): the fp16x2 kernels
+    p.f16 = 1;
+    p.w_hi = w.w_h16; p.w_lo = w.w_l16;
+  }
   p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
   if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
   if (res) {
@@ -129,7 +140,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
     y.W /= 2;
   }
   hipError_t e;
-  if (c->conv_bf16x3 && c->wino_min_channels > 0 && w.w_hi && w.KH == 3 && w.KW == 3 && x.C >= c->wino_min_channels &&
+  if (c->conv_bf16x3 && !p.f16 && c->wino_min_channels > 0 && w.w_hi && w.KH == 3 && w.KW == 3 && x.C >= c->wino_min_channels &&
       w.Cout >= c->wino_min_channels && wino_applicable(p)) {
     // Winograd form (same ProfRec shape as the direct kernel: the bench rates it in direct-convolution FLOPs).  The
     // Winograd-domain weights (16 / 9 of the layer's) are made on first use and live until the weights are re-packed.
@@ -201,7 +212,8 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   const bool sp = c->conv_bf16x3 && !c->cfg.gcb;
   Act x{pick(c, {}), B, H, W, c->stem.Cout};
   x.split = sp;
-  if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s));
+  const int f16 = sp && c->conv_f16;  // fp16 records between the stem and the last convolution
+  if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s, f16));
   else HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
   // the two 2x2 / stride 2 max-pools (resnet.py:94,106) run inside the epilogue of the convolution in front of them on the
   // split-record path with the 16x16x32 kernels: conv0_2 writes 268 MB instead of 1.07 GB and no pool kernel re-reads it
@@ -210,7 +222,7 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
     Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
     y.split = a.split;
-    hipError_t e = a.split ? launch_maxpool_split(a.planes(), y.planes(), a.B, a.H, a.W, a.C, sh, sw, ph, pw, s)
+    hipError_t e = a.split ? launch_maxpool_split(a.planes(), y.planes(), a.B, a.H, a.W, a.C, sh, sw, ph, pw, s, f16)
                            : launch_maxpool(a.p, y.p, a.B, a.H, a.W, a.C, sh, sw, ph, pw, s);
     if (e != hipSuccess && err == hipSuccess) err = e;
     return y;
@@ -472,19 +484,21 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
         if (b.c2.w_hi && b.down.w_hi && b.down.KH == 1 && b.down.KW == 1 && b.down.Cout == b.c2.Cout) {
           // conv2 | shortcut concatenated along K (both already folded and in the kernels' K order: a 1x1 layer's is plain)
           const int Co = b.c2.Cout, K2 = b.c2.KH * b.c2.KW * b.c2.Cin, Kd = b.down.Cin;
-          void *pw, *pb, *ph, *pl;
+          void *pw, *pb, *ph, *pl, *qh, *ql;
           const size_t n = (size_t)Co * (K2 + Kd);
           if ((rc = dev_alloc(c, &pw, n * 4)) || (rc = dev_alloc(c, &pb, (size_t)Co * 4)) || (rc = dev_alloc(c, &ph, n * 2)) ||
-              (rc = dev_alloc(c, &pl, n * 2)))
+              (rc = dev_alloc(c, &pl, n * 2)) || (rc = dev_alloc(c, &qh, n * 2)) || (rc = dev_alloc(c, &ql, n * 2)))
             return rc;
-          for (void* q : {pw, pb, ph, pl}) c->owned.push_back(q);
+          for (void* q : {pw, pb, ph, pl, qh, ql}) c->owned.push_back(q);
           b.c2cat = b.c2;
           b.c2cat.w = (float*)pw; b.c2cat.bias = (float*)pb; b.c2cat.w_hi = (uint16_t*)ph; b.c2cat.w_lo = (uint16_t*)pl;
+          b.c2cat.w_h16 = (uint16_t*)qh; b.c2cat.w_l16 = (uint16_t*)ql;
           HIPCHK(c, hipMemcpy2DAsync(pw, (size_t)(K2 + Kd) * 4, b.c2.w, (size_t)K2 * 4, (size_t)K2 * 4, Co, hipMemcpyDeviceToDevice, s));
           HIPCHK(c, hipMemcpy2DAsync((float*)pw + K2, (size_t)(K2 + Kd) * 4, b.down.w, (size_t)Kd * 4, (size_t)Kd * 4, Co,
                                      hipMemcpyDeviceToDevice, s));
           HIPCHK(c, launch_add_rows(b.c2.bias, b.down.bias, b.c2cat.bias, Co, s));
           HIPCHK(c, launch_split_bf16(b.c2cat.w, b.c2cat.w_hi, b.c2cat.w_lo, n, s));
+          HIPCHK(c, launch_split_f16(b.c2cat.w, b.c2cat.w_h16, b.c2cat.w_l16, n, s));
         } else {
           b.c2cat.w = nullptr;
         }
@@ -891,6 +905,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
+    if (c->conv_f16 && f.split && c->patch.w_h16) { p.f16 = 1; p.w_hi = c->patch.w_h16; p.w_lo = c->patch.w_l16; }  // fp16 records from the backbone
     p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
@@ -2026,6 +2041,7 @@ int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   DevGuard dg_(c);
   if (!c || kind < 0 || kind > 7 || kind == 4)
     return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs), 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps) 6 (3, with the band-resident 16x16x32 kernel for every 3x3 / stride 1 / pad 1 layer) or 7 (3, with 256x256 tiles on eight waves for layers of at least 256 output channels)");
+  if (c->conv_f16 && kind != 3) return fail(c, D2T_ESTATE, "the fp16x2 convolutions exist for conv kernel 3 only");
   c->conv_pipelined = kind;
   return D2T_OK;
 }
@@ -2054,8 +2070,12 @@ int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
 
 int d2t_set_conv_precision(d2t_ctx* c, int32_t mode) {
   DevGuard dg_(c);
-  if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3)) return fail(c, D2T_EINVAL, "unknown conv precision %d", mode);
-  c->conv_bf16x3 = mode == D2T_CONV_BF16X3;
+  if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3 && mode != D2T_CONV_FP16X2))
+    return fail(c, D2T_EINVAL, "unknown conv precision %d", mode);
+  if (mode == D2T_CONV_FP16X2 && c->conv_pipelined != 3)
+    return fail(c, D2T_ESTATE, "the fp16x2 convolutions exist for conv kernel 3 (pipelined 256x128 on 16x16x32 MFMAs) only");
+  c->conv_bf16x3 = mode != D2T_CONV_FP32;
+  c->conv_f16 = mode == D2T_CONV_FP16X2;
   return D2T_OK;
 }
 
@@ -2144,7 +2164,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 7 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable
+  if (kind < 0 || kind > 8 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable; 8: kind 3 in fp16x2 arithmetic (ConvP::f16)
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;
@@ -2174,15 +2194,17 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   ConvP p{};
   p.w = wp; p.w_hi = whi; p.w_lo = wlo; p.bias = bias;
   p.in_hi = xs; p.out_hi = ys; p.res_hi = rs; p.zero16 = zero;
-  p.pipelined = g_op_conv_kind; p.reserved_cus = g_op_reserved_cus; p.split_tail = 1;
+  const int f16 = g_op_conv_kind == 8;  // fp16 records, fp16 hi / lo weights, two MFMAs per product
+  p.f16 = f16;
+  p.pipelined = f16 ? 3 : g_op_conv_kind; p.reserved_cus = g_op_reserved_cus; p.split_tail = 1;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.OH = OH; p.OW = OW;
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = B * OH * OW; p.K = KH * KW * Cin; p.act = act;
   hipError_t e = hipMemsetAsync(zero, 0, 256, s);
   if (e == hipSuccess) e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
-  if (e == hipSuccess) e = launch_split_bf16(wp, whi, wlo, nw, s);
-  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s);
-  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s);
+  if (e == hipSuccess) e = f16 ? launch_split_f16(wp, whi, wlo, nw, s) : launch_split_bf16(wp, whi, wlo, nw, s);
+  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s, f16);
+  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s, f16);
   void* wbuf = nullptr;
   if (e == hipSuccess && g_op_conv_kind == 4 && wino_applicable(p)) {
     const size_t nu = (size_t)16 * Cout * Cin * 2, nv = wino_workspace_bytes(B, H, W, Cin);
@@ -2195,7 +2217,7 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
     if (g_op_conv_kind == 4) p.pipelined = 3;
     e = launch_conv_bf16x3(p, s);
   }
-  if (e == hipSuccess) e = launch_merge_act(ys, y, ry, Cout, s);
+  if (e == hipSuccess) e = launch_merge_act(ys, y, ry, Cout, s, f16);
   hipStreamSynchronize(s);
   hipFree(buf);
   if (wbuf) hipFree(wbuf);
@@ -2232,15 +2254,17 @@ int d2t_op_conv2d_bf16x3_split_pool(const float* x, const float* w, const float*
   p.KH = KH; p.KW = KW; p.SH = SH; p.SW = SW; p.PH = PH; p.PW = PW;
   p.M = 4 * B * (OH / 2) * (OW / 2); p.K = KH * KW * Cin; p.act = act;
   p.pool2 = 1; p.pipelined = 3;
+  const int f16 = g_op_conv_kind == 8;
+  p.f16 = f16;
   const size_t rp = (size_t)B * (OH / 2) * (OW / 2);
   hipError_t e = hipMemsetAsync(zero, 0, 256, s);
   if (e == hipSuccess) e = launch_repack_ohwi(w, wp, Cout, KH, KW, Cin, s);
-  if (e == hipSuccess) e = launch_split_bf16(wp, whi, wlo, nw, s);
-  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s);
-  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s);
+  if (e == hipSuccess) e = f16 ? launch_split_f16(wp, whi, wlo, nw, s) : launch_split_bf16(wp, whi, wlo, nw, s);
+  if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s, f16);
+  if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s, f16);
   void* wbuf = nullptr;
   if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
-  if (e == hipSuccess) e = launch_merge_act(ys, y, rp, Cout, s);
+  if (e == hipSuccess) e = launch_merge_act(ys, y, rp, Cout, s, f16);
   hipStreamSynchronize(s);
   hipFree(buf);
   if (wbuf) hipFree(wbuf);

@@ -53,6 +53,10 @@ struct ConvP {
   // conv2(t) + downsample(x) in ONE accumulator, no shortcut kernel, no residual round trip.
   const uint16_t* in2_hi;
   int Cin2;
+  // != 0: fp16x2 arithmetic (round 3).  Records (in_hi, in2_hi, res_hi, out_hi) hold the activation once, as fp16, in their hi
+  // half; w_hi / w_lo are fp16 hi / lo planes (launch_split_f16); a product is x16 * w_lo + x16 * w_hi -- two MFMAs instead of
+  // three (conv_common.h split_rec / join_rec).  Split-record kernels only: conv_bf16x3g_body and conv_bf16x3p16_body.
+  int f16;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
@@ -82,6 +86,8 @@ hipError_t launch_wino_weights(const float* w_packed, uint16_t* u_hi, uint16_t* 
 hipError_t launch_conv_winograd(const ConvP& p, const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* v_ws, hipStream_t s);
 // hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
+// hi = fp16(w), lo = fp16(w - hi) (fp16x2 mode, ConvP::f16)
+hipError_t launch_split_f16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 
 // Skinny GEMM for decode steps: y[M,N] = act(x[M,K] @ w[N,K]^T + bias + res), K % 16 == 0.
 // If step_ptr != nullptr the output base is advanced by (*step_ptr) * out_step_stride floats.
@@ -107,15 +113,15 @@ hipError_t launch_stem(const float* img, const float* w, const float* bias, floa
                        int act, hipStream_t s);
 // same, writing split-bf16 planes
 hipError_t launch_stem_split(const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
-                             int Cout, int act, hipStream_t s);
+                             int Cout, int act, hipStream_t s, int f16 = 0);
 // fp32 [rows][C] <-> split-activation records (C % 32 == 0); used by the test entry point
-hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s);
-hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s);
+hipError_t launch_split_act(const float* x, uint16_t* planes, size_t rows, int C, hipStream_t s, int f16 = 0);
+hipError_t launch_merge_act(const uint16_t* planes, float* x, size_t rows, int C, hipStream_t s, int f16 = 0);
 hipError_t launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int SH, int SW, int PH, int PW,
                           hipStream_t s);  // 2x2 window
 // 2x2 max-pool on split-bf16 planes (reconstruct, max, re-split)
 hipError_t launch_maxpool_split(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, int SH, int SW, int PH,
-                                int PW, hipStream_t s);
+                                int PW, hipStream_t s, int f16 = 0);
 hipError_t launch_maxpool_k(const float* x, float* y, int B, int H, int W, int C, int KH, int KW, int SH, int SW,
                             int PH, int PW, hipStream_t s);
 // y[b][w][c] = mean_h x[b][h][w][c]   (AdaptiveAvgPool2d((None,1)) on the permuted map, build_feat.py:50-55)

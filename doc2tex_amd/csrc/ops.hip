@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 
 __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                          const float* __restrict__ bias, uint16_t* __restrict__ out,
-                                                         int B, int H, int W, int Cout, int act) {
+                                                         int B, int H, int W, int Cout, int act, int f16) {
   const int cq = Cout >> 2;  // == 8: the stride of the loop below is a multiple of 8, so a thread keeps its 4 channels
   const long long total = (long long)B * H * W * cq;
   const int c4 = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % cq);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
 #pragma unroll
       for (int t = 0; t < 9; ++t) a = fmaf(v[t], wr[c][t], a);
       a += br[c];
-      split_f32(act == ACT_RELU ? fmaxf(a, 0.f) : a, hi[c], lo[c]);
+      split_rec(act == ACT_RELU ? fmaxf(a, 0.f) : a, hi[c], lo[c], f16);
     }
     const size_t o = plane_idx((size_t)pix, c4 * 4, Cout);
     *reinterpret_cast<uint2*>(out + o) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
@@ -99,11 +99,11 @@ __global__ __launch_bounds__(256) void stem_split_kernel(const float* __restrict
 }
 
 hipError_t launch_stem_split(const float* img, const float* w, const float* bias, uint16_t* out, int B, int H, int W,
-                             int Cout, int act, hipStream_t s) {
+                             int Cout, int act, hipStream_t s, int f16) {
   if (Cout != 32) return hipErrorInvalidValue;  // 8 channel quads per pixel: see the kernel's hoisted weights
   const long long total = (long long)B * H * W * (Cout / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(stem_split_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, out, B, H, W, Cout, act);
+  hipLaunchKernelGGL(stem_split_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, out, B, H, W, Cout, act, f16);
   return hipGetLastError();
 }
 
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void maxpool_split_kernel(const uint16_t* __restrict__ xp, uint16_t* __restrict__ yp,
                                                             int B, int H, int W, int C, int OH, int OW, int SH, int SW,
-                                                            int PH, int PW) {
+                                                            int PH, int PW, int f16) {
   const int cq = C >> 2;
   const long long total = (long long)B * OH * OW * cq;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -166,16 +166,14 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const uint16_t* __re
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
           const size_t o = plane_idx((size_t)((b * H + ih) * W + iw), c4 * 4, C);
           const uint2 h2 = *reinterpret_cast<const uint2*>(xp + o), l2 = *reinterpret_cast<const uint2*>(xp + o + 32);
-          const float v0 = __uint_as_float(h2.x << 16) + __uint_as_float(l2.x << 16);
-          const float v1 = __uint_as_float(h2.x & 0xFFFF0000u) + __uint_as_float(l2.x & 0xFFFF0000u);
-          const float v2 = __uint_as_float(h2.y << 16) + __uint_as_float(l2.y << 16);
-          const float v3 = __uint_as_float(h2.y & 0xFFFF0000u) + __uint_as_float(l2.y & 0xFFFF0000u);
-          m[0] = fmaxf(m[0], v0); m[1] = fmaxf(m[1], v1); m[2] = fmaxf(m[2], v2); m[3] = fmaxf(m[3], v3);
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          add_rec4(v, h2, l2, f16);
+          m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
         }
       }
     uint16_t hi[4], lo[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) split_f32(m[c], hi[c], lo[c]);
+    for (int c = 0; c < 4; ++c) split_rec(m[c], hi[c], lo[c], f16);
     const size_t o = plane_idx((size_t)pix, c4 * 4, C);
     *reinterpret_cast<uint2*>(yp + o) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
     *reinterpret_cast<uint2*>(yp + o + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
@@ -183,12 +181,12 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const uint16_t* __re
 }
 
 hipError_t launch_maxpool_split(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, int SH, int SW, int PH,
-                                int PW, hipStream_t s) {
+                                int PW, hipStream_t s, int f16) {
   if (C % 32) return hipErrorInvalidValue;
   const int OH = (H + 2 * PH - 2) / SH + 1, OW = (W + 2 * PW - 2) / SW + 1;
   const long long total = (long long)B * OH * OW * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(maxpool_split_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, SH, SW, PH, PW);
+  hipLaunchKernelGGL(maxpool_split_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, SH, SW, PH, PW, f16);
   return hipGetLastError();
 }
 

@@ -278,8 +278,9 @@ class Engine:
         return memory, (gh, gw), (pw, ph)
 
     def set_conv_precision(self, mode):
-        """'fp32' (exact) or 'bf16x3' (the default: split-bf16 matrix-core path for the convolutions)."""
-        code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3}[mode]
+        """'fp32' (exact), 'bf16x3' (split-bf16 matrix-core path for the convolutions: three products per element) or 'fp16x2'
+        (fp16 feature maps times fp16 hi / lo weights in the backbone: two products per element)."""
+        code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3, "fp16x2": _lib.CONV_FP16X2}[mode]
         self._check(self.lib.d2t_set_conv_precision(self.ctx, code), "set_conv_precision")
 
     def set_reserved_blocks(self, blocks):

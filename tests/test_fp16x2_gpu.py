@@ -1,0 +1,116 @@
+"""GPU: the opt-in fp16x2 arithmetic of the backbone (Model.conv_precision = "fp16x2"; include/d2t.h D2T_CONV_FP16X2): feature
+maps kept as fp16 records, convolutions as x16 * w_lo + x16 * w_hi -- two MFMAs per product instead of three.
+
+Bar (north_star): greedy token ids bit-exact, logits within 1e-3.  It holds on every fixture of the HybridViT configs and of
+the LSTM heads; it does NOT hold on the ResNet-only configs (C1, T1: tokens exact, logits off by 2.5e-3 .. 9e-3 -- their
+decoder reads the backbone's output directly, with magnitudes of several hundred), which is why the mode is opt-in and the
+default stays split-bf16.  Op-level tests: tests/test_ops_gpu.py (test_fp16x2_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, engine_model, oracle_state_dict
+from doc2tex_amd import synth
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3  # BASELINE.json north_star: "logits within 1e-3 fp32"
+MEM_TOL = 2e-3    # encoder memory relative to its largest magnitude: feature maps are rounded to 11 bits where a layer stores them
+
+
+def _case(cases, kind, name):
+    return next(c for c in cases[kind] if c["case"] == name)
+
+
+def _model(c):
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c.get("beam_size"))
+    m.conv_precision = "fp16x2"
+    return cfg, m
+
+
+@pytest.mark.parametrize("name", ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "c2_small_crop", "c2_greedy", "c0_greedy",
+                                  "c0_greedy_early", "ts0_greedy", "s0_greedy", "s0_small_crop", "t2g_greedy", "t1g_greedy",
+                                  "c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "b0_greedy", "b0_greedy_early", "tb0_greedy",
+                                  "to0_greedy"])
+def test_fp16x2_greedy_vs_reference_fixture(cases, name):
+    c = _case(cases, "greedy", name)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, m = _model(c)
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        mem, shape, pad = m.forward_encoder(img)
+        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
+    torch.cuda.synchronize()
+    mem, preds, logits = mem.cpu(), preds.cpu(), logits.cpu()
+    rows = z["mem_rows"].tolist()
+    dmem = float(np.abs(mem[:, rows].numpy() - z["mem_sample"]).max()) / max(1.0, c["mem_absmax"])
+    assert dmem <= MEM_TOL, f"encoder memory rel err {dmem}"
+    assert preds.shape[1] == c["steps"] and np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
+    dl = float(np.abs(logits[:, z["logit_steps"].tolist()].numpy() - z["logits_sample"]).max())
+    assert dl <= LOGIT_TOL, f"logits differ by {dl}"
+
+
+@pytest.mark.parametrize("name", ["t1_greedy", "c1_greedy"])
+def test_fp16x2_on_the_resnet_only_configs_keeps_the_tokens(cases, name):
+    """Where the mode is NOT offered (the logits leave the 1e-3 bar, see the module docstring) the greedy tokens of the
+    fixtures still come out exact and the logits stay within 2e-2: the failure is graceful."""
+    c = _case(cases, "greedy", name)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, m = _model(c)
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
+    assert np.array_equal(preds.cpu().numpy(), z["tokens"])
+    assert float(np.abs(logits.cpu()[:, z["logit_steps"].tolist()].numpy() - z["logits_sample"]).max()) <= 2e-2
+
+
+def test_fp16x2_all_64_rows_of_a_headline_batch_vs_the_oracle(cases, manifests):
+    """BASELINE configs[2], one whole batch in the benchmarked serving mode with fp16x2 arithmetic: every row's token ids equal
+    the CPU oracle's, every logit is within 1e-3; and the answers do not depend on how the batch is sharded (bit for bit)."""
+    c = _case(cases, "greedy", "c2_greedy")
+    cfg, m = _model(c)
+    ocfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    img = synth.synth_images(64, c["H"], c["W"], seed=4100)
+    img[: c["B"]] = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = torch.full((64, 1), R.GO, dtype=torch.long)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        op, ol, _ = R.forward(ocfg, sd, img, text, is_test=False, faithful=False)
+        m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 3, 6, 0
+        p, l, extra = m(img.cuda(), text.cuda(), is_train=False)
+        p, l = extra["decode"].result()
+        torch.cuda.synchronize()
+        m.pipelined, m.decode_group = False, 1
+        halves = [m(img[i:i + 32].cuda(), text[i:i + 32].cuda(), is_train=False) for i in (0, 32)]
+    assert p.shape == (64, 151) and torch.equal(p.cpu(), op), "greedy token ids differ from the oracle on some of the 64 rows"
+    dl = float((l.cpu() - ol).abs().max())
+    assert dl <= LOGIT_TOL, f"logits differ by {dl}"
+    assert torch.equal(p, torch.cat([h[0] for h in halves])) and torch.equal(l, torch.cat([h[1] for h in halves]))
+
+
+def test_fp16x2_beam_sequences_vs_reference_fixture(cases):
+    """Beam search (C4's geometry) on fp16x2 encoder memory: the sequence is the reference's; the score, a sum of ~150
+    log-probabilities, within 5e-3."""
+    for name in ("c4_beam5_160", "c2_beam5"):
+        c = _case(cases, "beam", name)
+        cfg, m = _model(c)
+        img = synth.synth_images(1, c["H"], c["W"], seed=c["iseed"]).cuda()
+        text = torch.full((1, 1), R.GO, dtype=torch.long, device="cuda")
+        with torch.no_grad():
+            seq, score, _ = m(img, text, is_train=False, is_test=True)
+        assert seq.shape[0] == 1 and seq[0].tolist() == c["seq"], name
+        assert abs(float(score) - float(c["score"])) <= 5e-3, (name, float(score), float(c["score"]))
+
+
+def test_fp16x2_needs_the_pipelined_16x16x32_kernel(cases):
+    c = _case(cases, "greedy", "t2_greedy")
+    cfg, m = _model(c)
+    m.conv_kernel = "pipelined"
+    img = synth.synth_images(1, c["H"], c["W"], seed=1).cuda()
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m.forward_encoder(img)

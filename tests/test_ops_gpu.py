@@ -407,3 +407,83 @@ def test_winograd_convolution_vs_float64(shape):
     assert torch.isfinite(out[4]).all()
     assert e_wino <= 4e-4 and e_wino <= 3 * e_direct + 1e-6, (e_direct, e_wino)
     assert torch.equal(out[4][B - 1:], y1.cpu())
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, k, stride, pad, residual
+    (2, 16, 129, 512, 512, (3, 3), (1, 1), (1, 1), True),    # the dominant layer's geometry (pipelined kernel)
+    (2, 64, 96, 32, 64, (3, 3), (1, 1), (1, 1), False),      # conv0_2's (128 x 64 kernel)
+    (3, 7, 37, 128, 384, (3, 3), (1, 1), (1, 1), True),      # ragged rows and a partial last row tile
+    (1, 16, 129, 256, 512, (2, 2), (2, 1), (0, 1), False),   # conv4_1's strided, asymmetrically padded window
+    (5, 13, 50, 96, 96, (3, 3), (1, 1), (1, 1), True),       # 64 < Cout < 128: the 128 x 128 kernel
+    (2, 9, 33, 256, 512, (1, 1), (1, 1), (0, 0), False),     # a 1x1 shortcut
+])
+def test_fp16x2_convolution_vs_float64(shape):
+    """fp16x2 arithmetic (ConvP::f16; d2t_op_set_conv_kernel kind 8): activations and residual are fp16 records, the weights
+    fp16 hi + fp16 lo, a product is x*w_lo + x*w_hi with fp32 accumulation, the result is stored as fp16.  Against float64
+    on the SAME rounded inputs the only error left is the fp32 accumulation and the final rounding to fp16 (half an ulp:
+    2^-11 relative); a sample's rows do not depend on the batch they are computed in."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout, k, st, pd, use_res = shape
+    x = _rand(B, Cin, H, W, seed=41)
+    w = _rand(Cout, Cin, *k, seed=42, scale=(2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = _rand(Cout, seed=43, scale=0.1)
+    OH, OW = (H + 2 * pd[0] - k[0]) // st[0] + 1, (W + 2 * pd[1] - k[1]) // st[1] + 1
+    res = _rand(B, Cout, OH, OW, seed=44) if use_res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = b.to(DEV)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
+    try:
+        assert lib.d2t_op_set_conv_kernel(8, 0) == 0
+        y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
+                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
+        y0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
+                                              _lib.ptr(y0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
+                                              _lib.stream_of(xd)) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.d2t_op_set_conv_kernel(3, 0)
+    y, y0 = y.cpu(), y0.cpu()
+    assert torch.isfinite(y).all() and torch.equal(y[B - 1:], y0)
+    x16 = x.half().double()
+    wh = w.half()
+    w22 = wh.double() + (w - wh.float()).half().double()
+    ref = F.conv2d(x16, w22, b.double(), st, pd)
+    if use_res:
+        ref = ref + res.half().double()
+    ref = F.relu(ref)
+    got = y.permute(0, 3, 1, 2).double()
+    assert torch.equal(got.float().half().float(), got.float())  # what is stored IS fp16
+    err = (got - ref).abs()
+    # fp16 rounding of the result (2^-11 relative, one more ulp where the fp32 sum lands next to a rounding boundary)
+    assert bool((err <= ref.abs() * 2.0 ** -10 + 2e-4).all()), float((err - ref.abs() * 2.0 ** -10).max())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96, 32, 64), (2, 32, 64, 64, 128)])
+def test_fp16x2_convolution_with_the_max_pool_fused(shape):
+    """The fused 2x2 max-pool in fp16x2 arithmetic equals max_pool2d of the unfused fp16x2 convolution exactly (the maximum of
+    fp16 values is one of them)."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout = shape
+    x = _rand(B, Cin, H, W, seed=51)
+    w = _rand(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
+    b = _rand(Cout, seed=53, scale=0.1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bd = b.to(DEV)
+    try:
+        assert lib.d2t_op_set_conv_kernel(8, 0) == 0
+        y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), None, _lib.ptr(y), B, H, W, Cin, Cout, 3, 3,
+                                              1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+        yp = torch.full((B, H // 2, W // 2, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split_pool(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(yp), B, H, W, Cin, Cout, 3, 3,
+                                                   1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.d2t_op_set_conv_kernel(3, 0)
+    ref = F.max_pool2d(y.cpu().permute(0, 3, 1, 2), 2, 2)
+    assert torch.isfinite(yp).all() and torch.equal(yp.cpu().permute(0, 3, 1, 2), ref)

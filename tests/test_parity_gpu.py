@@ -13,6 +13,7 @@ from oracle import restatement as R
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3  # BASELINE.json north_star: "logits within 1e-3 fp32"
+MEM_TOL = {"fp32": 1e-4, "bf16x3": 5e-4, "fp16x2": 2e-3}  # encoder memory, relative to its largest magnitude (our own bar)
 
 
 def _case(cases, kind, name):
@@ -49,8 +50,9 @@ def test_greedy_vs_reference_fixture(cases, name):
     scale = max(1.0, c["mem_absmax"])
     rows = z["mem_rows"].tolist()
     dmem = float(np.abs(mem[:, rows].numpy() - z["mem_sample"]).max()) / scale
-    # fp32 arithmetic: 1e-4; the default split-bf16 arithmetic (2^-16 relative per product through 32 convolutions): 5e-4
-    assert dmem <= (1e-4 if m.conv_precision == "fp32" else 5e-4), f"encoder memory rel err {dmem}"
+    # fp32 arithmetic: 1e-4; split-bf16 arithmetic (2^-16 relative per product through 32 convolutions): 5e-4; fp16x2 (feature
+    # maps rounded to 11 bits where a layer stores them): 2e-3 -- the north_star bar is the tokens and the logits below
+    assert dmem <= MEM_TOL[m.conv_precision], f"encoder memory rel err {dmem}"
     assert preds.shape[1] == c["steps"], (preds.shape, c["steps"])
     assert np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
     steps = z["logit_steps"].tolist()
@@ -68,7 +70,7 @@ def test_full_tensors_vs_oracle(cases, manifests, name):
     with torch.no_grad():
         omem, oshape, opad = R.forward_encoder(ocfg, sd, img, faithful=False)
         op, ol, _ = R.forward(ocfg, sd, img, torch.full((c["B"], 1), R.GO, dtype=torch.long), is_test=c["is_test"])
-    assert float((mem - omem).abs().max()) <= 1e-4 * max(1.0, float(omem.abs().max()))
+    assert float((mem - omem).abs().max()) <= (2e-3 if m.conv_precision == "fp16x2" else 1e-4) * max(1.0, float(omem.abs().max()))
     assert torch.equal(preds, op)
     assert float((logits - ol).abs().max()) <= LOGIT_TOL
 
