@@ -501,7 +501,7 @@ def other_configs(args, dev):
     out = {}
     a = copy.copy(args)
     a.batch, a.group = 0, 0
-    line, _ = serving_bench(a, "C1", 0, 1, dev, None, secondary_runs=False, steps=max(20, args.steps), warmup=4)
+    line, _ = serving_bench(a, "C1", 0, 1, dev, None, secondary_runs=False, steps=max(40, args.steps), warmup=4)
     out["c1"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline")}
     torch.cuda.empty_cache()
     a = copy.copy(args)

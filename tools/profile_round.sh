@@ -43,4 +43,6 @@ with open(out + "/kernel_stats.csv", "w") as fh:
         fh.write('"%s",%d,%.1f,%.2f,%.2f\n' % (k.replace('"', "'"), n, t, t / n, 100 * t / tot))
 PY
 head -25 $out/kernel_stats.csv
-rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_mfma
+# rocprofv3's own --stats table, then drop the raw traces (gpurun merges at most 64 MiB back)
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/rocprofv3_kernel_stats.csv 2>/dev/null || true
+rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_mfma $out/trace
