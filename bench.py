@@ -161,7 +161,8 @@ def train_bench(args, rank, world, dev, dist, emit=True):
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.to(dev).train()
-    model.conv_precision = args.precision
+    tprec = args.precision if args.precision in ("fp32", "bf16x3") else "bf16x3"  # (the training step has no fp16x2 form)
+    model.conv_precision = tprec
     if world > 1:
         model.grad_sync = GradSync()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
@@ -211,11 +212,11 @@ def train_bench(args, rank, world, dev, dist, emit=True):
             dom = max(by_shape, key=lambda q: sum(by_shape[q]))
             dom_ms = sum(by_shape[dom]) / len(by_shape[dom])
             flop = 2.0 * dom[0] * dom[1] * dom[2]
-            bf = args.precision == "bf16x3"
+            bf = tprec == "bf16x3"
             peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
             ach = flop / (dom_ms * 1e-3) / 1e12
             total_ms = sum(sum(v) for v in by_shape.values())
-            traffic, traffic_src = train_pmc_traffic(args.precision, dom)
+            traffic, traffic_src = train_pmc_traffic(tprec, dom)
             roofline = {"bound": "mfma", "kernel": "forward / data-gradient convolution GEMM (split-bf16, LDS-DMA kernels on split-record copies of the inputs)" if bf
                         else "forward / data-gradient convolution GEMM (fp32 MFMA)",
                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -228,7 +229,7 @@ def train_bench(args, rank, world, dev, dist, emit=True):
             "metric": "formulas/s (training step, 128x512 crops, CE loss)", "value": round(B * world * args.steps / elapsed, 2),
             "unit": "formulas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if tprec == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"C3: HybridViT + TFM-6 training step, {H}x{W} crops, {L + 1}-token labels, "
                                    "forward + CE + backward + clip + AdamW",
                        "per_gpu_batch": B, "global_batch": B * world,
@@ -260,7 +261,9 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl, end_bias=args.end_bias), strict=False)
     model.eval().to(dev)
-    model.conv_precision = args.precision
+    if args.precision:
+        model.conv_precision = args.precision
+    precision = model.effective_conv_precision()  # the Model's default for this stack unless --precision says otherwise
     early = args.end_bias != 0.0
     model.pipelined = not args.no_pipeline and not early
     model.decode_chains = args.chains
@@ -396,7 +399,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
         }
         if tuple(dom) != (132096, 512, 4608):  # the committed counter passes describe the headline shape only
             roofline["traffic"], roofline["traffic_source"] = None, None
-        elif not f16 and _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
+        elif _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
             roofline["mfma_busy_frac_pmc"] = round(_PMC["mfma_busy_frac"], 4)
             roofline["kernel_alone_ms_rocprof"] = round(_PMC.get("kernel_trace_avg_ms", 0.0), 4)
         if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi), or two fp16 ones (x*lo + x*hi)
@@ -428,11 +431,11 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "value": round(world * B * steps / e2, 2), "unit": "formulas/s", "ms_per_step": round(e2 / steps * 1e3, 3),
             "what": f"as `value`, plus per step the H2D copy of the batch ({host_img.numel() * 4 / 1e6:.1f} MB from pinned host "
                     "memory, on a copy stream) and, before the region ends, the D2H copy of every batch's token ids"}
-        if args.precision == "bf16x3":
+        if precision in ("bf16x3", "fp16x2"):
             k3 = max(4, steps // 4)
             model.conv_precision = "fp32"
             e3, r3, _ = timed(k3, 2)
-            model.conv_precision = args.precision
+            model.conv_precision = precision
             if rank == 0:
                 secondary["fp32"] = {
                     "value": round(world * B * k3 / e3, 2), "unit": "formulas/s", "ms_per_step": round(e3 / k3 * 1e3, 3),
@@ -440,25 +443,27 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
                     "what": "same workload and serving configuration with exact fp32 arithmetic on the fp32-input MFMA "
                             "(v_mfma_f32_32x32x2_f32) everywhere",
                     "roofline": roofline_of(r3, "fp32", k3)}
-            if name in ("C2", "C4"):  # fp16x2 arithmetic: validated on the HybridViT configs (tests), opt-in
-                model.conv_precision = "fp16x2"
+            other = "bf16x3" if precision == "fp16x2" else ("fp16x2" if name in ("C2", "C4") else None)
+            if other:  # the other 16-bit arithmetic beside the headline's, with its own roofline and its own parity
+                model.conv_precision = other
                 e4, r4, o4 = timed(steps, 2)
-                model.conv_precision = args.precision
+                model.conv_precision = precision
                 if rank == 0:
-                    secondary["fp16x2"] = {
+                    secondary[other] = {
                         "value": round(world * B * steps / e4, 2), "unit": "formulas/s", "ms_per_step": round(e4 / steps * 1e3, 3),
-                        "steps": steps, "dtype": "fp16x2",
-                        "what": "same workload and serving configuration with the backbone's feature maps kept as fp16 records and "
-                                "its convolutions as x16 * w_lo + x16 * w_hi (two MFMAs per product instead of three); opt-in "
-                                "(Model.conv_precision = 'fp16x2'): tokens exact and logits within 1e-3 on the HybridViT fixtures, "
-                                "not on the ResNet-only configs",
-                        "roofline": roofline_of(r4, "fp16x2", steps),
+                        "steps": steps, "dtype": other,
+                        "what": "same workload and serving configuration, " +
+                                ("split-bf16 arithmetic (three bf16 MFMAs per product): the default of rounds 1-2 and of the stacks "
+                                 "without a ViT encoder" if other == "bf16x3" else
+                                 "the backbone's feature maps as fp16 records and its convolutions as x16 * w_lo + x16 * w_hi (two MFMAs "
+                                 "per product instead of three)"),
+                        "roofline": roofline_of(r4, other, steps),
                         "_out": (o4[0], o4[1])}
 
     if rank == 0:
         T = model.engine().encoder_shape(H, W)[0]
-        bf = args.precision == "bf16x3"
-        roofline = roofline_of(recs, args.precision, steps)
+        bf = precision == "bf16x3"
+        roofline = roofline_of(recs, precision, steps)
         formulas = world * B * steps
         ms_step = elapsed / steps * 1e3
         enc_flops = {"C2": 205.28e9, "C1": 50.79e9}.get(name, 0.0)
@@ -471,7 +476,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3" if bf else ("fp16x2" if args.precision == "fp16x2" else "f32"), "data": "synthetic",
+            "dtype": "bf16x3" if bf else ("fp16x2" if precision == "fp16x2" else "f32"), "data": "synthetic",
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
@@ -498,7 +503,10 @@ def other_configs(args, dev):
     """The other BASELINE configs on one GPU, measured after the headline and outside its timed region (world == 1):
     C1 (configs[1]) greedy serving, C3's per-GPU training step (configs[3]) and C4's beam-5 decode (configs[4])."""
     import copy
+    import gc
     out = {}
+    gc.collect()  # the headline's model and engine context (its buffers, streams and graphs) go first
+    torch.cuda.empty_cache()
     a = copy.copy(args)
     a.batch, a.group = 0, 0
     line, _ = serving_bench(a, "C1", 0, 1, dev, None, secondary_runs=False, steps=max(40, args.steps), warmup=4)
@@ -539,7 +547,7 @@ def beam_bench(dev, n=128, beam=5, per_sample=8):
             m(img[i:i + 1], go, is_train=False, is_test=True)
         torch.cuda.synchronize(dev)
         ds = time.perf_counter() - t1
-    return {"value": round(n / dt, 2), "unit": "formulas/s", "ms_per_batch": round(dt * 1e3, 2), "dtype": "bf16x3",
+    return {"value": round(n / dt, 2), "unit": "formulas/s", "ms_per_batch": round(dt * 1e3, 2), "dtype": m.effective_conv_precision(),
             "config": {"workload": f"C4: HybridViT + TFM-6, beam width {beam}, {H}x{W} crops (max_dimension [160, 640]), one bucket "
                                    f"per batch, up to {cfg['Prediction']['params']['max_seq_len'] + 1} steps, batched API",
                        "per_gpu_batch": n},
@@ -557,9 +565,10 @@ def main():
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "fp16x2"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "fp16x2"],
                     help="convolution arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs per product), or fp16 feature maps x fp16 "
-                         "hi / lo weights in the backbone (2 MFMAs per product; HybridViT configs: see DESIGN.md)")
+                         "hi / lo weights in the backbone (2 MFMAs per product).  Default: the Model's own default for the stack "
+                         "(fp16x2 behind a ViT encoder, bf16x3 otherwise and for the training step: DESIGN.md section 3)")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16", "band16", "wide16"],
@@ -674,8 +683,8 @@ def main():
                                     "what": f"rows 0..{n - 1} of the last batch of the timed region (pipelined, decode groups of "
                                             f"{result['config']['decode_group']}) against oracle/restatement.py (KV-cached mode) on the "
                                             "same crops and weights"}
-        f16s = result.get("secondary", {}).get("fp16x2")
-        if f16s:  # the fp16x2 run proves its answers the same way (or carries none)
+        f16s = result.get("secondary", {}).get("fp16x2") or result.get("secondary", {}).get("bf16x3")
+        if f16s and "_out" in f16s:  # the other 16-bit run proves its answers the same way (or carries none)
             o4 = f16s.pop("_out")
             if "parity" in result:
                 n = args.cpu_sample

@@ -174,9 +174,21 @@ class Model(nn.Module):
         # of a group become valid after synchronize() (which also launches a group that is still incomplete).
         self.decode_group = 1
         self._grp = None
-        # 'bf16x3' (default) = split-bf16 convolutions / large GEMMs (3 bf16 MFMAs per product, fp32 accumulate: tokens
-        # bit-exact, logits within 1e-3 on every fixture); 'fp32' = exact fp32 matrix-core arithmetic
-        self.conv_precision = os.environ.get("D2T_CONV_PRECISION", "bf16x3")
+        # Arithmetic of the backbone / large GEMMs, each held to the north_star bar -- greedy tokens
+        # bit-exact, logits within 1e-3 -- on every reference fixture of the stacks it is the default for:
+        #   'bf16x3'  split-bf16: 3 bf16 MFMAs per product, fp32 accumulate (max |dlogit| ~5e-5);
+        #   'fp16x2'  fp16 feature-map records x fp16 hi / lo weights in the backbone: 2 MFMAs per product (max |dlogit|
+        #             ~2e-4 behind a ViT encoder; NOT for Feat=ResNet + Seq=None, whose decoder reads the backbone's output
+        #             directly: up to 9e-3 there);
+        #   'fp32'    exact fp32 matrix-core arithmetic.
+        # Default ('auto' resolved here): 'fp16x2' for the HybridViT stacks on the pipelined16 kernel, 'bf16x3' otherwise.
+        # An 'auto' fp16x2 steps back to 'bf16x3' while another convolution kernel or the Winograd form is selected (the
+        # fp16x2 kernels exist for pipelined16 only); an explicit conv_precision = 'fp16x2' raises there instead.
+        prec = os.environ.get("D2T_CONV_PRECISION", "auto")
+        self._precision_auto = prec == "auto"
+        if prec == "auto":
+            prec = "fp16x2" if stages["Seq"].__contains__("Vi") else "bf16x3"
+        self._conv_precision = prec
         # data-parallel training: a doc2tex_amd.dist.GradSync makes loss.backward() return all-reduced (mean) gradients
         self.grad_sync = None
 
@@ -262,6 +274,10 @@ class Model(nn.Module):
         if getattr(self._engine, "_reserved_cus", None) != want_cus:
             self._engine.set_reserved_cus(want_cus)
             self._engine._reserved_cus = want_cus
+        prec = self.effective_conv_precision()
+        if prec != "fp16x2" and getattr(self._engine, "_precision", None) != prec:  # (before a change of the kernel)
+            self._engine.set_conv_precision(prec)
+            self._engine._precision = prec
         if getattr(self._engine, "_conv_kernel", None) != self.conv_kernel:
             self._engine.set_conv_kernel(self.conv_kernel)
             self._engine._conv_kernel = self.conv_kernel
@@ -274,10 +290,27 @@ class Model(nn.Module):
         if getattr(self._engine, "_chains", None) != self.decode_chains:
             self._engine.set_decode_chains(self.decode_chains)
             self._engine._chains = self.decode_chains
-        if getattr(self._engine, "_precision", None) != self.conv_precision:
-            self._engine.set_conv_precision(self.conv_precision)
-            self._engine._precision = self.conv_precision
+        if prec == "fp16x2" and getattr(self._engine, "_precision", None) != prec:  # (after the kernel choice: needs pipelined16)
+            self._engine.set_conv_precision(prec)
+            self._engine._precision = prec
         return self._engine
+
+    @property
+    def conv_precision(self):
+        return self._conv_precision
+
+    @conv_precision.setter
+    def conv_precision(self, mode):
+        if mode not in ("fp32", "bf16x3", "fp16x2"):
+            raise ValueError(f"conv_precision must be 'fp32', 'bf16x3' or 'fp16x2', not {mode!r}")
+        self._conv_precision = mode
+        self._precision_auto = False
+
+    def effective_conv_precision(self):
+        """The arithmetic the next forward runs in (an 'auto' fp16x2 steps back to bf16x3 for other convolution kernels)."""
+        if self._precision_auto and self._conv_precision == "fp16x2" and (self.conv_kernel != "pipelined16" or self.conv_winograd):
+            return "bf16x3"
+        return self._conv_precision
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

@@ -1,10 +1,11 @@
-"""GPU: the opt-in fp16x2 arithmetic of the backbone (Model.conv_precision = "fp16x2"; include/d2t.h D2T_CONV_FP16X2): feature
-maps kept as fp16 records, convolutions as x16 * w_lo + x16 * w_hi -- two MFMAs per product instead of three.
+"""GPU: the fp16x2 arithmetic of the backbone (Model.conv_precision = "fp16x2"; include/d2t.h D2T_CONV_FP16X2): feature maps
+kept as fp16 records, convolutions as x16 * w_lo + x16 * w_hi -- two MFMAs per product instead of three.  Since round 3 the
+default of the stacks with a ViT encoder (Model resolves 'auto'), set explicitly here for every stack.
 
 Bar (north_star): greedy token ids bit-exact, logits within 1e-3.  It holds on every fixture of the HybridViT configs and of
 the LSTM heads; it does NOT hold on the ResNet-only configs (C1, T1: tokens exact, logits off by 2.5e-3 .. 9e-3 -- their
-decoder reads the backbone's output directly, with magnitudes of several hundred), which is why the mode is opt-in and the
-default stays split-bf16.  Op-level tests: tests/test_ops_gpu.py (test_fp16x2_*)."""
+decoder reads the backbone's output directly, with magnitudes of several hundred), which is why those keep split-bf16.
+Op-level tests: tests/test_ops_gpu.py (test_fp16x2_*)."""
 import os
 
 import numpy as np

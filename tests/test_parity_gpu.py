@@ -20,6 +20,13 @@ def _case(cases, kind, name):
     return next(c for c in cases[kind] if c["case"] == name)
 
 
+def _score_tol(m, n):
+    """Bar for a beam score = a SUM of n log-probabilities.  Split-bf16 / fp32 encoders hold each to ~1e-5 (the logits bar is
+    1e-3 per value): 1e-3 for the short fixtures, 2e-5 per token for the 151-token one (a sum around -520, whose own fp32
+    spacing is 6e-5).  fp16x2 encoder memory (the default behind a ViT encoder) moves a logit by up to 2e-4: 5e-3 on the sum."""
+    return 5e-3 if m.effective_conv_precision() == "fp16x2" else max(1e-3, 2e-5 * n)
+
+
 def _run_engine(c, B=None):
     cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c.get("beam_size"))
     B = B or c["B"]
@@ -52,12 +59,33 @@ def test_greedy_vs_reference_fixture(cases, name):
     dmem = float(np.abs(mem[:, rows].numpy() - z["mem_sample"]).max()) / scale
     # fp32 arithmetic: 1e-4; split-bf16 arithmetic (2^-16 relative per product through 32 convolutions): 5e-4; fp16x2 (feature
     # maps rounded to 11 bits where a layer stores them): 2e-3 -- the north_star bar is the tokens and the logits below
-    assert dmem <= MEM_TOL[m.conv_precision], f"encoder memory rel err {dmem}"
+    assert dmem <= MEM_TOL[m.effective_conv_precision()], f"encoder memory rel err {dmem}"
     assert preds.shape[1] == c["steps"], (preds.shape, c["steps"])
     assert np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
     steps = z["logit_steps"].tolist()
     dl = float(np.abs(logits[:, steps].numpy() - z["logits_sample"]).max())
     assert dl <= LOGIT_TOL, f"logits differ by {dl}"
+
+
+@pytest.mark.parametrize("name", ["t2_greedy", "t2_greedy_early", "c2_small_crop", "c2_greedy", "c4_greedy_160", "c4_greedy_96"])
+def test_split_bf16_greedy_vs_reference_fixture_behind_a_vit_encoder(cases, name):
+    """The HybridViT stacks default to fp16x2 arithmetic since round 3 (tests above; tests/test_fp16x2_gpu.py); their split-bf16
+    form (conv_precision = 'bf16x3', the default of rounds 1-2 and of the bench's `secondary.bf16x3`) keeps its tighter bars."""
+    c = _case(cases, "greedy", name)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c.get("beam_size"))
+    m.conv_precision = "bf16x3"
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        mem, _, _ = m.forward_encoder(img)
+        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
+    mem, preds, logits = mem.cpu(), preds.cpu(), logits.cpu()
+    dmem = float(np.abs(mem[:, z["mem_rows"].tolist()].numpy() - z["mem_sample"]).max()) / max(1.0, c["mem_absmax"])
+    assert dmem <= MEM_TOL["bf16x3"], f"encoder memory rel err {dmem}"
+    assert np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
+    dl = float(np.abs(logits[:, z["logit_steps"].tolist()].numpy() - z["logits_sample"]).max())
+    assert dl <= 2e-4, f"logits differ by {dl}"  # (a fifth of the north_star bar: what split-bf16 holds on these fixtures)
 
 
 @pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop"])
@@ -70,7 +98,7 @@ def test_full_tensors_vs_oracle(cases, manifests, name):
     with torch.no_grad():
         omem, oshape, opad = R.forward_encoder(ocfg, sd, img, faithful=False)
         op, ol, _ = R.forward(ocfg, sd, img, torch.full((c["B"], 1), R.GO, dtype=torch.long), is_test=c["is_test"])
-    assert float((mem - omem).abs().max()) <= (2e-3 if m.conv_precision == "fp16x2" else 1e-4) * max(1.0, float(omem.abs().max()))
+    assert float((mem - omem).abs().max()) <= (2e-3 if m.effective_conv_precision() == "fp16x2" else 1e-4) * max(1.0, float(omem.abs().max()))
     assert torch.equal(preds, op)
     assert float((logits - ol).abs().max()) <= LOGIT_TOL
 
@@ -214,9 +242,7 @@ def test_beam_vs_reference_fixture(cases, name):
         seq, score, _ = m(img, text, is_train=False, is_test=True)
         seq2, score2, _ = m(img, text, is_train=False, is_test=True)  # fresh beam state per call
     assert seq.shape[0] == 1 and seq[0].tolist() == c["seq"], (seq, c["seq"])
-    # the score is a SUM of len(seq) log-probabilities, each held to ~1e-5 (the logits bar is 1e-3 per value): 1e-3 for the
-    # short fixtures, 2e-5 per token for the 151-token one (a sum around -520, whose own fp32 spacing is 6e-5)
-    assert abs(score - c["score"]) <= max(1e-3, 2e-5 * len(c["seq"])), (score, c["score"])
+    assert abs(score - c["score"]) <= _score_tol(m, len(c["seq"])), (score, c["score"])
     assert torch.equal(seq, seq2) and score == score2
 
 
@@ -232,7 +258,7 @@ def test_beam_vs_oracle_other_seeds(cases, manifests):
             seq, score, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=True)
             oseq, oscore, _ = R.forward(ocfg, sd, img, text, is_test=True)
         assert seq[0].tolist() == oseq[0].tolist(), (iseed, eb)
-        assert abs(score - oscore) <= 1e-3
+        assert abs(score - oscore) <= _score_tol(m, seq.shape[1])
 
 
 @pytest.mark.parametrize("name", ["ts0_beam5", "c0_beam3", "c0_beam3_end", "s0_beam10", "s0_beam10_late", "ts0_beam4_nofinish",
@@ -327,7 +353,7 @@ def test_beam_with_one_cross_attention_block_per_sample(cases):
         with torch.no_grad():
             seq, score, _ = m(img, text, is_train=False, is_test=True)
         assert seq[0].tolist() == c["seq"], (name, seq, c["seq"])
-        assert abs(score - c["score"]) <= max(1e-3, 2e-5 * len(c["seq"]))
+        assert abs(score - c["score"]) <= _score_tol(m, len(c["seq"]))
     c = _case(cases, "beam", "t2_beam5")
     for eb, beam in [(1.8, 5), (1.75, 3), (0.0, 6)]:
         cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], eb, beam_size=beam)
@@ -338,7 +364,7 @@ def test_beam_with_one_cross_attention_block_per_sample(cases):
             got = m.beam_search_batch(img)
         for (s1, v1), (s2, v2) in zip(ref, got):
             assert torch.equal(s1, s2), (eb, beam)
-            assert abs(v1 - v2) <= max(1e-3, 2e-5 * s1.shape[1])
+            assert abs(v1 - v2) <= _score_tol(m, s1.shape[1])
 
 
 def test_batched_attn_beam_equals_per_sample_beam(cases):
@@ -609,9 +635,11 @@ def test_shortcut_inside_conv2_equals_the_separate_shortcut_kernel(monkeypatch, 
     assert torch.isfinite(outs[0][0]).all()
     assert not torch.equal(outs[0][0], outs[1][0])  # (the two paths really differ: otherwise the switch is dead)
     scale = max(1.0, float(outs[1][0].abs().max()))
-    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * scale
+    # (fp16x2, the default behind a ViT encoder: the unfused path also rounds the shortcut to an fp16 record in between)
+    f16 = m.effective_conv_precision() == "fp16x2"
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= (3e-3 if f16 else 1e-4) * scale
     assert torch.equal(outs[0][1], outs[1][1])
-    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 5e-4
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= (1e-3 if f16 else 5e-4)
 
 
 def test_error_paths_raise_instead_of_crashing():

@@ -358,7 +358,7 @@ def test_config_c3_per_gpu_shard_properties(cases):
     per-gradient events; what the 8-GPU run uses) returning exactly the plain path's gradients."""
     from doc2tex_amd.dist import GradSync
     _, m = engine_model("C3", 150)
-    assert m.conv_precision == "bf16x3"
+    assert m.conv_precision in ("bf16x3", "fp16x2")  # (the training step runs split-bf16 under either: DESIGN.md section 3)
     state0 = {k: v.clone() for k, v in m.state_dict().items()}
     img = synth.synth_images(32, 128, 512, seed=1400)
     text = synth.synth_labels(32, max_len=150, seed=1400)
