@@ -529,11 +529,17 @@ typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 
 // F16 (ConvP::f16, fp16x2 mode): A = the fp16 hi halves of the records only (12 instead of 16 fragment reads, 8 instead of
 // 12 LDS-DMA pieces per loader and K-step), B = fp16 hi / lo planes, 32 MFMAs (x * w_lo, x * w_hi) instead of 48
-template <int BM, int BN, int WM, int WN, int NL, bool STG, int ABL = 0, bool F16 = false>  // ABL (probe builds): 1 no LDS-DMA, 2 no MFMA, 4 LDS-DMA never awaited
+// KPB = 2 (an experiment for the fp16x2 builds: 32 KB stages, four of them): ONE barrier per TWO K-steps, on the hypothesis
+// that a barrier interval has a fixed cost of 550-650 cycles in either arithmetic (K-step 2200 cycles for 1536 of MFMAs in
+// split-bf16, 1580 for 1024 in fp16x2).  Measured: correct, and slower -- dominant layer 1.12 vs 1.04 ms in situ, 1786 vs
+// 1889 formulas/s (the loaders then issue sixteen pieces in one burst).  Not instantiated.
+template <int BM, int BN, int WM, int WN, int NL, bool STG, int ABL = 0, bool F16 = false, int KPB = 1>  // ABL (probe builds): 1 no LDS-DMA, 2 no MFMA, 4 LDS-DMA never awaited
 __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned char* smem) {
   constexpr int NW = WM * WN, NT = (NW + NL) * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
+  constexpr int NSTG = KPB == 2 ? 4 : 3;  // LDS stages in the ring
+  static_assert(KPB == 1 || KPB == 2, "one or two K-steps per barrier");
   constexpr bool UPFRONT = ABL != 8;  // (8: the reads as the compiler schedules them, for A/B timing in probe builds)
   static_assert(MI >= 2 && (MI & 1) == 0 && NJ >= 1 && NL > 0, "wave tile / loader configuration");
   using Issuer = DmaIssuer<BM, BN, NL, ABL == 1 ? 1 : 0, true, F16>;
@@ -557,6 +563,14 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       dma.issue(p, smem, 0, 0);
       if (KT > 1) dma.issue(p, smem, 1, 1);
       int nxt2 = 2;
+      if (KPB == 2) {
+        for (int kt = 0; kt < KT; kt += 2) {
+          wait_vm<0>();                  // the pair of stages (kt, kt + 1) has landed ...
+          __builtin_amdgcn_s_barrier();  // ... for every loader; the compute waves are done with the pair before it
+          if (kt + 2 < KT) dma.issue(p, smem, kt + 2, (kt + 2) & 3);
+          if (kt + 3 < KT) dma.issue(p, smem, kt + 3, (kt + 3) & 3);
+        }
+      } else
       for (int kt = 0; kt < KT; ++kt) {
         if (ABL != 4) { if (kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
@@ -636,7 +650,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
     const bool late = STG && wave >= NW / 2;
     if (!late) {
       for (int kt = 0; kt < KT; ++kt) {
-        __builtin_amdgcn_s_barrier();  // stage kt is complete for everyone; nobody reads stage kt-1 any more
+        if (KPB == 1 || (kt & 1) == 0) __builtin_amdgcn_s_barrier();  // stage kt (and kt + 1) complete for everyone; nobody reads the stages before
         const unsigned char* ah = smem + cur * STAGE;
         // all sixteen fragment reads of the K-step go out before the first MFMA (the SIMD partner's carried MFMAs cover
         // their latency); left to itself the compiler interleaves them in three groups, each with its own wait
@@ -647,12 +661,12 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
         if (UPFRONT) __builtin_amdgcn_sched_barrier(0);
         mma(H0{}, fah, fal, fbh, fbl);
         mma(H1{}, fch, fcl, fbh, fbl);
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = cur == NSTG - 1 ? 0 : cur + 1;
       }
     } else {
       bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
-      auto step = [&](auto carried_c) {
-        __builtin_amdgcn_s_barrier();
+      auto step = [&](auto carried_c, int kt) {
+        if (KPB == 1 || (kt & 1) == 0) __builtin_amdgcn_s_barrier();
         const unsigned char* ah = smem + cur * STAGE;
         if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);  // second half of the previous K-step
         __builtin_amdgcn_sched_barrier(0);  // (no reads of this step hoisted above: the carried fragments die first)
@@ -669,10 +683,10 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
         if (!UPFRONT) read_a(ah, H1{}, gah, gal);
         // the reads have returned before this wave arrives at the next barrier (after it the stage may be overwritten)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = cur == NSTG - 1 ? 0 : cur + 1;
       };
-      step(H0{});  // peeled: nothing carried into K-step 0
-      for (int kt = 1; kt < KT; ++kt) step(H1{});
+      step(H0{}, 0);  // peeled: nothing carried into K-step 0
+      for (int kt = 1; kt < KT; ++kt) step(H1{}, kt);
       mma(H1{}, gah, gal, gbh, gbl);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
