@@ -232,7 +232,7 @@ int d2t_decode_attn_beam(d2t_ctx* ctx, const float* memory, int32_t T, int32_t b
 
 /* ---- convolution arithmetic ------------------------------------------------
  * D2T_CONV_FP32   exact fp32 on v_mfma_f32_32x32x2_f32.
- * D2T_CONV_BF16X3 (default of d2t_create, as of doc2tex_amd.Model) backbone / patch-embed convolutions on the bf16 matrix cores with each fp32 operand
+ * D2T_CONV_BF16X3 (default of d2t_create; doc2tex_amd.Model selects FP16X2 for the stacks with a ViT encoder) backbone / patch-embed convolutions on the bf16 matrix cores with each fp32 operand
  *                 split into two bf16 (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate): ~2^-17 relative
  *                 product error, measured logits error 2.4e-5 against the 1e-3 budget.  Takes effect at the
  *                 next d2t_encode.
