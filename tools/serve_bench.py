@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--group", type=int, default=6, help="decode groups (batches per decode step loop)")
+    ap.add_argument("--chains", type=int, default=3, help="decode chains in flight (as bench.py)")
     ap.add_argument("--page-sets", type=int, default=4, help="distinct batches of pages cycled through")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -38,7 +39,7 @@ def main():
     tmpl = {k: v for k, v in model.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     model.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
     model.eval().to(dev)
-    model.pipelined, model.decode_chains, model.decode_group, model.reserved_blocks = True, 2, args.group, 0 if args.group > 1 else 64
+    model.pipelined, model.decode_chains, model.decode_group, model.reserved_blocks = True, args.chains, args.group, 0 if args.group > 1 else 64
     opt = {"imgH": None, "imgW": None, "max_dimension": cfg["max_dimension"], "min_dimension": [32, 32], "mean": 0.5,
            "std": 0.5, "rgb": False, "pad": False, "device": str(dev)}
     pre = Preprocessor(opt, "demo")
