@@ -729,13 +729,16 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
 // Same K order, same three MFMAs per product in the same order: bit-identical to conv_bf16x3p16_body, which takes the rows that
 // do not fill whole rounds of 256-row tiles (launch_conv_bf16x3p) and every layer this tile does not fit.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool STG, int ABL = 0>
+// F16 (ConvP::f16): fp16 hi halves of the records x fp16 hi / lo weights, two MFMAs per product; 48 KB stages, THREE of them
+// (the LDS-DMA two K-steps ahead, as in conv_bf16x3p16_body).
+template <bool STG, int ABL = 0, bool F16 = false>
 __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned char* smem) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NJ = WTN / 16, MH = MI / 2;
-  using Issuer = DmaIssuer<BM, BN, NW, ABL == 1 ? 1 : 0, true>;
-  constexpr int PLANE_A = Issuer::PLANE_A, PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE;
-  static_assert(BM * (BN / 2) * 4 <= 2 * STAGE, "half of the fp32 epilogue tile must fit in the staging area");
+  using Issuer = DmaIssuer<BM, BN, NW, ABL == 1 ? 1 : 0, true, F16>;
+  constexpr int PLANE_B = Issuer::PLANE_B, STAGE = Issuer::STAGE, A_BYTES = Issuer::A_BYTES, PER_STEP = Issuer::PER_STEP;
+  constexpr int NSTG = F16 ? 3 : 2;  // LDS stages; the LDS-DMA runs NSTG - 1 K-steps ahead
+  static_assert(BM * (BN / 2) * 4 <= NSTG * STAGE, "half of the fp32 epilogue tile must fit in the staging area");
   const int nt = (p.Cout + BN - 1) / BN;
   const int ntiles = nt * ((p.M + BM - 1) / BM);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -749,6 +752,7 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
     Issuer dma;
     dma.setup(p, m0, n0, wave, lane);
     dma.issue(p, smem, 0, 0);
+    if (NSTG == 3 && KT > 1) dma.issue(p, smem, 1, 1);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, q = lane >> 4;
     f32x4v acc[MI][NJ];
@@ -757,10 +761,11 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     // fragment offsets: rows 16 apart share the swizzle (aswz: (row >> 1) & 7, pswz16: (row >> 2) & 2), lo = hi ^ 64
-    const int offa0 = (wm * WTM + r) * 128 + aswz(wm * WTM + r, q) * 16;
+    const int offa0 = F16 ? (wm * WTM + r) * PROW + pswz16(wm * WTM + r, q) * 16 : (wm * WTM + r) * 128 + aswz(wm * WTM + r, q) * 16;
+    constexpr int AROW = F16 ? PROW : 128;  // bytes per A row in LDS
     const int offb0 = (wn * WTN + r) * PROW + pswz16(wn * WTN + r, q) * 16;
     auto read_b = [&](const unsigned char* ah, bf16x8 (&fbh)[NJ], bf16x8 (&fbl)[NJ]) {
-      const unsigned char* bh = ah + 2 * PLANE_A + offb0;
+      const unsigned char* bh = ah + A_BYTES + offb0;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         fbh[j] = *reinterpret_cast<const bf16x8*>(bh + j * 16 * PROW);
@@ -771,8 +776,8 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
       constexpr int half = decltype(half_c)::value;
 #pragma unroll
       for (int i = 0; i < MH; ++i) {
-        fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa0 + (half * MH + i) * 16 * 128);
-        fal[i] = *reinterpret_cast<const bf16x8*>(ah + (offa0 ^ 64) + (half * MH + i) * 16 * 128);
+        fah[i] = *reinterpret_cast<const bf16x8*>(ah + offa0 + (half * MH + i) * 16 * AROW);
+        if (!F16) fal[i] = *reinterpret_cast<const bf16x8*>(ah + (offa0 ^ 64) + (half * MH + i) * 16 * AROW);
       }
     };
     auto mma = [&](auto half_c, const bf16x8 (&fah)[MH], const bf16x8 (&fal)[MH], const bf16x8 (&fbh)[NJ], const bf16x8 (&fbl)[NJ]) {
@@ -786,6 +791,13 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
             continue;
           }
           f32x4v c = acc[half * MH + i][j];
+          if (F16) {
+            const f16x8v xa = __builtin_bit_cast(f16x8v, fah[i]);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa, __builtin_bit_cast(f16x8v, fbl[j]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa, __builtin_bit_cast(f16x8v, fbh[j]), c, 0, 0, 0);
+            acc[half * MH + i][j] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], c, 0, 0, 0);
@@ -794,13 +806,13 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    int cur = 0;
+    int cur = 0, nxt = NSTG - 1;  // stage of K-step kt / of the K-step whose LDS-DMA is issued at kt
     const bool late = STG && wave >= NW / 2;
     if (!late) {
       for (int kt = 0; kt < KT; ++kt) {
-        if (ABL != 4) wait_vm<0>();      // this wave's pieces of stage kt have landed ...
-        __builtin_amdgcn_s_barrier();    // ... and everyone's; nobody reads stage kt - 1 (the other buffer) any more
-        if (kt + 1 < KT) dma.issue(p, smem, kt + 1, cur ^ 1);
+        if (ABL != 4) { if (NSTG == 3 && kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>(); }  // this wave's pieces of stage kt have landed ...
+        __builtin_amdgcn_s_barrier();    // ... and everyone's; nobody reads stage kt - 1 any more
+        if (kt + NSTG - 1 < KT) dma.issue(p, smem, kt + NSTG - 1, nxt);
         __builtin_amdgcn_sched_barrier(0);  // keep the LDS-DMA issue ahead of the ds_reads / MFMAs
         const unsigned char* ah = smem + cur * STAGE;
         bf16x8 fbh[NJ], fbl[NJ];
@@ -815,17 +827,18 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
           read_a(ah, H1{}, fah, fal);
           mma(H1{}, fah, fal, fbh, fbl);
         }
-        cur ^= 1;
+        cur = cur == NSTG - 1 ? 0 : cur + 1;
+        nxt = nxt == NSTG - 1 ? 0 : nxt + 1;
       }
     } else {
       bf16x8 gah[MH], gal[MH], gbh[NJ], gbl[NJ];  // second-half A fragments and the step's B fragments, carried across the barrier
       auto step = [&](auto carried_c, int kt) {
-        if (ABL != 4) wait_vm<0>();
+        if (ABL != 4) { if (NSTG == 3 && kt + 1 < KT) wait_vm<PER_STEP>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
         const unsigned char* ah = smem + cur * STAGE;
         if (decltype(carried_c)::value) mma(H1{}, gah, gal, gbh, gbl);  // second half of the previous K-step (the SIMD partner issues its LDS-DMA meanwhile)
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) dma.issue(p, smem, kt + 1, cur ^ 1);
+        if (kt + NSTG - 1 < KT) dma.issue(p, smem, kt + NSTG - 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         read_b(ah, gbh, gbl);
         {
@@ -835,7 +848,8 @@ __device__ __forceinline__ void conv_bf16x3w16_body(const ConvP& p, unsigned cha
         }
         read_a(ah, H1{}, gah, gal);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the next barrier
-        cur ^= 1;
+        cur = cur == NSTG - 1 ? 0 : cur + 1;
+        nxt = nxt == NSTG - 1 ? 0 : nxt + 1;
       };
       step(H0{}, 0);
       for (int kt = 1; kt < KT; ++kt) step(H1{}, kt);
@@ -1710,6 +1724,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256_ns(const ConvP 
   conv_bf16x3w16_body<false>(p, smem);
 }
 
+// fp16x2 build of the 256 x 256 tile (three 48 KB stages)
+__global__ __launch_bounds__(512, 2) void conv_f16x2w16_256x256(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (256 * PROW + 2 * 256 * PROW)];
+  conv_bf16x3w16_body<true, 0, true>(p, smem);
+}
+__global__ __launch_bounds__(512, 2) void conv_f16x2w16_256x256_k4608(const ConvP p) {  // the dominant shape, own symbol
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (256 * PROW + 2 * 256 * PROW)];
+  conv_bf16x3w16_body<true, 0, true>(p, smem);
+}
+
 // fp16x2 builds of the pipelined kernel (ConvP::f16): 32 KB stages; the 128 KB are the epilogue's fp32 tile
 __global__ __launch_bounds__(768, 3) void conv_f16x2p16_256x128_s(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[256 * 128 * 4];
@@ -1788,6 +1812,31 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   }
   if (p.f16) {  // fp16x2 mode: the pipelined 16x16x32 kernel only
     if (p.pipelined != 3) return hipErrorInvalidValue;
+    static const int f16_wide = getenv("D2T_F16_WIDE") ? atoi(getenv("D2T_F16_WIDE")) : 0;
+    if (f16_wide && p.Cout >= 256 && p.m_base == 0) {  // 256 x 256 tiles for whole rounds, the 256 x 128 kernel for the leftover tile rows
+      const int ntw = (p.Cout + 255) / 256, mtw = (p.M + 255) / 256;
+      int tw = mtw * ntw, gw = grid < tw ? grid : tw;
+      const int rounds = tw / gw, rem = tw - rounds * gw;
+      int tail_from = -1;
+      if (rounds >= 1 && rem > 0 && rem < 0.5f * gw) {
+        const int main_mt = rounds * gw / ntw;
+        tail_from = main_mt * 256;
+        q.M = tail_from;
+        tw = main_mt * ntw;
+        if (gw > tw) gw = tw;
+      }
+      if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_f16x2w16_256x256_k4608, dim3(gw), dim3(512), 0, s, p2);
+      else hipLaunchKernelGGL(conv_f16x2w16_256x256, dim3(gw), dim3(512), 0, s, p2);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess || tail_from < 0) return e;
+      ConvP t = p;
+      t.wave_prio = prio;
+      t.m_base = tail_from;
+      const int tt = ((p.M - tail_from + 255) / 256) * nt;
+      hipLaunchKernelGGL(conv_f16x2p16_256x128_s, dim3(tt < grid ? tt : grid), dim3(768), 0, s, t);
+      return hipGetLastError();
+    }
+    tiles = ((p.M - p.m_base + 255) / 256) * nt;
     if (grid > tiles) grid = tiles;
     if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_f16x2p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_f16x2p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);

@@ -487,3 +487,24 @@ def test_fp16x2_convolution_with_the_max_pool_fused(shape):
         lib.d2t_op_set_conv_kernel(3, 0)
     ref = F.max_pool2d(y.cpu().permute(0, 3, 1, 2), 2, 2)
     assert torch.isfinite(yp).all() and torch.equal(yp.cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_fp16x2_records_saturate_instead_of_overflowing():
+    """fp16 records hold at most 65504: a feature map beyond that saturates (no inf / NaN reaches the next layer).  Trained
+    models stay orders of magnitude below (the fixtures' largest feature-map value is a few hundred)."""
+    lib = _lib.require_device()
+    B, H, W, Cin, Cout = 1, 8, 40, 32, 64
+    x = torch.full((B, H, W, Cin), 300.0, device=DEV)
+    w = torch.full((Cout, 3, 3, Cin), 1.0, device=DEV)  # sums of up to 9 * 32 * 300 = 86400 > 65504
+    b = torch.zeros(Cout, device=DEV)
+    try:
+        assert lib.d2t_op_set_conv_kernel(8, 0) == 0
+        y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), B, H, W, Cin, Cout, 3, 3,
+                                              1, 1, 1, 1, 1, _lib.stream_of(x)) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.d2t_op_set_conv_kernel(3, 0)
+    y = y.cpu()
+    assert torch.isfinite(y).all() and float(y.max()) == 65504.0  # interior pixels: 86400 -> saturated
+    assert float(y[0, 0, 0, 0]) == 4 * 32 * 300.0               # a corner pixel (4 taps): 38400, exact in fp16

@@ -7,5 +7,5 @@ for kind in ${KINDS:-3 6 7}; do
   rm -rf /tmp/ck_$kind
   rocprofv3 --kernel-trace --stats -d /tmp/ck_$kind -o t --output-format csv -- python3 $R/tools/probe/conv_abl.py ${REPS:-30} $kind > /tmp/ck_$kind.log 2>&1
   f=$(find /tmp/ck_$kind -name "*kernel_stats.csv" | head -1)
-  echo "kind=$kind: $(grep -i "conv_bf16x3[pbw]16" $f | cut -d, -f1-4 | tr '\n' ' ')"
+  echo "kind=$kind: $(grep -i "conv_\(bf16x3\|f16x2\)[pbw]16" $f | cut -d, -f1-4 | tr '\n' ' ')"
 done
