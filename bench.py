@@ -567,8 +567,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "fp16x2"],
                     help="convolution arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs per product), or fp16 feature maps x fp16 "
-                         "hi / lo weights in the backbone (2 MFMAs per product).  Default: the Model's own default for the stack "
-                         "(fp16x2 behind a ViT encoder, bf16x3 otherwise and for the training step: DESIGN.md section 3)")
+                         "hi / lo weights in the backbone (2 MFMAs per product; opt-in, DESIGN.md section 3).  Default: the Model's "
+                         "own default (bf16x3); the other 16-bit arithmetic runs beside it under `secondary`")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
     ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16", "band16", "wide16"],

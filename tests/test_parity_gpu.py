@@ -23,7 +23,8 @@ def _case(cases, kind, name):
 def _score_tol(m, n):
     """Bar for a beam score = a SUM of n log-probabilities.  Split-bf16 / fp32 encoders hold each to ~1e-5 (the logits bar is
     1e-3 per value): 1e-3 for the short fixtures, 2e-5 per token for the 151-token one (a sum around -520, whose own fp32
-    spacing is 6e-5).  fp16x2 encoder memory (the default behind a ViT encoder) moves a logit by up to 2e-4: 5e-3 on the sum."""
+    spacing is 6e-5).  fp16x2 encoder memory (opt-in; these tests run in it under D2T_CONV_PRECISION=fp16x2) moves a logit by
+    a few 1e-4: 5e-3 on the sum."""
     return 5e-3 if m.effective_conv_precision() == "fp16x2" else max(1e-3, 2e-5 * n)
 
 
@@ -65,27 +66,6 @@ def test_greedy_vs_reference_fixture(cases, name):
     steps = z["logit_steps"].tolist()
     dl = float(np.abs(logits[:, steps].numpy() - z["logits_sample"]).max())
     assert dl <= LOGIT_TOL, f"logits differ by {dl}"
-
-
-@pytest.mark.parametrize("name", ["t2_greedy", "t2_greedy_early", "c2_small_crop", "c2_greedy", "c4_greedy_160", "c4_greedy_96"])
-def test_split_bf16_greedy_vs_reference_fixture_behind_a_vit_encoder(cases, name):
-    """The HybridViT stacks default to fp16x2 arithmetic since round 3 (tests above; tests/test_fp16x2_gpu.py); their split-bf16
-    form (conv_precision = 'bf16x3', the default of rounds 1-2 and of the bench's `secondary.bf16x3`) keeps its tighter bars."""
-    c = _case(cases, "greedy", name)
-    z = np.load(os.path.join(GOLD, name + ".npz"))
-    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c.get("beam_size"))
-    m.conv_precision = "bf16x3"
-    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
-    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
-    with torch.no_grad():
-        mem, _, _ = m.forward_encoder(img)
-        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
-    mem, preds, logits = mem.cpu(), preds.cpu(), logits.cpu()
-    dmem = float(np.abs(mem[:, z["mem_rows"].tolist()].numpy() - z["mem_sample"]).max()) / max(1.0, c["mem_absmax"])
-    assert dmem <= MEM_TOL["bf16x3"], f"encoder memory rel err {dmem}"
-    assert np.array_equal(preds.numpy(), z["tokens"]), "greedy token ids differ from the reference"
-    dl = float(np.abs(logits[:, z["logit_steps"].tolist()].numpy() - z["logits_sample"]).max())
-    assert dl <= 2e-4, f"logits differ by {dl}"  # (a fifth of the north_star bar: what split-bf16 holds on these fixtures)
 
 
 @pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop"])
@@ -635,7 +615,7 @@ def test_shortcut_inside_conv2_equals_the_separate_shortcut_kernel(monkeypatch, 
     assert torch.isfinite(outs[0][0]).all()
     assert not torch.equal(outs[0][0], outs[1][0])  # (the two paths really differ: otherwise the switch is dead)
     scale = max(1.0, float(outs[1][0].abs().max()))
-    # (fp16x2, the default behind a ViT encoder: the unfused path also rounds the shortcut to an fp16 record in between)
+    # (fp16x2, under D2T_CONV_PRECISION=fp16x2: the unfused path also rounds the shortcut to an fp16 record in between)
     f16 = m.effective_conv_precision() == "fp16x2"
     assert float((outs[0][0] - outs[1][0]).abs().max()) <= (3e-3 if f16 else 1e-4) * scale
     assert torch.equal(outs[0][1], outs[1][1])
