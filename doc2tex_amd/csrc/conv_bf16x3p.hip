@@ -1724,6 +1724,18 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3w16_256x256_ns(const ConvP 
   conv_bf16x3w16_body<false>(p, smem);
 }
 
+// 64 x 128 tile on the same body (eight 64 x 16 wave tiles + four loaders, 24 KB stages): the rows of a last, sparsely
+// filled round of 256-row tiles (launch_conv_bf16x3p).  Same MFMA shape, K order and products: bit-identical to the 256 x 128
+// build, so which of the two computes a row never shows in the values.
+__global__ __launch_bounds__(768, 3) void conv_bf16x3p16_64x128_tail(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (2 * 64 * PROW + 2 * 128 * PROW)];
+  conv_bf16x3p16_body<64, 128, 1, 8, 4, false>(p, smem);
+}
+__global__ __launch_bounds__(768, 3) void conv_f16x2p16_64x128_tail(const ConvP p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (64 * PROW + 2 * 128 * PROW)];  // 20 KB stages (>= the 32 KB fp32 tile)
+  conv_bf16x3p16_body<64, 128, 1, 8, 4, false, 0, true>(p, smem);
+}
+
 // fp16x2 build of the 256 x 256 tile (three 48 KB stages)
 __global__ __launch_bounds__(512, 2) void conv_f16x2w16_256x256(const ConvP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * (256 * PROW + 2 * 256 * PROW)];
@@ -1837,9 +1849,26 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
       return hipGetLastError();
     }
     tiles = ((p.M - p.m_base + 255) / 256) * nt;
+    int tail_f = -1;  // whole rounds only, as for the split-bf16 build below
+    static const float tail_frac_f = getenv("D2T_CONV_TAIL") ? (float)atof(getenv("D2T_CONV_TAIL")) : 0.5f;
+    if (p.split_tail && p.m_base == 0) {
+      const int rounds = tiles / grid, rem = tiles - rounds * grid;
+      if (rounds >= 1 && rem > 0 && rem < tail_frac_f * grid) {
+        const int main_mt = rounds * grid / nt;
+        tail_f = main_mt * 256;
+        q.M = tail_f;
+        tiles = main_mt * nt;
+      }
+    }
     if (grid > tiles) grid = tiles;
     if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_f16x2p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_f16x2p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);
+    hipError_t ef = hipGetLastError();
+    if (ef != hipSuccess || tail_f < 0) return ef;
+    ConvP tf = p;
+    tf.wave_prio = prio;
+    tf.m_base = tail_f;
+    hipLaunchKernelGGL(conv_f16x2p16_64x128_tail, dim3(((p.M - tail_f + 63) / 64) * nt), dim3(768), 0, s, tf);
     return hipGetLastError();
   }
   if (p.pipelined == 7 && p.Cout >= 256 && p.m_base == 0) {
@@ -1901,6 +1930,32 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
       return hipGetLastError();
     }
     static const int stagger16 = getenv("D2T_CONV_STAGGER") ? atoi(getenv("D2T_CONV_STAGGER")) : 1;
+    // Whole rounds only (round 3, the 16x16x32 form of round 2's hand-over): when the last round of 256-row tiles would be
+    // less than half full (the dominant layer at B = 64: 2064 tiles = eight rounds + 16 tiles; at B = 32: 4.03 rounds), the
+    // rows behind the whole rounds go to the 64 x 128 build of the same body.  The caller switches it off (split_tail = 0)
+    // while decode loops are in flight: their kernels run in exactly that hole.
+    static const float tail16 = getenv("D2T_CONV_TAIL") ? (float)atof(getenv("D2T_CONV_TAIL")) : 0.5f;
+    int tail_from16 = -1;
+    if (p.pipelined == 3 && p.split_tail && p.m_base == 0 && !abl_probe()) {
+      const int g0 = grid, rounds = tiles / g0, rem = tiles - rounds * g0;
+      if (rounds >= 1 && rem > 0 && rem < tail16 * g0) {
+        const int main_mt = rounds * g0 / nt;  // whole rows of tiles that fit into the whole rounds
+        tail_from16 = main_mt * 256;
+        q.M = tail_from16;
+        tiles = main_mt * nt;
+        if (grid > tiles) grid = tiles;
+      }
+    }
+    auto launch_tail16 = [&]() -> hipError_t {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess || tail_from16 < 0) return e;
+      ConvP t = p;
+      t.wave_prio = prio;
+      t.m_base = tail_from16;
+      const int tt = ((p.M - tail_from16 + 63) / 64) * nt;
+      hipLaunchKernelGGL(conv_bf16x3p16_64x128_tail, dim3(tt), dim3(768), 0, s, t);
+      return hipGetLastError();
+    };
 #ifdef D2T_PROBES
     if (abl_probe()) {
       switch (abl_probe()) {
@@ -1915,7 +1970,7 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
     if (!stagger16) hipLaunchKernelGGL(conv_bf16x3p16_256x128, dim3(grid), dim3(768), 0, s, p2);
     else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3p16_256x128_s_k4608, dim3(grid), dim3(768), 0, s, p2);
     else hipLaunchKernelGGL(conv_bf16x3p16_256x128_s, dim3(grid), dim3(768), 0, s, p2);
-    return hipGetLastError();
+    return launch_tail16();
   }
   // Whole rounds only.  The dominant layer has 2064 tiles: eight rounds on 256 CUs and then sixteen tiles that keep 16 CUs
   // busy for a ninth of the kernel's duration while 240 idle.  When the last round is less than `tail_frac` full, the pipelined
