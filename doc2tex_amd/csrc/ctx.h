@@ -106,6 +106,7 @@ struct d2t_ctx {
   // D2T_CONV_FP16X2 (on top of conv_bf16x3): the backbone's feature maps are fp16 records and its split-record convolutions run
   // x16 * w_lo + x16 * w_hi (two MFMAs per product); everything that takes fp32 input stays on the bf16x3 kernels
   bool conv_f16 = false;
+  int stream_prio = 0;  // priority the decode streams were acquired with (they return to the process-wide pool: engine.hip)
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
   int conv_pipelined = 3;    // d2t_set_conv_kernel: 3 = pipelined 256x128 split-bf16 kernel on 16x16x32 MFMAs (default), 1 = the same on 32x32x16, 2 = 1 + patch-resident 3x3, 0 = 128x128 (two per CU)

@@ -3,6 +3,7 @@
 // conv_mfma.hip / ops.hip on the caller's HIP stream; there is no CPU compute
 // path and no fallback.
 #include "ctx.h"
+#include <mutex>
 
 namespace {
 
@@ -306,6 +307,32 @@ int get_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) 
 int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out) { return get_pe2d(c, h, w, C, s, out); }
 hipError_t d2t_internal_conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) { return conv_timed(c, p, s); }
 
+// Process-wide pool of the engine's decode streams.  The first streams a process creates get hardware queues of their own;
+// streams created after others were destroyed can end up sharing one (measured: the SECOND context of a process decoded its
+// three chains at the rate of ~2.4: 2830 instead of 3810 formulas/s on config C1).  A destroyed context's streams are
+// therefore kept and handed, in the same roles, to the next context of that device and priority.
+namespace {
+std::mutex g_stream_mu;
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;
+hipError_t acquire_stream(int device, int prio, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& v = g_stream_pool[std::make_pair(device, prio)];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+}
+void release_stream(int device, int prio, hipStream_t st) {
+  hipStreamSynchronize(st);
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  g_stream_pool[std::make_pair(device, prio)].push_back(st);
+}
+}  // namespace
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================
@@ -362,9 +389,9 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(c, hipStreamCreateWithPriority(&c->dstream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
-    for (int i = 1; i < d2t_ctx::MAXC; ++i)
-      HIPCHK(c, hipStreamCreateWithPriority(&c->chains[i].stream, hipStreamNonBlocking, getenv("D2T_NO_PRIO") ? lo : hi));
+    c->stream_prio = getenv("D2T_NO_PRIO") ? lo : hi;
+    HIPCHK(c, acquire_stream(c->device, c->stream_prio, &c->dstream));
+    for (int i = 1; i < d2t_ctx::MAXC; ++i) HIPCHK(c, acquire_stream(c->device, c->stream_prio, &c->chains[i].stream));
   }
   HIPCHK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   for (int i = 0; i < d2t_ctx::MAXC; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
@@ -402,7 +429,6 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->h_steps) hipHostFree(c->h_steps);
   for (hipEvent_t ev : c->ticket_ev) if (ev) hipEventDestroy(ev);
-  if (c->dstream) hipStreamDestroy(c->dstream);
   if (c->dout) hipFree(c->dout);
   for (int i = 0; i < d2t_ctx::MAXC; ++i) {
     if (i == c->active_chain) continue;  // (the active chain's buffers are the members freed around here)
@@ -411,7 +437,11 @@ void d2t_destroy(d2t_ctx* c) {
     if (o.dws) hipFree(o.dws);
     if (o.dstate) hipFree(o.dstate);
     if (o.out) hipFree(o.out);
-    if (o.stream) hipStreamDestroy(o.stream);
+  }
+  // the streams go back to the process-wide pool, last acquired first (the next context takes them in the same roles)
+  for (int i = d2t_ctx::MAXC - 1; i >= 0; --i) {
+    hipStream_t st = i == c->active_chain ? c->dstream : c->chains[i].stream;
+    if (st) release_stream(c->device, c->stream_prio, st);
   }
   delete c;
 }
