@@ -185,3 +185,22 @@ def test_two_models_on_two_gpus_in_one_process():
         p, l, _ = moved(synth.synth_images(2, 48, 64).to("cuda:0"), torch.ones(2, 1, dtype=torch.long, device="cuda:0"),
                         is_train=False)
     assert moved.engine().device == 0 and torch.equal(p.cpu(), outs[0][0])
+
+
+def test_conv_precision_default_and_switches(monkeypatch):
+    """Model.conv_precision: split-bf16 by default for every stack ('auto' resolves to it), fp16x2 / fp32 by request; an
+    unknown mode is refused at assignment."""
+    from doc2tex_amd import Model, synth
+    monkeypatch.delenv("D2T_CONV_PRECISION", raising=False)
+    for name in ("T2", "T1"):
+        m = Model(synth.make_config(name, max_seq_len=8))
+        assert m.conv_precision == "bf16x3" and m.effective_conv_precision() == "bf16x3"
+        m.conv_precision = "fp16x2"
+        assert m.conv_precision == "fp16x2" and m.effective_conv_precision() == "fp16x2"  # explicit: never stepped back
+        m.conv_precision = "fp32"
+        assert m.effective_conv_precision() == "fp32"
+        with pytest.raises(ValueError):
+            m.conv_precision = "bf16"
+    monkeypatch.setenv("D2T_CONV_PRECISION", "fp16x2")
+    m = Model(synth.make_config("T2", max_seq_len=8))
+    assert m.conv_precision == "fp16x2"
