@@ -383,7 +383,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "bound": "mfma",
             "kernel": ("fp16x2 implicit-GEMM convolution (fp16 records x fp16 hi / lo weights), pipelined 256x128 kernel on "
                        "v_mfma_f32_16x16x32_f16" if f16 else
-                       _PMC.get("kernel_short") or ("split-bf16 implicit-GEMM convolution, pipelined 256x128 kernel" if bf
+                       _PMC.get("kernel_short") or ("split-bf16 implicit-GEMM convolution, pipelined 256x128 kernel on v_mfma_f32_16x16x32_bf16" if bf
                                                       else "conv_mfma_kernel<128,128>")) +
                       (" (512->512 3x3 conv @16x129 as implicit GEMM)" if tuple(dom) == (132096, 512, 4608)
                        else f" (the most expensive GEMM shape of the timed region, M x N x K = {dom[0]} x {dom[1]} x {dom[2]})"),
