@@ -263,6 +263,8 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
     model.eval().to(dev)
     if args.precision:
         model.conv_precision = args.precision
+    if args.mixed_units is not None:
+        model.mixed_units = args.mixed_units
     precision = model.effective_conv_precision()  # the Model's default for this stack unless --precision says otherwise
     early = args.end_bias != 0.0
     model.pipelined = not args.no_pipeline and not early
@@ -272,8 +274,6 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
     model.reserved_cus = args.reserve_cus
     if args.conv_kernel:
         model.conv_kernel = args.conv_kernel
-    if args.winograd is not None:
-        model.conv_winograd = args.winograd
     host_img = synth.synth_images(B, H, W, seed=1000 + rank).pin_memory()  # each rank its own shard
     img = host_img.to(dev)
     text = torch.full((B, 1), 1, dtype=torch.long, device=dev)
@@ -377,12 +377,15 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(precision)
         f16 = precision == "fp16x2"
-        bf = precision == "bf16x3" or f16  # (16-bit matrix-core operands: the bf16 / fp16 dense peak)
+        mixed = precision == "mixed"  # split-bf16 with the two-MFMA fp16 arithmetic in `mixed_units` of the 512 -> 512 units
+        bf = precision == "bf16x3" or f16 or mixed  # (16-bit matrix-core operands: the bf16 / fp16 dense peak)
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         roofline = {
             "bound": "mfma",
             "kernel": ("fp16x2 implicit-GEMM convolution (fp16 records x fp16 hi / lo weights), pipelined 256x128 kernel on "
                        "v_mfma_f32_16x16x32_f16" if f16 else
+                       f"implicit-GEMM convolution, pipelined 256x128 kernel on 16x16x32 MFMAs: the launches of this shape in the "
+                       f"two-MFMA fp16 arithmetic ({model.mixed_units} of the 8 plain 512->512 units) and in split-bf16 together" if mixed else
                        _PMC.get("kernel_short") or ("split-bf16 implicit-GEMM convolution, pipelined 256x128 kernel on v_mfma_f32_16x16x32_bf16" if bf
                                                       else "conv_mfma_kernel<128,128>")) +
                       (" (512->512 3x3 conv @16x129 as implicit GEMM)" if tuple(dom) == (132096, 512, 4608)
@@ -402,7 +405,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
         elif _PMC.get("mfma_busy_frac") is not None:  # from the same committed PMC pass (kernel alone), not measured live
             roofline["mfma_busy_frac_pmc"] = round(_PMC["mfma_busy_frac"], 4)
             roofline["kernel_alone_ms_rocprof"] = round(_PMC.get("kernel_trace_avg_ms", 0.0), 4)
-        if bf:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi), or two fp16 ones (x*lo + x*hi)
+        if bf and not mixed:  # every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi), or two fp16 ones (x*lo + x*hi)
             per = 2 if f16 else 3
             roofline["mfma_issued_tflops"] = round(per * achieved, 2)
             roofline["mfma_issued_frac"] = round(per * achieved / peak, 4)
@@ -431,7 +434,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "value": round(world * B * steps / e2, 2), "unit": "formulas/s", "ms_per_step": round(e2 / steps * 1e3, 3),
             "what": f"as `value`, plus per step the H2D copy of the batch ({host_img.numel() * 4 / 1e6:.1f} MB from pinned host "
                     "memory, on a copy stream) and, before the region ends, the D2H copy of every batch's token ids"}
-        if precision in ("bf16x3", "fp16x2"):
+        if precision in ("bf16x3", "fp16x2", "mixed"):
             k3 = max(4, steps // 4)
             model.conv_precision = "fp32"
             e3, r3, _ = timed(k3, 2)
@@ -443,7 +446,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
                     "what": "same workload and serving configuration with exact fp32 arithmetic on the fp32-input MFMA "
                             "(v_mfma_f32_32x32x2_f32) everywhere",
                     "roofline": roofline_of(r3, "fp32", k3)}
-            other = "bf16x3" if precision == "fp16x2" else ("fp16x2" if name in ("C2", "C4") else None)
+            other = "bf16x3" if precision in ("fp16x2", "mixed") else ("fp16x2" if name in ("C2", "C4") else None)
             if other:  # the other 16-bit arithmetic beside the headline's, with its own roofline and its own parity
                 model.conv_precision = other
                 e4, r4, o4 = timed(steps, 2)
@@ -476,7 +479,8 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "value": round(formulas / elapsed, 2), "unit": "formulas/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3" if bf else ("fp16x2" if precision == "fp16x2" else "f32"), "data": "synthetic",
+            "dtype": "bf16x3" if bf else ("fp16x2" if precision == "fp16x2" else
+                                          f"bf16x3+fp16x2({model.mixed_units}u)" if precision == "mixed" else "f32"), "data": "synthetic",
             "config": {"workload": f"{name}: HybridViT(ResNet-512, patch 2x2, depth 6) + TFM-6 greedy, "
                                    f"{H}x{W} crops, {L + 1} decode steps (no early exit)" if name == "C2" else name,
                        "per_gpu_batch": B, "global_batch": B * world, "vocab": synth.VOCAB, "memory_tokens": T,
@@ -565,16 +569,16 @@ def main():
     ap.add_argument("--config", default="C2", help="C2 (headline) or C1")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "fp16x2"],
+    ap.add_argument("--mixed-units", type=int, default=None,
+                    help="--precision mixed: how many of the backbone's eight plain 512->512 units run the two-MFMA fp16 arithmetic")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "fp16x2", "mixed"],
                     help="convolution arithmetic: exact fp32 MFMA, split-bf16 (3 bf16 MFMAs per product), or fp16 feature maps x fp16 "
                          "hi / lo weights in the backbone (2 MFMAs per product; opt-in, DESIGN.md section 3).  Default: the Model's "
                          "own default (bf16x3); the other 16-bit arithmetic runs beside it under `secondary`")
     ap.add_argument("--reserve", type=int, default=0,
                     help="pipelined mode: block slots the persistent convolution leaves free for the decode stream")
-    ap.add_argument("--conv-kernel", default=None, choices=["pipelined", "classic", "patch", "pipelined16", "patch16", "band16", "wide16"],
+    ap.add_argument("--conv-kernel", default=None, choices=["classic", "pipelined16"],
                     help="split-bf16 convolution kernel: 256x128 tile with loader waves, one block per CU / 128x128, two per CU")
-    ap.add_argument("--winograd", type=int, default=None,
-                    help="Winograd F(2x2,3x3) for the 3x3 layers with at least this many channels (0 = off)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="pipelined mode: compute units the pipelined convolution kernel's grid leaves to the decode streams")
     ap.add_argument("--chains", type=int, default=3, choices=[1, 2, 3, 4],

@@ -9,13 +9,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libd2t.so")
+if os.environ.get("D2T_PROBE_LIB"):  # development tools only: a probe build of the library (csrc/build.sh with D2T_PROBES=1)
+    LIB_PATH = os.path.abspath(os.environ["D2T_PROBE_LIB"])
 
 D2T_OK = 0
 ENC_RESNET, ENC_HYBRID_VIT, ENC_VGG_BILSTM, ENC_RESNET_BILSTM = 0, 1, 2, 3
 DEC_TFM, DEC_ATTN = 0, 1
 ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-CONV_FP32, CONV_BF16X3, CONV_FP16X2 = 0, 1, 2
+CONV_FP32, CONV_BF16X3, CONV_FP16X2, CONV_MIXED = 0, 1, 2, 3
 ATTN_CELL_LOCATION, ATTN_CELL_BAHDANAU = 0, 1
 
 
@@ -71,10 +73,11 @@ SIGNATURES = {
     "d2t_decode_attn_beam_batch": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_decode_attn_beam": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_float), _P]),
     "d2t_set_conv_precision": (_I, [_P, _I]),
+    "d2t_set_mixed_units": (_I, [_P, _I]),
     "d2t_set_reserved_blocks": (_I, [_P, _I]),
     "d2t_set_decode_chains": (_I, [_P, _I]),
     "d2t_set_conv_kernel": (_I, [_P, _I]),
-    "d2t_set_conv_winograd": (_I, [_P, _I]),
+    "d2t_set_conv_fusion": (_I, [_P, _I, _I]),
     "d2t_set_beam_shared_tile": (_I, [_P, _I]),
     "d2t_set_reserved_cus": (_I, [_P, _I]),
     "d2t_train_forward": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),

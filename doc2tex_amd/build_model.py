@@ -157,14 +157,14 @@ class Model(nn.Module):
         # pipelined mode: block slots the persistent convolution leaves free for the decode stream
         self.reserved_blocks = 64
         # split-bf16 convolution kernel: 'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs;
-        # default), 'pipelined' (the same on 32x32x16 MFMAs), 'patch', or 'classic' (128x128, two blocks per CU);
+        # default) or 'classic' (128x128 on 32x32x16 MFMAs, two blocks per CU)
+        self.conv_kernel = "pipelined16"
         # pipelined serving: compute units the pipelined kernel's grid leaves to the decode streams
-        self.conv_kernel = os.environ.get("D2T_CONV_KERNEL_NAME", "pipelined16")
         self.reserved_cus = 0
+        # validation switches (tests): the 2x2 max-pools / 1x1 shortcuts inside the neighbouring convolution's launch (default)
+        self.conv_fusion = (True, True)
         # beam search (TFM, d_model 256, beam <= 6): one cross-attention block per sample for all its hypotheses (default: per row)
         self.beam_shared_tile = False
-        # Winograd F(2x2,3x3) for the 3x3 backbone layers with at least this many channels on both sides (0 = direct only)
-        self.conv_winograd = int(os.environ.get("D2T_CONV_WINOGRAD", "0"))
         # pipelined mode: decode loops in flight side by side (1 .. 4)
         self.decode_chains = 1
         # pipelined mode: decode the rows of this many consecutive forward() calls in ONE step loop.  The decode step is a
@@ -182,13 +182,17 @@ class Model(nn.Module):
         #             (C2: ~2e-4, C4: ~1.5e-4), but the margin is 5x, not 20x: the tiny test stack T2 reaches 5e-4 .. 1.05e-3 on
         #             fresh seeds, a near-tie between two tokens flips ~5x as often, and Feat=ResNet + Seq=None stacks (their
         #             decoder reads the backbone's output directly) move by up to 9e-3.  Needs conv_kernel = 'pipelined16';
+        #   'mixed'   (round 4, opt-in) 'bf16x3' with the two-MFMA arithmetic in the first `mixed_units` of the backbone's eight
+        #             plain 512 -> 512 units only (layer3.1 .. layer3.4, conv3, layer4.0 .. layer4.2: the K = 4608 layers); the error
+        #             grows with the square root of the number of such layers;
         #   'fp32'    exact fp32 matrix-core arithmetic.
-        # D2T_CONV_PRECISION=auto|bf16x3|fp16x2|fp32 overrides the default; 'auto' is 'bf16x3'.
+        # D2T_CONV_PRECISION=auto|bf16x3|fp16x2|mixed|fp32 overrides the default; 'auto' is 'bf16x3'.
         prec = os.environ.get("D2T_CONV_PRECISION", "auto")
         self._precision_auto = prec == "auto"
         if prec == "auto":
             prec = "bf16x3"
         self._conv_precision = prec
+        self.mixed_units = 4  # conv_precision 'mixed': units on the two-MFMA arithmetic (0 .. 8)
         # data-parallel training: a doc2tex_amd.dist.GradSync makes loss.backward() return all-reduced (mean) gradients
         self.grad_sync = None
 
@@ -275,7 +279,7 @@ class Model(nn.Module):
             self._engine.set_reserved_cus(want_cus)
             self._engine._reserved_cus = want_cus
         prec = self.effective_conv_precision()
-        if prec != "fp16x2" and getattr(self._engine, "_precision", None) != prec:  # (before a change of the kernel)
+        if prec not in ("fp16x2", "mixed") and getattr(self._engine, "_precision", None) != prec:  # (before a change of the kernel)
             self._engine.set_conv_precision(prec)
             self._engine._precision = prec
         if getattr(self._engine, "_conv_kernel", None) != self.conv_kernel:
@@ -284,15 +288,19 @@ class Model(nn.Module):
         if getattr(self._engine, "_beam_shared", None) != bool(self.beam_shared_tile):
             self._engine.set_beam_shared_tile(self.beam_shared_tile)
             self._engine._beam_shared = bool(self.beam_shared_tile)
-        if getattr(self._engine, "_winograd", None) != self.conv_winograd:
-            self._engine.set_conv_winograd(self.conv_winograd)
-            self._engine._winograd = self.conv_winograd
+        if getattr(self._engine, "_fusion", None) != tuple(self.conv_fusion):
+            self._engine.set_conv_fusion(*self.conv_fusion)
+            self._engine._fusion = tuple(self.conv_fusion)
         if getattr(self._engine, "_chains", None) != self.decode_chains:
             self._engine.set_decode_chains(self.decode_chains)
             self._engine._chains = self.decode_chains
-        if prec == "fp16x2" and getattr(self._engine, "_precision", None) != prec:  # (after the kernel choice: needs pipelined16)
+        if prec in ("fp16x2", "mixed") and getattr(self._engine, "_precision", None) != prec:  # (after the kernel choice: needs pipelined16)
             self._engine.set_conv_precision(prec)
             self._engine._precision = prec
+            self._engine._mixed_units = None
+        if prec == "mixed" and getattr(self._engine, "_mixed_units", None) != int(self.mixed_units):
+            self._engine.set_mixed_units(int(self.mixed_units))
+            self._engine._mixed_units = int(self.mixed_units)
         return self._engine
 
     @property
@@ -301,14 +309,14 @@ class Model(nn.Module):
 
     @conv_precision.setter
     def conv_precision(self, mode):
-        if mode not in ("fp32", "bf16x3", "fp16x2"):
-            raise ValueError(f"conv_precision must be 'fp32', 'bf16x3' or 'fp16x2', not {mode!r}")
+        if mode not in ("fp32", "bf16x3", "fp16x2", "mixed"):
+            raise ValueError(f"conv_precision must be 'fp32', 'bf16x3', 'fp16x2' or 'mixed', not {mode!r}")
         self._conv_precision = mode
         self._precision_auto = False
 
     def effective_conv_precision(self):
         """The arithmetic the next forward runs in (an 'auto' fp16x2 steps back to bf16x3 for other convolution kernels)."""
-        if self._precision_auto and self._conv_precision == "fp16x2" and (self.conv_kernel != "pipelined16" or self.conv_winograd):
+        if self._precision_auto and self._conv_precision in ("fp16x2", "mixed") and self.conv_kernel != "pipelined16":
             return "bf16x3"
         return self._conv_precision
 

@@ -501,7 +501,7 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
       else hipLaunchKernelGGL(conv_bf16x3g_128x64, dim3(grid3), dim3(256), 0, s, p);
     } else {
       // 8 waves per tile (4 per SIMD at two blocks per CU) measured 1-2 % faster end to end than 4 waves
-      static const bool w4 = getenv("D2T_BF16X3_WAVES") && atoi(getenv("D2T_BF16X3_WAVES")) == 4;
+      static const bool w4 = D2T_PROBE_ENV("D2T_BF16X3_WAVES") == 4;
       if (p.f16) hipLaunchKernelGGL(conv_f16x2g_128x128_w8, dim3(grid), dim3(512), 0, s, p);
       else if (w4) hipLaunchKernelGGL(conv_bf16x3g_128x128, dim3(grid), dim3(256), 0, s, p);
       else if (p.K == 4608 && p.Cout == 512) hipLaunchKernelGGL(conv_bf16x3g_128x128_w8_k4608, dim3(grid), dim3(512), 0, s, p);
@@ -509,7 +509,7 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
     }
     return hipGetLastError();
   }
-  static const int variant = getenv("D2T_BF16X3_WAVES") ? atoi(getenv("D2T_BF16X3_WAVES")) : 4;
+  static const int variant = D2T_PROBE_ENV_STR("D2T_BF16X3_WAVES") ? D2T_PROBE_ENV("D2T_BF16X3_WAVES") : 4;
   if (p.Cout <= 64) {
     hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2, true>), dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
   } else if (variant == 4) {

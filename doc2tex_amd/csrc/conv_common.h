@@ -23,25 +23,40 @@ __device__ __forceinline__ void split_f32(float x, uint16_t& hi, uint16_t& lo) {
 
 // fp16x2 mode (ConvP::f16, round 3): a record holds the activation ONCE, as fp16, in its hi half (the lo half is unused);
 // the convolution is x16 * w_lo + x16 * w_hi with the weights as fp16 hi + fp16 lo -- two MFMAs per product instead of three.
-// Values beyond the fp16 range saturate (a feature map of a trained model stays far below 65504).
+// FINITE values beyond the fp16 range saturate (a feature map of a trained model stays far below 65504); NaN and +-Inf pass
+// through the conversion unchanged, so a numerically broken forward stays visible in the logits as it does in the other modes
+// (fmaxf / fminf alone would turn a NaN into -65504 and the next ReLU into 0).
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float x) {
-  const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);  // v_cvt_f16_f32: round to nearest even
+  const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+  const _Float16 h = (_Float16)(fabsf(x) <= 3.402823466e38f ? c : x);  // v_cvt_f16_f32: round to nearest even; NaN -> NaN, Inf -> Inf
   return *reinterpret_cast<const uint16_t*>(&h);
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)*reinterpret_cast<const _Float16*>(&b); }
-// one element of a record: (hi, lo) <-> fp32 in either mode
-__device__ __forceinline__ void split_rec(float x, uint16_t& hi, uint16_t& lo, int f16) {
-  if (f16) { hi = f32_to_f16_bits(x); lo = 0; }
-  else split_f32(x, hi, lo);
+// record formats: 0 = bf16 hi | lo (x ~ hi + lo), 1 = ONE fp16 in the hi half (lo half unused), 2 = fp16 hi | fp16 lo (x ~ hi + lo)
+enum : int { REC_BF16 = 0, REC_F16 = 1, REC_F16_PAIR = 2 };
+__device__ __forceinline__ int out_fmt(const ConvP& p) { return p.out_fmt ? p.out_fmt - 1 : p.f16; }
+__device__ __forceinline__ int res_fmt(const ConvP& p) { return p.res_fmt ? p.res_fmt - 1 : p.f16; }
+// one element of a record: (hi, lo) <-> fp32
+__device__ __forceinline__ void split_rec(float x, uint16_t& hi, uint16_t& lo, int fmt) {
+  if (fmt == REC_BF16) { split_f32(x, hi, lo); return; }
+  hi = f32_to_f16_bits(x);
+  lo = fmt == REC_F16_PAIR ? f32_to_f16_bits(x - f16_bits_to_f32(hi)) : (uint16_t)0;  // (x - hi is exact in fp32)
 }
-__device__ __forceinline__ float join_rec(uint16_t hi, uint16_t lo, int f16) {
-  return f16 ? f16_bits_to_f32(hi) : bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo);
+__device__ __forceinline__ float join_rec(uint16_t hi, uint16_t lo, int fmt) {
+  if (fmt == REC_BF16) return bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo);
+  return fmt == REC_F16_PAIR ? f16_bits_to_f32(hi) + f16_bits_to_f32(lo) : f16_bits_to_f32(hi);
 }
 // four consecutive elements: rh / rl = the 8-byte hi / lo words of the record
-__device__ __forceinline__ void add_rec4(float (&v)[4], const uint2 rh, const uint2 rl, int f16) {
-  if (f16) {
-    v[0] += f16_bits_to_f32((uint16_t)(rh.x & 0xFFFFu)); v[1] += f16_bits_to_f32((uint16_t)(rh.x >> 16));
-    v[2] += f16_bits_to_f32((uint16_t)(rh.y & 0xFFFFu)); v[3] += f16_bits_to_f32((uint16_t)(rh.y >> 16));
+__device__ __forceinline__ void add_rec4(float (&v)[4], const uint2 rh, const uint2 rl, int fmt) {
+  if (fmt != REC_BF16) {
+    const unsigned h[2] = {rh.x, rh.y}, l[2] = {rl.x, rl.y};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float a = f16_bits_to_f32((uint16_t)(h[e] & 0xFFFFu)), b = f16_bits_to_f32((uint16_t)(h[e] >> 16));
+      if (fmt == REC_F16_PAIR) { a += f16_bits_to_f32((uint16_t)(l[e] & 0xFFFFu)); b += f16_bits_to_f32((uint16_t)(l[e] >> 16)); }
+      v[2 * e] += a;
+      v[2 * e + 1] += b;
+    }
   } else {
     v[0] += __uint_as_float(rh.x << 16) + __uint_as_float(rl.x << 16);
     v[1] += __uint_as_float(rh.x & 0xFFFF0000u) + __uint_as_float(rl.x & 0xFFFF0000u);
@@ -122,13 +137,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][
         if (p.res) v += p.res[off];
         if (p.res_hi) {
           const size_t ri = plane_idx(row, n, p.Cout);
-          v += join_rec(p.res_hi[ri], p.res_hi[ri + 32], p.f16);
+          v += join_rec(p.res_hi[ri], p.res_hi[ri + 32], res_fmt(p));
         }
         v = apply_act(v, p.act);
         if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
         if (p.out_hi) {
           uint16_t hi, lo;
-          split_rec(v, hi, lo, p.f16);
+          split_rec(v, hi, lo, out_fmt(p));
           const size_t oi = plane_idx(row, n, p.Cout);
           p.out_hi[oi] = hi;
           p.out_hi[oi + 32] = lo;
@@ -188,14 +203,14 @@ __device__ __forceinline__ void conv_epilogue_wide(const ConvP& p, f32x16 (&acc)
     }
     if (p.res_hi) {
       const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
-      add_rec4(v, rh, rl, p.f16);
+      add_rec4(v, rh, rl, res_fmt(p));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], out_fmt(p));
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
@@ -249,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue_wide_pool(const ConvP& p, f32x16 (
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], out_fmt(p));
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);
@@ -322,7 +337,7 @@ __device__ __forceinline__ void conv_epilogue_wide_full(const ConvP& p, f32x16 (
     }
     if (p.res_hi) {
       const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + pi), rl = *reinterpret_cast<const uint2*>(p.res_hi + pi + 32);
-      add_rec4(v, rh, rl, p.f16);
+      add_rec4(v, rh, rl, res_fmt(p));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
@@ -333,7 +348,7 @@ __device__ __forceinline__ void conv_epilogue_wide_full(const ConvP& p, f32x16 (
     if (p.out_hi) {
       uint16_t hi[4], lo[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], p.f16);
+      for (int e = 0; e < 4; ++e) split_rec(v[e], hi[e], lo[e], out_fmt(p));
       uint2 oh, ol;
       oh.x = (unsigned)hi[0] | ((unsigned)hi[1] << 16), oh.y = (unsigned)hi[2] | ((unsigned)hi[3] << 16);
       ol.x = (unsigned)lo[0] | ((unsigned)lo[1] << 16), ol.y = (unsigned)lo[2] | ((unsigned)lo[3] << 16);

@@ -89,6 +89,7 @@ struct Act {
   float* p;
   int B, H, W, C;
   bool split = false;  // two bf16 planes (hi | lo) in the same buffer instead of fp32
+  int fmt = 0;         // split records: 0 = bf16 hi | lo, 1 = one fp16 in the hi half, 2 = fp16 hi | fp16 lo (conv_common.h REC_*)
   size_t numel() const { return (size_t)B * H * W * C; }
   uint16_t* planes() const { return reinterpret_cast<uint16_t*>(p); }
 };
@@ -106,10 +107,15 @@ struct d2t_ctx {
   // D2T_CONV_FP16X2 (on top of conv_bf16x3): the backbone's feature maps are fp16 records and its split-record convolutions run
   // x16 * w_lo + x16 * w_hi (two MFMAs per product); everything that takes fp32 input stays on the bf16x3 kernels
   bool conv_f16 = false;
+  // D2T_CONV_MIXED (round 4; on top of conv_bf16x3, not with conv_f16): the two-MFMA fp16 arithmetic for the first
+  // `mixed_units` of the backbone's plain 512 -> 512 units [layer3.1, layer3.2, layer3.3, layer3.4, conv3, layer4.0, layer4.1,
+  // layer4.2] only (the K = 4608 layers: 64 % of the step); every other layer stays split-bf16.  The tensors entering and
+  // leaving those units travel as fp16 hi | lo pairs (22 bits), so only the MFMA operand is rounded to 11 bits.
+  int mixed_units = 0;
   int stream_prio = 0;  // priority the decode streams were acquired with (they return to the process-wide pool: engine.hip)
   int conv_max_blocks = 0;   // d2t_set_reserved_blocks: grid cap of the persistent split-bf16 convolution (0 = none)
   int num_cus = 0;
-  int conv_pipelined = 3;    // d2t_set_conv_kernel: 3 = pipelined 256x128 split-bf16 kernel on 16x16x32 MFMAs (default), 1 = the same on 32x32x16, 2 = 1 + patch-resident 3x3, 0 = 128x128 (two per CU)
+  int conv_pipelined = 3;    // d2t_set_conv_kernel: 3 = pipelined 256x128 split-bf16 kernel on 16x16x32 MFMAs (default), 0 = 128x128 on 32x32x16 (two per CU)
   int reserved_cus = 0;      // d2t_set_reserved_cus: CUs the pipelined kernel's grid leaves to other streams (decode)
   int device = 0;            // HIP device the context was created on: every stream, event and buffer lives there
 
@@ -147,11 +153,6 @@ struct d2t_ctx {
   // d_model 256 / 8 heads: the decode attends over the encoder memory itself (absorbed K / V projections); the slots then
   // hold a COPY OF THE MEMORY [B][T][d] instead of the projected K / V of every layer [layers*2][B][heads][T][hd]
   bool dec_absorbed = false;
-  // Winograd F(2x2,3x3) for the 3x3 / stride 1 / pad 1 split-record layers with Cin, Cout >= wino_min_channels
-  // (d2t_set_conv_winograd; 0 = off): workspace for the transformed input tiles
-  int wino_min_channels = 0;
-  float* wino_ws = nullptr; size_t wino_ws_cap = 0;
-  std::map<const float*, std::pair<uint16_t*, uint16_t*>> wino_u;  // Winograd-domain weights [16][Cout][Cin] per layer, made on first use
   hipEvent_t ev_done[MAXC] = {};                                     // decode that used slot i has finished
   bool ev_done_valid[MAXC] = {};
   unsigned decode_seq = 0;
@@ -169,8 +170,8 @@ struct d2t_ctx {
   // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
   // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
   int beam_shared_tile = 0;
-  int no_shortcut_fusion = 0;  // debug / A-B: 1 = the 1x1 shortcuts as their own kernels (D2T_NO_SHORTCUT_FUSION at context creation)
-  int no_pool_fusion = 0;  // debug / A-B: 1 = the two 2x2 max-pools as their own kernels (D2T_NO_POOL_FUSION at context creation)
+  int no_shortcut_fusion = 0;  // debug / A-B: 1 = the 1x1 shortcuts as their own kernels (d2t_set_conv_fusion)
+  int no_pool_fusion = 0;  // debug / A-B: 1 = the two 2x2 max-pools as their own kernels (d2t_set_conv_fusion)
   float* beam_qp = nullptr; size_t beam_qp_cap = 0;  // beam, absorbed cross-attention: q' / context rows + LN1 rows (decode.hip)
   float* dws = nullptr; size_t dws_cap = 0;
   int* dstate = nullptr;   // [0]=step [1]=end_count [2]=steps_done [3..]=ended[B]

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void skinny_generic_kernel(const SkinnyP p) {
 // small = 1: the 256-thread forms of the decode kernels (one wave per SIMD, <= 128 VGPRs), which fit on a CU beside the
 // pipelined convolution kernel's three 128-register waves per SIMD; identical arithmetic per row, so identical results
 static int decode_small() {
-  static const int v = getenv("D2T_DECODE_SMALL") ? atoi(getenv("D2T_DECODE_SMALL")) : 0;
+  static const int v = D2T_PROBE_ENV("D2T_DECODE_SMALL");
   return v;
 }
 
@@ -1137,16 +1137,447 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_kernel(const Dec
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the two-row kernel with its memory latencies hidden.  rocprofv3 PMC of the kernel above at 384 rows
+// (profiles/r04_pmc_decode.txt): matrix pipes 12 % busy, L2 -> fabric 104 MB per launch = 1.7 TB/s, SQ_WAIT_ANY 49 % of the wave
+// cycles -- neither arithmetic nor bandwidth, but a serial chain of phases that each begin with an exposed round trip (a
+// K / V group of the cache, a GEMV's weight rows from L2, a memory tile of the cross-attention).  Same arithmetic per element
+// in the same order (results bit-identical to decoder_row2_absorbed_kernel), different issue order:
+//   * a wave's FIRST memory tile is on its way (LDS-DMA) from the kernel's first instruction -- the staging area is idle until
+//     the cross-attention (the GEMV partials of the first two projections live in the absorbed queries' LDS instead);
+//   * inside the cross-attention the NEXT tile travels to registers (16 x 16 bytes per lane) while the matrix cores work on the
+//     current one, and moves to LDS when its reads are done: a tile costs max(arithmetic, round trip), not their sum;
+//   * a GEMV's weight rows (32 x 16 bytes per thread) are requested one phase early: W_o before the self-attention, W_q behind
+//     the W_o products, W_k behind the W_q products, W_v behind the cross-attention loop, W_co behind the W_v products;
+//   * the self-attention runs a wave's two heads in ONE loop (twice the K / V groups in flight per round trip);
+//   * block barriers are raw s_barrier behind lgkmcnt(0) (LDS only): a __syncthreads() fence would drain the prefetches.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef D2T_PROBES
+// probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
+__device__ unsigned long long d2t_row_phase[32];
+#define ROW_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_row_phase[k], now_ - phase_t_); phase_t_ = now_; } } while (0)
+#define ROW_PHASE_INIT() unsigned long long phase_t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_row_phase[31], 1ull)
+#else
+#define ROW_PHASE(k) do { } while (0)
+#define ROW_PHASE_INIT() do { } while (0)
+#endif
+#define ROW_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// weight rows of one two-row GEMV: thread (lr = tid % 64, g = tid / 64) holds Wt[32 g + k][4 lr .. 4 lr + 3], k = 0 .. 31
+__device__ __forceinline__ void gemv2_load(const float* __restrict__ Wt, int g, int lr, float4 (&w)[32]) {
+  const float* src = Wt + (size_t)(g * 32) * 256 + lr * 4;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) w[k] = *reinterpret_cast<const float4*>(src + (size_t)k * 256);
+}
+// part_s[row][g][n] += ... exactly row2_gemv<256>'s products in its order; in0 / in1 = the two rows' inputs at k = 32 g
+__device__ __forceinline__ void gemv2_fma(const float4 (&w)[32], const float* in0, const float* in1, float4& a0, float4& a1) {
+  a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  a1 = a0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const float4 w4 = w[k];
+    const float x0 = in0[k], x1 = in1[k];
+    a0.x = fmaf(x0, w4.x, a0.x); a0.y = fmaf(x0, w4.y, a0.y); a0.z = fmaf(x0, w4.z, a0.z); a0.w = fmaf(x0, w4.w, a0.w);
+    a1.x = fmaf(x1, w4.x, a1.x); a1.y = fmaf(x1, w4.y, a1.y); a1.z = fmaf(x1, w4.z, a1.z); a1.w = fmaf(x1, w4.w, a1.w);
+  }
+}
+
+// row_attention<32, U> for TWO heads of one row in one loop (per head the same keys per lane in the same order)
+template <int U>
+__device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], const float* const (&Kc)[2], const float* const (&Vc)[2],
+                                                 const float* const (&curk)[2], const float* const (&curv)[2], int t, int L,
+                                                 float* const (&out)[2], int lane) {
+  constexpr int HD = 32, LPK = HD / 4, KPI = 64 / LPK;
+  const int kig = lane / LPK, ch = lane % LPK;
+  float4 q4[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) q4[h] = *reinterpret_cast<const float4*>(q[h] + ch * 4);
+  const float scale = 0.17677669529663687f;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  const int nit = (L + KPI - 1) / KPI;
+  for (int it0 = 0; it0 < nit; it0 += U) {
+    float4 k4[2][U], v4[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (it0 + u) * KPI + kig;
+      const int jj = j < L ? j : 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* kr = jj == t ? curk[h] : Kc[h] + (size_t)jj * HD;
+        const float* vr = jj == t ? curv[h] : Vc[h] + (size_t)jj * HD;
+        k4[h][u] = *reinterpret_cast<const float4*>(kr + ch * 4);
+        v4[h][u] = *reinterpret_cast<const float4*>(vr + ch * 4);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = (it0 + u) * KPI + kig;
+        float d = (q4[h].x * k4[h][u].x + q4[h].y * k4[h][u].y) + (q4[h].z * k4[h][u].z + q4[h].w * k4[h][u].w);
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+        if (j < L) {
+          const float sj = d * scale;
+          const float mn = fmaxf(m[h], sj);
+          const float f = expf(m[h] - mn);
+          const float pj = expf(sj - mn);
+          l[h] = l[h] * f + pj;
+          acc[h].x = acc[h].x * f + pj * v4[h][u].x; acc[h].y = acc[h].y * f + pj * v4[h][u].y;
+          acc[h].z = acc[h].z * f + pj * v4[h][u].z; acc[h].w = acc[h].w * f + pj * v4[h][u].w;
+          m[h] = mn;
+        }
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+      const float mo = __shfl_xor(m[h], o, 64), lo = __shfl_xor(l[h], o, 64);
+      const float ax = __shfl_xor(acc[h].x, o, 64), ay = __shfl_xor(acc[h].y, o, 64);
+      const float az = __shfl_xor(acc[h].z, o, 64), aw = __shfl_xor(acc[h].w, o, 64);
+      const float mn = fmaxf(m[h], mo);
+      const float f1 = l[h] > 0.f ? expf(m[h] - mn) : 0.f, f2 = lo > 0.f ? expf(mo - mn) : 0.f;
+      l[h] = l[h] * f1 + lo * f2;
+      acc[h].x = acc[h].x * f1 + ax * f2; acc[h].y = acc[h].y * f1 + ay * f2;
+      acc[h].z = acc[h].z * f1 + az * f2; acc[h].w = acc[h].w * f1 + aw * f2;
+      m[h] = mn;
+    }
+    if (kig == 0) {
+      const float inv = 1.f / l[h];
+      *reinterpret_cast<float4*>(out[h] + ch * 4) = make_float4(acc[h].x * inv, acc[h].y * inv, acc[h].z * inv, acc[h].w * inv);
+    }
+  }
+}
+
+// LDS-DMA of key tile `tile` of `mem` into a wave's 16 KB stage (the layout cross_absorbed_wave reads)
+__device__ __forceinline__ void cross_tile_dma(const float* __restrict__ mem, int T, int tile, unsigned char* stage, int lane) {
+  const int j0 = tile << 4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = j0 + i < T ? j0 + i : T - 1;
+    __builtin_amdgcn_global_load_lds(mem + (size_t)j * 256 + ((lane ^ i) << 2), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
+  }
+}
+
+// cross_absorbed_wave<NW> with the tile stream pipelined: the wave's first tile was started with cross_tile_dma long before;
+// every following tile is loaded to registers during the arithmetic on the current one.  Same products, same order.
+template <int NW>
+__device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__ mem, int T, const float* qp_s, unsigned char* stage,
+                                                       int wave, int lane, float& m_run, float& l_run, f32x4 (&acc)[4][4]) {
+  const int col = lane & 15, g = lane >> 4;
+  const int hrow = col & 7;
+  m_run = -INFINITY;
+  l_run = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[w][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 15) >> 4;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile (issued at kernel entry) has landed
+  for (int tile = wave; tile < ntiles; tile += NW) {
+    const int j0 = tile << 4;
+    const int nxt = tile + NW;
+    f32x4 pf[16];
+    if (nxt < ntiles) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = (nxt << 4) + i < T ? (nxt << 4) + i : T - 1;
+        pf[i] = *reinterpret_cast<const f32x4*>(mem + (size_t)j * 256 + ((lane ^ i) << 2));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float4 a4 = *reinterpret_cast<const float4*>(stage + col * 1024 + (((4 * u + g) ^ col) << 4));
+      const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(qp_s) + hrow * 1024 + (((4 * u + g) ^ hrow) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, q4.x, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, q4.y, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, q4.z, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, q4.w, sacc, 0, 0, 0);
+    }
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
+      mx = fmaxf(mx, sv[reg]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float pv[4], ps = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      pv[reg] = expf(sv[reg] - m_new);
+      ps += pv[reg];
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    float ar[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ar[reg] = __shfl(alpha, 4 * g + reg, 64);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[w][e][reg] *= ar[reg];
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {
+      const int key = 4 * g + sk;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 b4 = *reinterpret_cast<const float4*>(stage + key * 1024 + (((16 * w + col) ^ key) << 4));
+        acc[w][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.x, acc[w][0], 0, 0, 0);
+        acc[w][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.y, acc[w][1], 0, 0, 0);
+        acc[w][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.z, acc[w][2], 0, 0, 0);
+        acc[w][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.w, acc[w][3], 0, 0, 0);
+      }
+    }
+    if (nxt < ntiles) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads have returned: the stage may be overwritten
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(stage + i * 1024 + lane * 16) = pf[i];
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+}
+
+__global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const DecRow2P q) {
+  constexpr int D = 256, HD = 32, G = 8;
+  const DecRowP& p = q.r;
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
+  ROW_PHASE_INIT();
+  __shared__ __attribute__((aligned(1024))) unsigned char stage_s[8 * 16384];
+  __shared__ __attribute__((aligned(1024))) float qp_s[2][8 * D];
+  __shared__ __attribute__((aligned(16))) float a_s[2][D], y_s[2][D], x1_s[2][D], q2_s[2][D];
+  __shared__ float wm_s[2][4][8], wl_s[2][4][8];
+  float* const part_late = reinterpret_cast<float*>(stage_s);   // [2][G][D]: the GEMVs behind the cross-attention (stages idle again)
+  float* const part_early = &qp_s[0][0];                        // [2][G][D]: the GEMVs in front of it (the first tiles are landing in the stages)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform values in SGPRs)
+  const int half = wave >> 2, w4i = wave & 3;
+  const bool valid = 2 * (int)blockIdx.x + half < p.M;
+  const int b = valid ? 2 * blockIdx.x + half : p.M - 1;
+  const int trow = wave >> 2, tcol = tid & 255;
+  const bool tvalid = valid;
+  const int brow = b;
+  const int t = *p.step_ptr;
+  const int lr = lane, gg = wave;  // GEMV thread coordinates: columns 4 lr .. 4 lr + 3, K group gg
+  // ---- this wave's first memory tile, and the first GEMV's weight rows, are requested before anything else ----
+  const int cb = p.c_row_map ? p.c_row_map[b] : b;
+  const float* const mem = q.mem + (size_t)cb * q.mem_stride;
+  unsigned char* const stage = stage_s + wave * 16384;
+  if (w4i < ((p.T + 15) >> 4)) cross_tile_dma(mem, p.T, w4i, stage, lane);
+  // the element-wise phases' few global operands, requested BEFORE the weight prefetches: the vector-memory counter retires in
+  // order, so a small load issued behind a 256 KB prefetch would wait for all of it
+  const float bo_v = p.bo[tcol] + p.xres[(size_t)brow * D + tcol], bq_v = p.bq[tcol], bv_v = q.bv[tcol], bco_v = p.bco[tcol];
+  float ln_g[4], ln_b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ln_g[i] = p.ln1_g[i * 64 + lane]; ln_b[i] = p.ln1_b[i * 64 + lane]; }
+  float4 W[32];
+  gemv2_load(p.wo_t, gg, lr, W);
+  // ---- self-attention over the cache, this wave's two heads in one loop ----
+  {
+    const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
+    const float *qh[2], *Kh[2], *Vh[2], *ck[2], *cv[2];
+    float* oh[2];
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+      const int head = w4i + hp * 4;
+      float* Kc = p.sk + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      float* Vc = p.sv + (size_t)b * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      ck[hp] = qkv + D + head * HD;
+      cv[hp] = qkv + 2 * D + head * HD;
+      if (lane < HD && valid) {
+        Kc[(size_t)t * HD + lane] = ck[hp][lane];
+        Vc[(size_t)t * HD + lane] = cv[hp][lane];
+      }
+      qh[hp] = qkv + head * HD; Kh[hp] = Kc; Vh[hp] = Vc; oh[hp] = a_s[half] + head * HD;
+    }
+    row_attention_2h<4>(qh, Kh, Vh, ck, cv, t, t + 1, oh, lane);
+  }
+  ROW_SYNC();
+  ROW_PHASE(0);
+  {
+    float4 a0, a1;
+    gemv2_fma(W, a_s[0] + gg * 32, a_s[1] + gg * 32, a0, a1);
+    gemv2_load(p.wq_t, gg, lr, W);  // next projection's rows: on their way during the reduction and LN1
+    *reinterpret_cast<float4*>(part_early + (0 * G + gg) * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_early + (1 * G + gg) * D + lr * 4) = a1;
+  }
+  ROW_SYNC();
+  ROW_PHASE(1);
+  {
+    float v = bo_v;
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_early[(trow * G + g) * D + tcol];
+    y_s[trow][tcol] = v;
+  }
+  ROW_SYNC();
+  ROW_PHASE(2);
+  if (w4i == 0) {  // LN1, two-pass, one wave per row
+    constexpr int V = D / 64;
+    float v[V], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = y_s[half][i * 64 + lane]; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] -= mean; qq += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float rstd = 1.f / sqrtf(qq * (1.f / D) + p.eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = i * 64 + lane;
+      x1_s[half][c] = v[i] * rstd * ln_g[i] + ln_b[i];
+    }
+  }
+  ROW_SYNC();
+  ROW_PHASE(3);
+  {
+    float4 a0, a1;
+    gemv2_fma(W, x1_s[0] + gg * 32, x1_s[1] + gg * 32, a0, a1);
+    gemv2_load(q.wk, gg, lr, W);  // W_k rows of head gg (= tid / 64), columns 4 lr ..: the absorbed-query product's operand
+    *reinterpret_cast<float4*>(part_early + (0 * G + gg) * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_early + (1 * G + gg) * D + lr * 4) = a1;
+  }
+  ROW_SYNC();
+  ROW_PHASE(4);
+  {
+    float v = bq_v;
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_early[(trow * G + g) * D + tcol];
+    q2_s[trow][tcol] = v;
+  }
+  ROW_SYNC();
+  ROW_PHASE(5);
+  // ---- absorbed queries of both rows: q'[h][c] = scale * sum_e q2[h*32 + e] * W_k[h*32 + e][c]; thread -> (head gg, 4 channels) ----
+  {
+    const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+    float4 a0, a1;
+    gemv2_fma(W, q2_s[0] + gg * HD, q2_s[1] + gg * HD, a0, a1);
+    const int o = gg * D + ((lr ^ gg) << 2);
+    *reinterpret_cast<float4*>(qp_s[0] + o) = make_float4(a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale);
+    *reinterpret_cast<float4*>(qp_s[1] + o) = make_float4(a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale);
+  }
+  ROW_SYNC();
+  ROW_PHASE(6);
+  // ---- cross-attention over the memory rows of each row's sample: four waves per row ----
+  {
+    float m_run, l_run;
+    f32x4 acc[4][4];
+    cross_absorbed_wave_pf<4>(mem, p.T, qp_s[half], stage, w4i, lane, m_run, l_run, acc);
+    ROW_PHASE(12);
+    const int col = lane & 15, g = lane >> 4;
+    if (g == 0 && col < 8) { wm_s[half][w4i][col] = m_run; wl_s[half][w4i][col] = l_run; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* mine = reinterpret_cast<float*>(stage);
+    if (g < 2) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
+              make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+    }
+  }
+  gemv2_load(q.wv_t, gg, lr, W);  // value projection's rows: on their way during the merge
+  ROW_SYNC();
+  ROW_PHASE(7);
+  for (int idx = tid; idx < 2 * 8 * (D / 4); idx += 512) {  // merge each row's four partial softmaxes (log-sum-exp combine)
+    const int row = idx / (8 * (D / 4)), rem = idx % (8 * (D / 4));
+    const int h = rem / (D / 4), c4 = (rem % (D / 4)) * 4;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, wm_s[row][w][h]);
+    float L = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = wl_s[row][w][h] > 0.f ? expf(wm_s[row][w][h] - M) : 0.f;
+      L += wl_s[row][w][h] * f;
+      const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(stage_s + (row * 4 + w) * 16384) + h * D + c4);
+      o.x += c.x * f; o.y += c.y * f; o.z += c.z * f; o.w += c.w * f;
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<float4*>(qp_s[row] + h * D + c4) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);  // ctx in the queries' place
+  }
+  ROW_SYNC();
+  ROW_PHASE(8);
+  // ---- a2[o] = b_v[o] + sum_c ctx[head(o)][c] * W_v^T[c][o], both rows ----
+  {
+    const int hoff = ((lr * 4) / HD) * D + gg * 32;
+    float4 a0, a1;
+    gemv2_fma(W, qp_s[0] + hoff, qp_s[1] + hoff, a0, a1);
+    gemv2_load(p.wco_t, gg, lr, W);
+    *reinterpret_cast<float4*>(part_late + (0 * G + gg) * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_late + (1 * G + gg) * D + lr * 4) = a1;
+  }
+  ROW_SYNC();
+  ROW_PHASE(9);
+  {
+    float v = bv_v;
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_late[(trow * G + g) * D + tcol];
+    a_s[trow][tcol] = v;
+  }
+  ROW_SYNC();
+  ROW_PHASE(10);
+  {
+    float4 a0, a1;
+    gemv2_fma(W, a_s[0] + gg * 32, a_s[1] + gg * 32, a0, a1);
+    ROW_SYNC();  // (every thread has read part_late's previous contents)
+    *reinterpret_cast<float4*>(part_late + (0 * G + gg) * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_late + (1 * G + gg) * D + lr * 4) = a1;
+  }
+  ROW_SYNC();
+  ROW_PHASE(11);
+  {
+    float v = bco_v + x1_s[trow][tcol];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_late[(trow * G + g) * D + tcol];
+    if (tvalid) p.y2[(size_t)brow * D + tcol] = v;
+  }
+  ROW_PHASE(20);
+}
+
+#ifdef D2T_PROBES
+}  // namespace d2t
+extern "C" int d2t_debug_row_phases(unsigned long long* out, int reset) {  // probe builds: read (and clear) d2t_row_phase
+  hipDeviceSynchronize();
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d2t::d2t_row_phase), 32 * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d2t::d2t_row_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace d2t {
+#endif
 hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
                                        const float* bv, hipStream_t s) {
   if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
   DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, nullptr, nullptr};
   static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
   q.r.probe = probe;
-  static const bool one_row = getenv("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
+  static const bool one_row = D2T_PROBE_ENV_STR("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
   if (r.anc && (!r.one_row || r.s_Lmax > ANC_MAX)) return hipErrorInvalidValue;  // the two-row kernel reads the cache directly
+  static const bool no_pf = getenv("D2T_DECODE_ROW2_NO_PREFETCH") != nullptr;  // A/B: the round-3 issue order
   if (one_row || r.one_row) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
-  else hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
+  else if (no_pf) hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
+  else hipLaunchKernelGGL(decoder_row2_absorbed_pf_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
   return hipGetLastError();
 }
 

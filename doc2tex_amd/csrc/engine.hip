@@ -81,7 +81,6 @@ int get_ln(d2t_ctx* c, const std::string& k, LNW* out, int D) {
 void free_packed(d2t_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   c->owned.clear();
-  c->wino_u.clear();
   for (int i = 0; i < 4; ++i) c->layers[i].clear();
   c->vit.clear();
   c->dec.clear();
@@ -114,7 +113,9 @@ hipError_t conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s) {
 // (only meaningful on the bf16x3 path; the consumer must be another bf16x3 convolution or the split pool).
 // pool2: fuse the 2x2 / stride 2 max-pool that follows (split-record path only: see ConvP::pool2); y is then the POOLED map.
 Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& w, int sh, int sw, int ph, int pw,
-         int act, const Act* res, float* outbuf, const ConvP* extra = nullptr, bool out_split = false, bool pool2 = false) {
+         int act, const Act* res, float* outbuf, const ConvP* extra = nullptr, bool out_split = false, bool pool2 = false,
+         int out_fmt = -1) {
+  // out_fmt: record format of a split output (conv_common.h REC_*); -1 = the input's (fp16x2 mode: one fp16; else bf16 hi | lo)
   Act y{outbuf, x.B, (x.H + 2 * ph - w.KH) / sh + 1, (x.W + 2 * pw - w.KW) / sw + 1, w.Cout};
   y.split = out_split;
   ConvP p{};
@@ -122,11 +123,17 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   p.w = w.w; p.bias = w.bias;
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
-  if (c->conv_f16 && x.split && w.w_h16) {  // fp16 records in (and out, and as the residual): the fp16x2 kernels
+  if (x.split && x.fmt != 0) {  // fp16 records in: the two-MFMA kernels (x16 * w_lo + x16 * w_hi), fp16 hi / lo weight planes
+    if (!w.w_h16) { if (*err == hipSuccess) *err = hipErrorInvalidValue; return y; }
     p.f16 = 1;
     p.w_hi = w.w_h16; p.w_lo = w.w_l16;
   }
-  p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
+  if (out_split) {
+    y.fmt = out_fmt >= 0 ? out_fmt : (x.split ? (x.fmt ? 1 : 0) : (c->conv_f16 ? 1 : 0));
+    p.out_fmt = 1 + y.fmt;
+  }
+  if (res && res->split) p.res_fmt = 1 + res->fmt;
+  p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight || D2T_PROBE_ENV("D2T_CONV_TAIL_ALWAYS");
   if (out_split) { p.out_hi = y.planes(); } else { p.out = outbuf; }
   if (res) {
     if (res->split) { p.res_hi = res->planes(); } else { p.res = res->p; }
@@ -140,33 +147,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
     y.H /= 2;
     y.W /= 2;
   }
-  hipError_t e;
-  if (c->conv_bf16x3 && !p.f16 && c->wino_min_channels > 0 && w.w_hi && w.KH == 3 && w.KW == 3 && x.C >= c->wino_min_channels &&
-      w.Cout >= c->wino_min_channels && wino_applicable(p)) {
-    // Winograd form (same ProfRec shape as the direct kernel: the bench rates it in direct-convolution FLOPs).  The
-    // Winograd-domain weights (16 / 9 of the layer's) are made on first use and live until the weights are re-packed.
-    auto it = c->wino_u.find(w.w);
-    if (it == c->wino_u.end()) {
-      void *uh = nullptr, *ul = nullptr;
-      const size_t nu = (size_t)16 * w.Cout * w.Cin;
-      if (dev_alloc(c, &uh, nu * 2) || dev_alloc(c, &ul, nu * 2)) { if (*err == hipSuccess) *err = hipErrorOutOfMemory; return y; }
-      c->owned.push_back(uh);
-      c->owned.push_back(ul);
-      hipError_t we = launch_wino_weights(w.w, (uint16_t*)uh, (uint16_t*)ul, w.Cout, w.Cin, s);
-      if (we != hipSuccess && *err == hipSuccess) *err = we;
-      it = c->wino_u.emplace(w.w, std::make_pair((uint16_t*)uh, (uint16_t*)ul)).first;
-    }
-    if (ensure(c, &c->wino_ws, &c->wino_ws_cap, wino_workspace_bytes(x.B, x.H, x.W, x.C))) e = hipErrorOutOfMemory;
-    else {
-      d2t_ctx::ProfRec r{p.M, p.Cout, p.K, nullptr, nullptr};
-      const bool prof = c->profiling && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess;
-      if (prof) hipEventRecord(r.a, s);
-      e = launch_conv_winograd(p, it->second.first, it->second.second, reinterpret_cast<uint16_t*>(c->wino_ws), s);
-      if (prof) { hipEventRecord(r.b, s); c->prof.push_back(r); }
-    }
-  } else {
-    e = conv_timed(c, p, s);
-  }
+  hipError_t e = conv_timed(c, p, s);
   if (e != hipSuccess && *err == hipSuccess) *err = e;
   return y;
 }
@@ -214,34 +195,52 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   Act x{pick(c, {}), B, H, W, c->stem.Cout};
   x.split = sp;
   const int f16 = sp && c->conv_f16;  // fp16 records between the stem and the last convolution
+  x.fmt = f16;
+  // mixed precision (ctx.h mixed_units): unit u of [layer3.1 .. layer3.4, conv3, layer4.0 .. layer4.2] runs the two-MFMA
+  // arithmetic; a tensor that a mixed unit consumes is written as fp16 hi | lo pairs (its MFMAs read the hi half, the
+  // residual add both), the map between a mixed block's two convolutions as one fp16
+  const int nmix = (sp && !f16 && c->conv_pipelined == 3) ? c->mixed_units : 0;
+  auto mixed = [&](int u) { return u >= 0 && u < nmix; };
+  auto fmt_for = [&](int consumer_unit) { return mixed(consumer_unit) ? 2 : -1; };
   if (sp) HIPCHK(c, launch_stem_split(img, c->stem.w, c->stem.bias, x.planes(), B, H, W, c->stem.Cout, ACT_RELU, s, f16));
   else HIPCHK(c, launch_stem(img, c->stem.w, c->stem.bias, x.p, B, H, W, c->stem.Cout, ACT_RELU, s));
   // the two 2x2 / stride 2 max-pools (resnet.py:94,106) run inside the epilogue of the convolution in front of them on the
   // split-record path with the 16x16x32 kernels: conv0_2 writes 268 MB instead of 1.07 GB and no pool kernel re-reads it
-  const bool fuse_pool = sp && (c->conv_pipelined == 3 || c->conv_pipelined >= 6) && !c->no_pool_fusion;
+  const bool fuse_pool = sp && c->conv_pipelined == 3 && !c->no_pool_fusion;
   x = conv(c, s, &err, x, c->conv0_2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, fuse_pool);
   auto pool = [&](const Act& a, int sh, int sw, int ph, int pw) {
     Act y{pick(c, {a.p}), a.B, (a.H + 2 * ph - 2) / sh + 1, (a.W + 2 * pw - 2) / sw + 1, a.C};
     y.split = a.split;
+    y.fmt = a.fmt;
     hipError_t e = a.split ? launch_maxpool_split(a.planes(), y.planes(), a.B, a.H, a.W, a.C, sh, sw, ph, pw, s, f16)
                            : launch_maxpool(a.p, y.p, a.B, a.H, a.W, a.C, sh, sw, ph, pw, s);
     if (e != hipSuccess && err == hipSuccess) err = e;
     return y;
   };
   auto stage = [&](int li) {
+    int bi = -1;
     for (const Block& b : c->layers[li]) {
+      ++bi;
+      // this block's unit and the unit that consumes its output (layer3.4 -> conv3 = unit 4; layer4.2 -> conv4_1: never mixed)
+      const int unit = li == 2 ? bi - 1 : li == 3 ? 5 + bi : -1;
+      const int next = li == 2 ? bi : li == 3 ? (bi < 2 ? 6 + bi : -1) : -1;
+      if (mixed(unit) && !b.has_down) {
+        Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, false, 1);
+        x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &x, pick(c, {x.p, t.p}), nullptr, sp, false, mixed(next) ? 2 : 0);
+        continue;
+      }
       Act t = conv(c, s, &err, x, b.c1, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
-      if (b.has_down && b.c2cat.w && sp && (c->conv_pipelined == 3 || c->conv_pipelined >= 6) && b.c2.Cout >= 128 && !c->no_shortcut_fusion) {
+      if (b.has_down && b.c2cat.w && sp && c->conv_pipelined == 3 && b.c2.Cout >= 128 && !c->no_shortcut_fusion) {
         // the 1x1 shortcut inside conv2's launch: K-steps over x appended behind the taps over t, one accumulator, no residual
         ConvP ex{};
         ex.in2_hi = x.planes();
         ex.Cin2 = x.C;
-        x = conv(c, s, &err, t, b.c2cat, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p, t.p}), &ex, sp);
+        x = conv(c, s, &err, t, b.c2cat, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p, t.p}), &ex, sp, false, fmt_for(next));
         continue;
       }
       Act r = x;
       if (b.has_down) r = conv(c, s, &err, x, b.down, 1, 1, 0, 0, ACT_NONE, nullptr, pick(c, {x.p, t.p}), nullptr, sp);
-      x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &r, pick(c, {x.p, t.p, r.p}), nullptr, sp);
+      x = conv(c, s, &err, t, b.c2, 1, 1, 1, 1, ACT_RELU, &r, pick(c, {x.p, t.p, r.p}), nullptr, sp, false, fmt_for(next));
     }
     if (c->cfg.gcb) {  // resnet.py:200-201: GlobalContext closes the stage
       const int HW = x.H * x.W;
@@ -264,7 +263,7 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
   x = conv(c, s, &err, x, c->conv2, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = pool(x, 2, 1, 0, 1);
   stage(2);
-  x = conv(c, s, &err, x, c->conv3, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
+  x = conv(c, s, &err, x, c->conv3, 1, 1, 1, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp, false, mixed(5) ? 2 : x.fmt == 2 ? 0 : -1);
   stage(3);
   x = conv(c, s, &err, x, c->conv4_1, 2, 1, 0, 1, ACT_RELU, nullptr, pick(c, {x.p}), nullptr, sp);
   x = conv(c, s, &err, x, c->conv4_2, 1, 1, 0, 0, ACT_RELU, nullptr, final_out ? final_out : pick(c, {x.p}),
@@ -382,14 +381,11 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
-  if (const char* e = getenv("D2T_CONV_KERNEL")) c->conv_pipelined = atoi(e) != 0;
-  if (const char* e = getenv("D2T_NO_POOL_FUSION")) c->no_pool_fusion = atoi(e) != 0;  // (values equal either way)
-  if (const char* e = getenv("D2T_NO_SHORTCUT_FUSION")) c->no_shortcut_fusion = atoi(e) != 0;
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    c->stream_prio = getenv("D2T_NO_PRIO") ? lo : hi;
+    c->stream_prio = D2T_PROBE_ENV_STR("D2T_NO_PRIO") ? lo : hi;
     HIPCHK(c, acquire_stream(c->device, c->stream_prio, &c->dstream));
     for (int i = 1; i < d2t_ctx::MAXC; ++i) HIPCHK(c, acquire_stream(c->device, c->stream_prio, &c->chains[i].stream));
   }
@@ -419,7 +415,6 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->skv) hipFree(c->skv);
   if (c->skv_alt) hipFree(c->skv_alt);
   if (c->beam_ws) hipFree(c->beam_ws);
-  if (c->wino_ws) hipFree(c->wino_ws);
   if (c->beam_qp) hipFree(c->beam_qp);
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
@@ -791,7 +786,7 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
     c->ckv_hi = const_cast<uint16_t*>(hi);
     c->ckv_lo = const_cast<uint16_t*>(lo);
   }
-  c->dec_absorbed = d == 256 && g.dec_heads == 8 && !getenv("D2T_DECODE_PROJECTED_KV");
+  c->dec_absorbed = d == 256 && g.dec_heads == 8 && !D2T_PROBE_ENV_STR("D2T_DECODE_PROJECTED_KV");
   HIPCHK(c, hipStreamSynchronize(s));
   c->finalized = true;
   return D2T_OK;
@@ -935,8 +930,8 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
-    if (c->conv_f16 && f.split && c->patch.w_h16) { p.f16 = 1; p.w_hi = c->patch.w_h16; p.w_lo = c->patch.w_l16; }  // fp16 records from the backbone
-    p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight;
+    if (f.split && f.fmt != 0 && c->patch.w_h16) { p.f16 = 1; p.w_hi = c->patch.w_h16; p.w_lo = c->patch.w_l16; }  // fp16 records from the backbone
+    p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight || D2T_PROBE_ENV("D2T_CONV_TAIL_ALWAYS");
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
@@ -1136,7 +1131,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
   if (rc) return rc;
   c->skv_cur = c->skv;
   c->ckv = c->ckv2[slot];
-  const bool use_graph = getenv("D2T_NO_GRAPH") == nullptr;
+  const bool use_graph = D2T_PROBE_ENV_STR("D2T_NO_GRAPH") == nullptr;
   int64_t* const user_tokens = tokens;
   float* const user_logits = logits;
   const size_t tok_bytes = (size_t)B * S * sizeof(int64_t), log_bytes = (size_t)B * S * V * sizeof(float);
@@ -1197,7 +1192,7 @@ int greedy_impl(d2t_ctx* c, const float* memory, int B, int T, const int64_t* st
         break;
       }
     if (!exec) {
-      if (getenv("D2T_DECODE_TRACE")) {  // debug timeline: the kernel nodes of THIS captured loop get slots 0 .. n-1
+      if (D2T_PROBE_ENV_STR("D2T_DECODE_TRACE")) {  // debug timeline: the kernel nodes of THIS captured loop get slots 0 .. n-1
         if (!c->dtrace) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->dtrace), (size_t)d2t_ctx::DTRACE_SLOTS * 16));
         c->dtrace_next = 0;
       }
@@ -1908,7 +1903,7 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
   // Round 3: with the absorbed row kernel the self-attention cache is never copied -- every hypothesis keeps an ancestry row
   // (which cache row holds each of its earlier positions, launch_beam_ancestry); otherwise the survivors' caches are gathered
   // into the other buffer as before.
-  const bool use_anc = c->dec_absorbed && !c->beam_shared_tile && Lmax <= 512 && getenv("D2T_BEAM_CACHE_COPY") == nullptr;
+  const bool use_anc = c->dec_absorbed && !c->beam_shared_tile && Lmax <= 512 && D2T_PROBE_ENV_STR("D2T_BEAM_CACHE_COPY") == nullptr;
   const size_t skv_bytes = (size_t)g.dec_layers * 2 * cap * Lmax * d * 4;
   if (!use_anc && (rc = ensure(c, &c->skv_alt, &c->skv_alt_cap, skv_bytes))) return rc;
   // workspace: logits [cap][V] | topv [cap] | topi [cap] | step pack (one host -> device copy per step):
@@ -2069,9 +2064,9 @@ int d2t_set_reserved_cus(d2t_ctx* c, int32_t cus) {
 
 int d2t_set_conv_kernel(d2t_ctx* c, int32_t kind) {
   DevGuard dg_(c);
-  if (!c || kind < 0 || kind > 7 || kind == 4)
-    return fail(c, D2T_EINVAL, "conv kernel must be 0 (128x128, two blocks per CU), 1 (pipelined 256x128), 2 (1, with the patch-resident kernel for 3x3 layers on narrow maps) 3 (pipelined 256x128 on 16x16x32 MFMAs), 5 (3, with the patch-resident 16x16x32 kernel for 3x3 layers on narrow maps) 6 (3, with the band-resident 16x16x32 kernel for every 3x3 / stride 1 / pad 1 layer) or 7 (3, with 256x256 tiles on eight waves for layers of at least 256 output channels)");
-  if (c->conv_f16 && kind != 3) return fail(c, D2T_ESTATE, "the fp16x2 convolutions exist for conv kernel 3 only");
+  if (!c || (kind != 0 && kind != 3))
+    return fail(c, D2T_EINVAL, "conv kernel must be 3 (pipelined 256x128 on 16x16x32 MFMAs, one block per CU) or 0 (128x128 on 32x32x16 MFMAs, two blocks per CU)");
+  if ((c->conv_f16 || c->mixed_units) && kind != 3) return fail(c, D2T_ESTATE, "the fp16x2 convolutions exist for conv kernel 3 only");
   c->conv_pipelined = kind;
   return D2T_OK;
 }
@@ -2083,11 +2078,11 @@ int d2t_set_beam_shared_tile(d2t_ctx* c, int32_t on) {
   return D2T_OK;
 }
 
-int d2t_set_conv_winograd(d2t_ctx* c, int32_t min_channels) {
+int d2t_set_conv_fusion(d2t_ctx* c, int32_t pools, int32_t shortcuts) {
   DevGuard dg_(c);
-  if (!c || min_channels < 0) return fail(c, D2T_EINVAL, "bad argument");
-  if (min_channels > 0 && min_channels < 256) return fail(c, D2T_EINVAL, "Winograd-domain weights are kept for layers with >= 256 input channels");
-  c->wino_min_channels = min_channels;
+  if (!c) return D2T_EINVAL;
+  c->no_pool_fusion = pools == 0;
+  c->no_shortcut_fusion = shortcuts == 0;
   return D2T_OK;
 }
 
@@ -2100,12 +2095,22 @@ int d2t_set_decode_chains(d2t_ctx* c, int32_t chains) {
 
 int d2t_set_conv_precision(d2t_ctx* c, int32_t mode) {
   DevGuard dg_(c);
-  if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3 && mode != D2T_CONV_FP16X2))
+  if (!c || (mode != D2T_CONV_FP32 && mode != D2T_CONV_BF16X3 && mode != D2T_CONV_FP16X2 && mode != D2T_CONV_MIXED))
     return fail(c, D2T_EINVAL, "unknown conv precision %d", mode);
-  if (mode == D2T_CONV_FP16X2 && c->conv_pipelined != 3)
+  if ((mode == D2T_CONV_FP16X2 || mode == D2T_CONV_MIXED) && c->conv_pipelined != 3)
     return fail(c, D2T_ESTATE, "the fp16x2 convolutions exist for conv kernel 3 (pipelined 256x128 on 16x16x32 MFMAs) only");
   c->conv_bf16x3 = mode != D2T_CONV_FP32;
   c->conv_f16 = mode == D2T_CONV_FP16X2;
+  c->mixed_units = mode == D2T_CONV_MIXED ? D2T_MIXED_UNITS_DEFAULT : 0;
+  return D2T_OK;
+}
+
+int d2t_set_mixed_units(d2t_ctx* c, int32_t units) {
+  DevGuard dg_(c);
+  if (!c || units < 0 || units > 8) return fail(c, D2T_EINVAL, "mixed units must be 0 .. 8");
+  if (units > 0 && (!c->conv_bf16x3 || c->conv_f16 || c->conv_pipelined != 3))
+    return fail(c, D2T_ESTATE, "mixed units need the split-bf16 arithmetic on conv kernel 3");
+  c->mixed_units = units;
   return D2T_OK;
 }
 
@@ -2194,7 +2199,7 @@ int d2t_op_conv2d_bf16x3(const float* x, const float* w, const float* bias, cons
 // kernel selection of d2t_op_conv2d_bf16x3_split (process-wide; op-level tests and tools/conv_bench.py only)
 static int g_op_conv_kind = 3, g_op_reserved_cus = 0;
 int d2t_op_set_conv_kernel(int32_t kind, int32_t reserved_cus) {
-  if (kind < 0 || kind > 8 || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 4: Winograd F(2x2,3x3) where applicable; 8: kind 3 in fp16x2 arithmetic (ConvP::f16)
+  if ((kind != 0 && kind != 3 && kind != 8) || reserved_cus < 0 || reserved_cus > 128) return D2T_EINVAL;  // 0 / 3 as d2t_set_conv_kernel; 8: kind 3 in fp16x2 arithmetic (ConvP::f16)
   g_op_conv_kind = kind;
   g_op_reserved_cus = reserved_cus;
   return D2T_OK;
@@ -2235,22 +2240,10 @@ int d2t_op_conv2d_bf16x3_split(const float* x, const float* w, const float* bias
   if (e == hipSuccess) e = f16 ? launch_split_f16(wp, whi, wlo, nw, s) : launch_split_bf16(wp, whi, wlo, nw, s);
   if (e == hipSuccess) e = launch_split_act(x, xs, rx, Cin, s, f16);
   if (e == hipSuccess && residual) e = launch_split_act(residual, rs, ry, Cout, s, f16);
-  void* wbuf = nullptr;
-  if (e == hipSuccess && g_op_conv_kind == 4 && wino_applicable(p)) {
-    const size_t nu = (size_t)16 * Cout * Cin * 2, nv = wino_workspace_bytes(B, H, W, Cin);
-    if (hipMalloc(&wbuf, 2 * nu + nv) != hipSuccess) { hipFree(buf); return D2T_ENOMEM; }
-    uint16_t* uh = (uint16_t*)wbuf;
-    uint16_t* ul = (uint16_t*)((char*)wbuf + nu);
-    e = launch_wino_weights(wp, uh, ul, Cout, Cin, s);
-    if (e == hipSuccess) e = launch_conv_winograd(p, uh, ul, (uint16_t*)((char*)wbuf + 2 * nu), s);
-  } else if (e == hipSuccess) {
-    if (g_op_conv_kind == 4) p.pipelined = 3;
-    e = launch_conv_bf16x3(p, s);
-  }
+  if (e == hipSuccess) e = launch_conv_bf16x3(p, s);
   if (e == hipSuccess) e = launch_merge_act(ys, y, ry, Cout, s, f16);
   hipStreamSynchronize(s);
   hipFree(buf);
-  if (wbuf) hipFree(wbuf);
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 
@@ -2297,7 +2290,6 @@ int d2t_op_conv2d_bf16x3_split_pool(const float* x, const float* w, const float*
   if (e == hipSuccess) e = launch_merge_act(ys, y, rp, Cout, s, f16);
   hipStreamSynchronize(s);
   hipFree(buf);
-  if (wbuf) hipFree(wbuf);
   return e == hipSuccess ? D2T_OK : D2T_EHIP;
 }
 

@@ -9,10 +9,14 @@
 // D2T_PROBES=1 -> -DD2T_PROBES); the shipped library never reads them, so a stray variable in a serving or training
 // environment cannot change any result.
 #include <cstdlib>
+// The A/B switches of the kernels' rejected variants (round 4: every former getenv of the library) follow the same rule:
+// D2T_PROBE_ENV_STR is getenv in a probe build and nullptr in the shipped library.
 #ifdef D2T_PROBES
 #define D2T_PROBE_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#define D2T_PROBE_ENV_STR(name) getenv(name)
 #else
 #define D2T_PROBE_ENV(name) 0
+#define D2T_PROBE_ENV_STR(name) (static_cast<const char*>(nullptr))
 #endif
 
 namespace d2t {
@@ -40,8 +44,8 @@ struct ConvP {
   int max_blocks;        // > 0: launch at most this many (persistent) blocks of the split-bf16 kernel
   int reserved_cus;      // pipelined split-bf16 kernel (one block per CU): CUs left free for other streams' kernels
   int wave_prio;         // pipelined kernel: s_setprio of its waves (experiments; 0 = default)
-  int pipelined;         // != 0: take the pipelined 256x128 kernel (conv_bf16x3p.hip) when the layer qualifies
-  int split_tail;        // pipelined kernel: hand the rows of a sparsely filled last round of tiles to the 128-row kernel
+  int pipelined;         // 3: take the pipelined 256x128 kernel (conv_bf16x3p.hip) when the layer qualifies (Cout >= 128); 0: the 128-row kernels
+  int split_tail;        // pipelined kernel: hand the rows of a sparsely filled last round of tiles to its 64 x 128 build
   // != 0: a 2x2 / stride 2 max-pool (resnet.py:94,106) fused into the epilogue of the split-record LDS-DMA kernels
   // (conv_bf16x3g_body, conv_bf16x3p16_body): the GEMM's rows are the convolution's output pixels in POOLED ORDER --
   // row m = 4 * pooled pixel + (oh & 1) * 2 + (ow & 1), M = 4 * B * (OH / 2) * (OW / 2) -- and the wide epilogue writes one
@@ -57,6 +61,11 @@ struct ConvP {
   // half; w_hi / w_lo are fp16 hi / lo planes (launch_split_f16); a product is x16 * w_lo + x16 * w_hi -- two MFMAs instead of
   // three (conv_common.h split_rec / join_rec).  Split-record kernels only: conv_bf16x3g_body and conv_bf16x3p16_body.
   int f16;
+  // record formats of out_hi / res_hi when they differ from the input's (round 4, "mixed" precision: a few layers on the
+  // two-MFMA arithmetic inside a split-bf16 backbone).  0 = as `f16` says (bf16 split, or one fp16); otherwise 1 + format:
+  // 1 = bf16 hi | lo, 2 = fp16 in the hi half, 3 = fp16 hi | fp16 lo (x ~ hi + lo to 22 bits: what a residual path reads back
+  // in full precision while the next convolution's MFMAs take the hi half alone).  conv_common.h out_fmt / res_fmt.
+  int out_fmt, res_fmt;
   const float* bias;     // [Cout] or nullptr
   const float* res;      // [rows][Cout] or nullptr, indexed like out
   const float* row_add;  // [*][Cout] or nullptr (positional tables), added after the activation
@@ -78,12 +87,6 @@ hipError_t launch_conv(const ConvP& p, hipStream_t s);         // fp32 MFMA, or 
 hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s);
 hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s);  // 256x128 tile, 3 LDS stages, one block per CU
 hipError_t launch_conv_bf16x3g_rows(const ConvP& p, int bn, hipStream_t s);  // 128-row LDS-DMA kernel over rows [m_base, M)
-// Winograd F(2x2, 3x3) form of the split-bf16 3x3 / stride 1 / pad 1 convolution (conv_winograd.hip): u_hi / u_lo
-// [16][Cout][Cin] from launch_wino_weights (once per layer, from the packed folded weights), v_ws >= wino_workspace_bytes
-size_t wino_workspace_bytes(int B, int H, int W, int Cin);
-bool wino_applicable(const ConvP& p);
-hipError_t launch_wino_weights(const float* w_packed, uint16_t* u_hi, uint16_t* u_lo, int Cout, int Cin, hipStream_t s);
-hipError_t launch_conv_winograd(const ConvP& p, const uint16_t* u_hi, const uint16_t* u_lo, uint16_t* v_ws, hipStream_t s);
 // hi = bf16(w) (round-to-nearest-even), lo = bf16(w - hi)
 hipError_t launch_split_bf16(const float* w, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 // hi = fp16(w), lo = fp16(w - hi) (fp16x2 mode, ConvP::f16)

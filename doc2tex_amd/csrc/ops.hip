@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* _
 }
 
 hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s) {
-  static const bool valu = getenv("D2T_VIT_ATTN_VALU") != nullptr;
+  static const bool valu = D2T_PROBE_ENV_STR("D2T_VIT_ATTN_VALU") != nullptr;
   if (!valu && N <= 512) {
     const int tiles = (N + 31) / 32;
     const size_t lds2 = ((size_t)tiles * 32 * 33 + (size_t)tiles * 32 * 32) * sizeof(float);

@@ -192,7 +192,7 @@ struct Tr {  // builder / runner bound to one context and stream
   // the kernel that splits fp32 activations inside its K loop to the LDS-DMA kernels (conv_bf16x3p.hip: ~25 % faster; the
   // copy costs one pass over the input).  Same split, same three-MFMA products.
   bool want_planes(long long rows, int C) const {
-    static const bool off = getenv("D2T_TRAIN_SPLIT_INPUT") && atoi(getenv("D2T_TRAIN_SPLIT_INPUT")) == 0;
+    static const bool off = D2T_PROBE_ENV_STR("D2T_TRAIN_SPLIT_INPUT") && D2T_PROBE_ENV("D2T_TRAIN_SPLIT_INPUT") == 0;
     return !off && c->conv_bf16x3 && c->zero_page && C % 32 == 0 && rows * C * 2 <= 0x7fffffffLL;
   }
   // records written by the producer of a tensor (BatchNorm apply kernels), or nullptr
@@ -234,7 +234,7 @@ struct Tr {  // builder / runner bound to one context and stream
             const TT* xin, const TT* yout, float* dst, int layout, const uint16_t* a_rec = nullptr,
             const uint16_t* b_rec = nullptr) {
     // both operands exist as split-bf16 records (a convolution between BatchNorm layers): the LDS-DMA kernel
-    static const bool rec_off = getenv("D2T_WGRAD_REC") && atoi(getenv("D2T_WGRAD_REC")) == 0;
+    static const bool rec_off = D2T_PROBE_ENV_STR("D2T_WGRAD_REC") && D2T_PROBE_ENV("D2T_WGRAD_REC") == 0;
     const int shape = !rec_off && a_rec && b_rec && geom && c->conv_bf16x3 && c->zero_page && lda == M && ldb == N ? wgrad_rec_shape(M, N) : -1;
     const bool rec = shape >= 0;
     static const int TM[5] = {128, 256, 256, 128, 64}, TN[5] = {128, 128, 256, 64, 32}, SLOTS[5] = {768, 512, 256, 1024, 2048};
@@ -256,7 +256,7 @@ struct Tr {  // builder / runner bound to one context and stream
     }
     // the record kernel's K loops are cheap to keep long and every extra split is another [taps][M][N] partial to write
     // and sum: one round of blocks (measured against 2 ... 4 rounds and the rule above: 113.8 vs 114.2 ... 117.8 ms per step)
-    static const int rec_rounds = getenv("D2T_WGRAD_ROUNDS") ? std::max(1, atoi(getenv("D2T_WGRAD_ROUNDS"))) : 1;
+    static const int rec_rounds = D2T_PROBE_ENV_STR("D2T_WGRAD_ROUNDS") ? std::max(1, D2T_PROBE_ENV("D2T_WGRAD_ROUNDS")) : 1;
     if (rec) S = std::max<long long>(1, std::min<long long>(smax, rec_rounds * slots / tiles));
     long long chunk = ((P + S - 1) / S + 31) / 32 * 32;
     S = (P + chunk - 1) / chunk;
@@ -900,7 +900,7 @@ struct Tr {  // builder / runner bound to one context and stream
     p.B = B; p.S = S; p.V = V; p.H = Hh; p.E = Hh; p.coverage = g.attn_coverage;
     // The two products that do not take part in the recurrence leave the sequential kernel (each cost its weight matrix
     // per row and step from L2): dlogits . generator.weight for all (row, step) as one GEMM before it ...
-    static const bool hoist = !(getenv("D2T_LSTM_BWD_HOIST") && atoi(getenv("D2T_LSTM_BWD_HOIST")) == 0);
+    static const bool hoist = !(D2T_PROBE_ENV_STR("D2T_LSTM_BWD_HOIST") && D2T_PROBE_ENV("D2T_LSTM_BWD_HOIST") == 0);
     if (hoist) {
       const int Vp = (V + 31) / 32 * 32;
       float *gpad, *wgp, *dhl;

@@ -503,8 +503,8 @@ void wgrad_rec_kernel(const WgradP p) {
 // block tile of the record kernel: 0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256 (D2T_WGRAD_WIDE caps these three),
 // 3 = 128 x 64 (Cin = 64), 4 = 64 x 32 (conv0_2: 32 -> 64 channels); -1: the channel counts fit none of them
 int wgrad_rec_shape(int M, int N) {
-  static const int mode = getenv("D2T_WGRAD_WIDE") ? atoi(getenv("D2T_WGRAD_WIDE")) : 2;
-  static const bool narrow = !(getenv("D2T_WGRAD_NARROW") && atoi(getenv("D2T_WGRAD_NARROW")) == 0);
+  static const int mode = D2T_PROBE_ENV_STR("D2T_WGRAD_WIDE") ? D2T_PROBE_ENV("D2T_WGRAD_WIDE") : 2;
+  static const bool narrow = !(D2T_PROBE_ENV_STR("D2T_WGRAD_NARROW") && D2T_PROBE_ENV("D2T_WGRAD_NARROW") == 0);
   if (M % 128 == 0 && N % 128 == 0) {
     if (mode >= 2 && M % 256 == 0 && N % 256 == 0) return 2;
     if (mode >= 1 && M % 256 == 0) return 1;

@@ -279,9 +279,14 @@ class Engine:
 
     def set_conv_precision(self, mode):
         """'fp32' (exact), 'bf16x3' (split-bf16 matrix-core path for the convolutions: three products per element) or 'fp16x2'
-        (fp16 feature maps times fp16 hi / lo weights in the backbone: two products per element)."""
-        code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3, "fp16x2": _lib.CONV_FP16X2}[mode]
+        (fp16 feature maps times fp16 hi / lo weights in the backbone: two products per element), or 'mixed' ('bf16x3' with the
+        'fp16x2' arithmetic in the first few 512 -> 512 units of the backbone only: set_mixed_units)."""
+        code = {"fp32": _lib.CONV_FP32, "bf16x3": _lib.CONV_BF16X3, "fp16x2": _lib.CONV_FP16X2, "mixed": _lib.CONV_MIXED}[mode]
         self._check(self.lib.d2t_set_conv_precision(self.ctx, code), "set_conv_precision")
+
+    def set_mixed_units(self, units):
+        """'mixed' precision: how many of the backbone's eight plain 512 -> 512 units run the two-MFMA fp16 arithmetic (0 .. 8)."""
+        self._check(self.lib.d2t_set_mixed_units(self.ctx, int(units)), "set_mixed_units")
 
     def set_reserved_blocks(self, blocks):
         self._check(self.lib.d2t_set_reserved_blocks(self.ctx, int(blocks)), "set_reserved_blocks")
@@ -290,17 +295,20 @@ class Engine:
         self._check(self.lib.d2t_set_reserved_cus(self.ctx, int(cus)), "set_reserved_cus")
 
     def set_conv_kernel(self, kind):
-        """'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs), 'pipelined' (32x32x16 MFMAs),
-        'patch' (pipelined + patch-resident 3x3 kernel) or 'classic' (128x128, two blocks per CU)."""
-        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined": 1, "patch": 2, "pipelined16": 3, "patch16": 5, "band16": 6, "wide16": 7}[kind]), "set_conv_kernel")
+        """'pipelined16' (256x128 tile, one block per CU, three LDS stages, 16x16x32 MFMAs; default) or 'classic' (128x128 on
+        32x32x16 MFMAs, two blocks per CU)."""
+        if kind not in ("classic", "pipelined16"):
+            raise ValueError(f"conv kernel must be 'pipelined16' or 'classic', not {kind!r}")
+        self._check(self.lib.d2t_set_conv_kernel(self.ctx, {"classic": 0, "pipelined16": 3}[kind]), "set_conv_kernel")
 
     def set_beam_shared_tile(self, on):
         """Beam search: one cross-attention block per sample serving all its hypotheses from one staged memory tile (beam <= 6)."""
         self._check(self.lib.d2t_set_beam_shared_tile(self.ctx, int(bool(on))), "set_beam_shared_tile")
 
-    def set_conv_winograd(self, min_channels):
-        """Winograd F(2x2,3x3) for the 3x3 layers with at least `min_channels` channels on both sides (0 = off)."""
-        self._check(self.lib.d2t_set_conv_winograd(self.ctx, int(min_channels)), "set_conv_winograd")
+    def set_conv_fusion(self, pools=True, shortcuts=True):
+        """Validation switches: run the 2x2 max-pools / the BasicBlocks' 1x1 shortcuts as their own kernels (False) instead of
+        inside the neighbouring convolution's launch (True, default)."""
+        self._check(self.lib.d2t_set_conv_fusion(self.ctx, int(bool(pools)), int(bool(shortcuts))), "set_conv_fusion")
 
     def set_decode_chains(self, chains):
         self._check(self.lib.d2t_set_decode_chains(self.ctx, int(chains)), "set_decode_chains")

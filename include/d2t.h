@@ -242,9 +242,18 @@ int d2t_decode_attn_beam(d2t_ctx* ctx, const float* memory, int32_t T, int32_t b
  *                 exact and |dlogit| <= 1e-3 on the reference fixtures of the HybridViT / LSTM-head stacks (measured
  *                 1.2e-4 .. 2.1e-4 on the benchmark configs), with a 5x instead of a 20x margin -- and NOT on the ResNet-only
  *                 stacks (up to 9e-3): DESIGN.md section 3.  Everything that takes fp32 input (ViT linears, decoder) is as in
- *                 D2T_CONV_BF16X3.  Needs conv kernel 3 (d2t_set_conv_kernel). */
-enum { D2T_CONV_FP32 = 0, D2T_CONV_BF16X3 = 1, D2T_CONV_FP16X2 = 2 };
+ *                 D2T_CONV_BF16X3.  Needs conv kernel 3 (d2t_set_conv_kernel).
+ * D2T_CONV_MIXED  (round 4, opt-in) D2T_CONV_BF16X3 with the two-MFMA fp16 arithmetic of D2T_CONV_FP16X2 in the first
+ *                 D2T_MIXED_UNITS_DEFAULT of the backbone's eight plain 512 -> 512 units [layer3.1, layer3.2, layer3.3,
+ *                 layer3.4, conv3, layer4.0, layer4.1, layer4.2] (resnet.py:32-48, 205-245; the K = 4608 layers) and nothing
+ *                 else.  The tensors entering / leaving those units are stored as fp16 hi | fp16 lo pairs (22 bits), so the
+ *                 residual stream keeps its precision and only the MFMA's activation operand is rounded to 11 bits.  The error
+ *                 of the logits grows with the square root of the number of two-MFMA layers (DESIGN.md section 3,
+ *                 tools/probe/fp16x2_sim.py); d2t_set_mixed_units changes the count (0 .. 8; 0 = D2T_CONV_BF16X3). */
+enum { D2T_CONV_FP32 = 0, D2T_CONV_BF16X3 = 1, D2T_CONV_FP16X2 = 2, D2T_CONV_MIXED = 3 };
+#define D2T_MIXED_UNITS_DEFAULT 4
 int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
+int d2t_set_mixed_units(d2t_ctx* ctx, int32_t units);
 
 /* Pipelined serving: the split-bf16 convolution is a persistent kernel; capping its grid at
  * (2 x CUs - blocks) leaves `blocks` block slots free at all times, into which the latency-bound decode
@@ -252,22 +261,18 @@ int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
  * for a convolution block to retire.  0 (default) = use every slot. */
 int d2t_set_reserved_blocks(d2t_ctx* ctx, int32_t blocks);
 
-/* The split-bf16 convolution kernel and its grid.  kind 1 (default): the pipelined 256x128 kernel -- ONE block per CU
- * holding three LDS stages, LDS-DMA two K-steps ahead behind counted waits; its persistent grid spans (CUs - reserved)
- * compute units, d2t_set_reserved_cus leaving the rest to the decode streams of the previous batches (pipelined serving;
- * also the place where the tile count of the dominant layer comes out in whole rounds).  kind 0: the 128x128 kernel with
- * two blocks per CU (d2t_set_reserved_blocks applies to that one).  kind 2: as 1, but 3x3 / stride 1 / pad 1 layers on
- * maps at most 131 pixels wide take the patch-resident kernel (a tile's input records stay in LDS for all nine taps: half
- * the LDS-DMA; measured equal to kind 1 in sustained runs).  Results are bit-identical between kinds 0-2.
- * kind 3: the pipelined kernel built on v_mfma_f32_16x16x32_bf16 (same tile, stages and loaders; one MFMA per K-step of 32
- * and 16x16 output block): same three products per element in the same order, but the sum inside an MFMA spans 32 k, so
- * results agree with kinds 0-2 to fp32 rounding, not bit for bit; all rows of a layer stay on this kernel. */
+/* The split-bf16 convolution kernel of the layers with at least 128 output channels.  kind 3 (default): the pipelined
+ * 256x128 kernel on v_mfma_f32_16x16x32_bf16 -- ONE persistent block per CU holding three LDS stages, LDS-DMA two K-steps
+ * ahead behind counted waits, grid = (CUs - d2t_set_reserved_cus) -- with the fused max-pools / shortcuts and the fp16x2 /
+ * mixed arithmetic built on it.  kind 0: the 128x128 kernel on 32x32x16 MFMAs with two blocks per CU (the kernel of the
+ * narrower layers; d2t_set_reserved_blocks applies to it).  Same three products per element in the same order in both; the
+ * sum inside an MFMA spans 32 k in kind 3 and 16 in kind 0, so the two agree to fp32 rounding, not bit for bit; all rows of
+ * a layer always run on one kind.  (Rounds 1-3 exported five more variants here; they were A/B arms and left in round 4.) */
 int d2t_set_conv_kernel(d2t_ctx* ctx, int32_t kind);
-/* Winograd F(2x2, 3x3) form of the split-bf16 3x3 / stride 1 / pad 1 convolutions (inference; conv_winograd.hip) for the
- * layers with at least `min_channels` (>= 256) input and output channels; 0 switches it off.  2.25 x fewer matrix
- * products for 4 x the activation traffic of those layers; results agree with the direct kernels to the accuracy of
- * the split-bf16 arithmetic (tools/winograd_study.py: tokens exact on every fixture), not bit for bit. */
-int d2t_set_conv_winograd(d2t_ctx* ctx, int32_t min_channels);
+/* Validation switches (tests): pools = 0 runs the two 2x2 max-pools as their own kernels instead of inside the epilogue of the
+ * convolution in front of them, shortcuts = 0 the BasicBlocks' 1x1 shortcuts as their own launches instead of inside conv2's.
+ * Pooled values are bit-identical either way; the shortcut sum forms in another order (fp32 rounding).  Default: both fused. */
+int d2t_set_conv_fusion(d2t_ctx* ctx, int32_t pools, int32_t shortcuts);
 /* Beam search of the d_model-256 TFM decoder, cross-attention: 0 (default) one block per hypothesis row, each reading its
  * sample's memory rows; 1: one block per SAMPLE that stages the sample's memory tiles in LDS once per layer and step for
  * all its live hypotheses (beam <= 6; decode.hip beam_cross_kernel).  Same results to fp32 summation order. */

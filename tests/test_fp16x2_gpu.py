@@ -114,8 +114,66 @@ def test_fp16x2_beam_sequences_vs_reference_fixture(cases):
 def test_fp16x2_needs_the_pipelined_16x16x32_kernel(cases):
     c = _case(cases, "greedy", "t2_greedy")
     cfg, m = _model(c)
-    m.conv_kernel = "pipelined"
+    m.conv_kernel = "classic"
     img = synth.synth_images(1, c["H"], c["W"], seed=1).cuda()
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m.forward_encoder(img)
+
+
+# ---- 'mixed' precision (round 4; include/d2t.h D2T_CONV_MIXED): split-bf16 everywhere except the first few plain 512 -> 512
+# units of the backbone, which run the two-MFMA arithmetic on fp16 hi | lo records -----------------------------------------
+MIXED_LOGIT_TOL = 5e-4  # half the north_star bar: the mode rounds the MFMA operand of at most 15 of the 32 layers
+
+
+def _mixed_model(c, units):
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"], beam_size=c.get("beam_size"))
+    m.conv_precision = "mixed"
+    m.mixed_units = units
+    return cfg, m
+
+
+@pytest.mark.parametrize("units", [1, 4, 5, 8])
+@pytest.mark.parametrize("name", ["t2_greedy", "c2_small_crop", "c4_greedy_96", "s0_greedy", "t1_greedy"])
+def test_mixed_precision_greedy_vs_reference_fixture(cases, name, units):
+    """Every prefix length that changes the record formats at a unit boundary (1: one block; 4: all of layer3's plain blocks,
+    split-bf16 from conv3 on; 5: conv3 inside; 8: through layer4.2 into conv4_1) against the reference's fixtures.  On the
+    ResNet-only stack (T1: the decoder reads the backbone's output directly, magnitudes of several hundred) the mode is not
+    offered -- as for fp16x2 the failure is graceful: tokens exact, logits within 2e-2 (measured 1.8e-3 at 4 units)."""
+    c = _case(cases, "greedy", name)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, m = _mixed_model(c, units)
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        preds, logits, _ = m(img, text, is_train=False, is_test=c["is_test"])
+    torch.cuda.synchronize()
+    assert np.array_equal(preds.cpu().numpy(), z["tokens"]), "greedy token ids differ from the reference"
+    dl = float(np.abs(logits.cpu()[:, z["logit_steps"].tolist()].numpy() - z["logits_sample"]).max())
+    assert dl <= (2e-2 if name == "t1_greedy" else MIXED_LOGIT_TOL), f"logits differ by {dl}"
+
+
+def test_mixed_precision_with_zero_units_is_split_bf16_bit_for_bit(cases):
+    c = _case(cases, "greedy", "t2_greedy")
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    outs = []
+    for prec, units in (("bf16x3", 0), ("mixed", 0), ("mixed", 4)):
+        cfg, m = _mixed_model(c, units)
+        m.conv_precision = prec
+        with torch.no_grad():
+            outs.append(m(img, text, is_train=False)[1].cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])  # (the mode does change the arithmetic)
+
+
+def test_mixed_precision_is_shard_invariant(cases):
+    """Dispatch by layer shape only: a sample's logits do not depend on the batch it travels in."""
+    c = _case(cases, "greedy", "c2_small_crop")
+    cfg, m = _mixed_model(c, 4)
+    img = synth.synth_images(6, c["H"], c["W"], seed=77).cuda()
+    text = torch.full((6, 1), R.GO, dtype=torch.long, device="cuda")
+    with torch.no_grad():
+        p, l, _ = m(img, text, is_train=False)
+        parts = [m(img[i:i + n], text[i:i + n], is_train=False) for i, n in ((0, 1), (1, 2), (3, 3))]
+    assert torch.equal(p, torch.cat([q[0] for q in parts])) and torch.equal(l, torch.cat([q[1] for q in parts]))

@@ -250,15 +250,16 @@ def test_conv_bf16x3_large_tiles():
     (3, 7, 37, 128, 384, (3, 3), (1, 1), (1, 1), True),      # ragged rows and a partial last row tile
     (1, 16, 129, 256, 512, (2, 2), (2, 1), (0, 1), False),   # conv4_1's strided, asymmetrically padded window
     (1, 5, 9, 64, 128, (2, 2), (2, 2), (0, 0), False),       # 8 output rows
-    (3, 9, 131, 64, 256, (3, 3), (1, 1), (1, 1), True),      # the widest map the patch-resident kernel takes (W = 131)
+    (3, 9, 131, 64, 256, (3, 3), (1, 1), (1, 1), True),      # an odd width, two column tiles
     (5, 13, 50, 96, 128, (3, 3), (1, 1), (1, 1), False),     # three channel chunks, tiles that straddle images and rows
-    (33, 16, 129, 64, 512, (3, 3), (1, 1), (1, 1), True),    # 267 x 2 tiles of 256 x 256: one whole round + 11 tile rows left over
+    (33, 16, 129, 64, 512, (3, 3), (1, 1), (1, 1), True),    # 267 x 4 tiles: four whole rounds + 44 tiles for the 64 x 128 build
 ])
-def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
-    """The pipelined 256x128 kernel (default) and the 128x128 LDS-DMA kernel stage the same records and run the same three-MFMA
-    sequence per output element in the same K order, so every output must agree BIT FOR BIT -- which is what lets the engine
-    pick either per layer, hand a sparsely filled last round of tiles to the small kernel, and keep a sample's results
-    independent of its batch.  Both are also checked against float64."""
+def test_pipelined_convolution_vs_the_128_row_kernel_and_float64(shape):
+    """The pipelined 256x128 kernel on 16x16x32 MFMAs (default, kind 3) against the 128x128 LDS-DMA kernel on 32x32x16 (kind 0):
+    the same records, the same three products per output element in the same K order; the sum inside one MFMA spans 32 k
+    instead of 16, so the two agree to fp32 rounding and are equally close to float64.  And per sample: a sample's rows do not
+    depend on the batch they are computed in (one kernel per layer shape; the leftover rows of a sparsely filled last round of
+    tiles go to the 64 x 128 build of the same body, bit for bit)."""
     lib = _lib.require_device()
     B, H, W, Cin, Cout, k, st, pd, use_res = shape
     x = _rand(B, Cin, H, W, seed=31)
@@ -270,66 +271,28 @@ def test_pipelined_convolution_is_bit_identical_to_the_128_row_kernel(shape):
     wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
     bd = b.to(DEV)
     rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
-    outs = []
-    try:
-        for kind in (0, 1, 2):  # 128-row two-stage kernel, pipelined 256x128, patch-resident 3x3 (where the layer qualifies)
-            assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
-            y = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
-            assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
-                                                  Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
-                                                  _lib.stream_of(xd)) == 0
-            torch.cuda.synchronize()
-            outs.append(y.cpu())
-        # the default: the pipelined kernel on 16x16x32 MFMAs.  Same products per element in the same order, but the sum inside
-        # one MFMA spans 32 k instead of 16: equal to fp32 rounding, and exactly as close to float64 as the others
-        assert lib.d2t_op_set_conv_kernel(3, 0) == 0
-        y16 = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16), B, H, W,
-                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
-        # and per sample: a sample's rows do not depend on the batch they are computed in (one kernel per layer shape)
-        y16_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
-                                              _lib.ptr(y16_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
-                                              _lib.stream_of(xd)) == 0
-        # kind 5: the patch-resident 16x16x32 kernel where the layer qualifies -- bit-identical to kind 3
-        assert lib.d2t_op_set_conv_kernel(5, 0) == 0
-        y16p = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16p), B, H, W,
-                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
-        # kind 6: the band-resident 16x16x32 kernel (every 3x3 / stride 1 / pad 1 layer) -- bit-identical to kind 3, whole
-        # batch and single sample
-        assert lib.d2t_op_set_conv_kernel(6, 0) == 0
-        y16b = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16b), B, H, W,
-                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
-        y16b_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
-                                              _lib.ptr(y16b_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
-                                              _lib.stream_of(xd)) == 0
-        # kind 7: 256 x 256 tiles on eight waves (layers of at least 256 output channels; leftover tile rows on the 256 x 128
-        # kernel) -- bit-identical to kind 3, whole batch and single sample
-        assert lib.d2t_op_set_conv_kernel(7, 0) == 0
-        y16w = torch.full((B, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y16w), B, H, W,
-                                              Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
-        y16w_0 = torch.full((1, OH, OW, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
-                                              _lib.ptr(y16w_0), 1, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1,
-                                              _lib.stream_of(xd)) == 0
+
+    def run(kind, xs, rs, n):
+        assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
+        y = torch.full((n, OH, OW, Cout), float("nan"), device=DEV)
+        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xs), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rs) if use_res else None, _lib.ptr(y),
+                                              n, H, W, Cin, Cout, k[0], k[1], st[0], st[1], pd[0], pd[1], 1, _lib.stream_of(xd)) == 0
         torch.cuda.synchronize()
-        y16, y16_0 = y16.cpu(), y16_0.cpu()
-        assert torch.equal(y16p.cpu(), y16)
-        assert torch.equal(y16b.cpu(), y16) and torch.equal(y16b_0.cpu(), y16_0)
-        assert torch.equal(y16w.cpu(), y16) and torch.equal(y16w_0.cpu(), y16_0)
+        return y.cpu()
+
+    try:
+        y32 = run(0, xd, rd, B)
+        y16 = run(3, xd, rd, B)
+        y16_0 = run(3, xd[B - 1:], rd[B - 1:] if use_res else None, 1)
+        assert lib.d2t_op_set_conv_kernel(1, 0) != 0  # (the variants of rounds 1-3 are gone from the library)
     finally:
         lib.d2t_op_set_conv_kernel(3, 0)
-    assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(y32).all() and torch.isfinite(y16).all()
     ref = _ref_conv(x, w, b, res, st, pd, 1)
-    e32 = float((outs[1].permute(0, 3, 1, 2) - ref).abs().max())
+    e32 = float((y32.permute(0, 3, 1, 2) - ref).abs().max())
     e16 = float((y16.permute(0, 3, 1, 2) - ref).abs().max())
     assert e32 <= 4e-4 and e16 <= 4e-4 and e16 <= 1.5 * e32 + 1e-6, (e32, e16)
-    assert torch.isfinite(y16).all() and torch.equal(y16[B - 1:], y16_0)
+    assert torch.equal(y16[B - 1:], y16_0)
 
 
 @pytest.mark.parametrize("shape", [
@@ -363,50 +326,6 @@ def test_convolution_with_the_max_pool_fused(shape):
     assert torch.equal(pooled, want), float((pooled - want).abs().max())
     ref = torch.nn.functional.max_pool2d(_ref_conv(x, w, b, None, (1, 1), (1, 1), 1), 2, 2)
     assert float((pooled.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= 4e-4
-
-
-@pytest.mark.parametrize("shape", [
-    # B, H, W, Cin, Cout, residual
-    (2, 16, 129, 512, 512, True),    # the dominant layer's geometry (odd width: the last tile column is half outside)
-    (3, 7, 37, 128, 384, True),      # odd height and width, three column tiles
-    (1, 5, 9, 64, 128, False),       # a single block tile, mostly padding
-    (5, 13, 50, 96, 128, False),     # three channel chunks, tiles that straddle images
-])
-def test_winograd_convolution_vs_float64(shape):
-    """The Winograd F(2x2, 3x3) form (conv_winograd.hip; off by default -- DESIGN.md: the numerics hold, the speed does not):
-    input transform, the sixteen split-bf16 GEMMs with the output transform in registers, and the direct kernels' epilogue
-    (bias, residual, ReLU, split records).  As close to float64 as the direct kernel, and a sample's rows do not depend on
-    the batch."""
-    lib = _lib.require_device()
-    B, H, W, Cin, Cout, use_res = shape
-    x = _rand(B, Cin, H, W, seed=41)
-    w = _rand(Cout, Cin, 3, 3, seed=42, scale=(2.0 / (Cin * 9)) ** 0.5)
-    b = _rand(Cout, seed=43, scale=0.1)
-    res = _rand(B, Cout, H, W, seed=44) if use_res else None
-    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    bd = b.to(DEV)
-    rd = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
-    out = {}
-    try:
-        for kind in (3, 4):
-            assert lib.d2t_op_set_conv_kernel(kind, 0) == 0
-            y = torch.full((B, H, W, Cout), float("nan"), device=DEV)
-            assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), B, H, W,
-                                                  Cin, Cout, 3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
-            out[kind] = y.cpu()
-        y1 = torch.full((1, H, W, Cout), float("nan"), device=DEV)
-        assert lib.d2t_op_conv2d_bf16x3_split(_lib.ptr(xd[B - 1:]), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd[B - 1:]) if use_res else None,
-                                              _lib.ptr(y1), 1, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1, 1, _lib.stream_of(xd)) == 0
-        torch.cuda.synchronize()
-    finally:
-        lib.d2t_op_set_conv_kernel(3, 0)
-    ref = _ref_conv(x, w, b, res, (1, 1), (1, 1), 1)
-    e_direct = float((out[3].permute(0, 3, 1, 2) - ref).abs().max())
-    e_wino = float((out[4].permute(0, 3, 1, 2) - ref).abs().max())
-    assert torch.isfinite(out[4]).all()
-    assert e_wino <= 4e-4 and e_wino <= 3 * e_direct + 1e-6, (e_direct, e_wino)
-    assert torch.equal(out[4][B - 1:], y1.cpu())
 
 
 @pytest.mark.parametrize("shape", [

@@ -564,24 +564,24 @@ def test_odd_crop_shapes_and_batch_sizes(manifests, cname, H, W, B, precision):
 
 
 @pytest.mark.parametrize("cname,H,W,B", [("T2", 48, 64, 3), ("T2", 45, 63, 2), ("T1", 63, 130, 2), ("C2", 128, 512, 2)])
-def test_fused_max_pools_equal_the_pool_kernels(monkeypatch, cname, H, W, B):
+def test_fused_max_pools_equal_the_pool_kernels(cname, H, W, B):
     """The two 2x2 / stride 2 max-pools of the backbone (resnet.py:94,106) run inside the epilogue of the convolution in
     front of them (pooled-order GEMM rows, ConvP::pool2).  Every pooled VALUE equals the separate pool kernel's
-    (D2T_NO_POOL_FUSION=1 at context creation): max and the fp32 -> (hi, lo) split are both monotone.  The stored record
+    (Model.conv_fusion = (False, True): d2t_set_conv_fusion): max and the fp32 -> (hi, lo) split are both monotone.  The stored record
     can differ in representation only -- where lo rounds up to the next hi step the pool kernel re-splits hi + lo as
     (hi', 0) while the fused epilogue keeps (hi, lo) -- which moves a consumer's products by the dropped lo*lo term
     (2^-16 relative) and, through the thirty layers behind it, every later value at that level: tokens equal, memory within
     1e-4 relative (a fifth of its bar against the oracle), logits within 5e-4 (the ResNet + TFM-2 stack amplifies a
-    2^-16 perturbation most: tools/winograd_study.py measures 5e-4 for the direct split-bf16 form itself there; the
+    2^-16 perturbation most: 5e-4 for the direct split-bf16 form itself there, docs/winograd_study_r03.txt; the
     pooled VALUES are asserted exactly equal at the op level, test_convolution_with_the_max_pool_fused).  Odd crop sizes (a last row / column that
     belongs to no window) included."""
     L = 6
     img = synth.synth_images(B, H, W, seed=4200 + H).cuda()
     text = torch.full((B, 1), R.GO, dtype=torch.long, device="cuda")
     outs = []
-    for off in ("0", "1"):
-        monkeypatch.setenv("D2T_NO_POOL_FUSION", off)
+    for fused in (True, False):
         cfg, m = engine_model(cname, L)
+        m.conv_fusion = (fused, True)
         with torch.no_grad():
             mem, _, _ = m.forward_encoder(img)
             p, l, _ = m(img, text, is_train=False)
@@ -595,18 +595,18 @@ def test_fused_max_pools_equal_the_pool_kernels(monkeypatch, cname, H, W, B):
 
 
 @pytest.mark.parametrize("cname,H,W,B", [("T2", 48, 64, 3), ("T1", 63, 130, 2), ("C2", 128, 512, 2)])
-def test_shortcut_inside_conv2_equals_the_separate_shortcut_kernel(monkeypatch, cname, H, W, B):
+def test_shortcut_inside_conv2_equals_the_separate_shortcut_kernel(cname, H, W, B):
     """A BasicBlock's 1x1 shortcut (resnet.py:181-192) runs inside its conv2's launch: K-steps over the block input appended
     behind the filter taps, weights concatenated along K, ONE accumulator (ConvP::in2_hi).  Against the path with its own
-    shortcut kernel and a residual add in the epilogue (D2T_NO_SHORTCUT_FUSION=1): the same sums in another order, and no
+    shortcut kernel and a residual add in the epilogue (Model.conv_fusion = (True, False)): the same sums in another order, and no
     rounding of the shortcut to a record in between -- tokens equal, memory within 1e-4 relative, logits within 5e-4."""
     L = 6
     img = synth.synth_images(B, H, W, seed=4300 + H).cuda()
     text = torch.full((B, 1), R.GO, dtype=torch.long, device="cuda")
     outs = []
-    for off in ("0", "1"):
-        monkeypatch.setenv("D2T_NO_SHORTCUT_FUSION", off)
+    for fused in (True, False):
         cfg, m = engine_model(cname, L)
+        m.conv_fusion = (True, fused)
         with torch.no_grad():
             mem, _, _ = m.forward_encoder(img)
             p, l, _ = m(img, text, is_train=False)

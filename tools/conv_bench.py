@@ -39,7 +39,7 @@ for name, B, H, W, Cin, Cout, k, st, pd, use_res in LAYERS:
     res = torch.randn(B, OH, OW, Cout, generator=g).cuda() if use_res else None
     outs = {}
     for rep in range(reps):
-        for kind, rc_ in [(0, 0)] + [(1, r) for r in reserves] + [(3, r) for r in reserves] + [(4, 0), (5, 0)]:
+        for kind, rc_ in [(0, 0)] + [(3, r) for r in reserves] + [(8, 0)]:
             assert lib.d2t_op_set_conv_kernel(kind, rc_) == 0
             y = torch.full((B, OH, OW, Cout), float("nan"), device="cuda")
             t0 = time.perf_counter()
@@ -51,7 +51,6 @@ for name, B, H, W, Cin, Cout, k, st, pd, use_res in LAYERS:
                 outs[(kind, rc_)] = y
     ref = outs[(0, 0)]
     assert torch.isfinite(ref).all()
-    same = {f"pipelined/reserve{r}": bool(torch.equal(outs[(1, r)], ref)) for r in reserves}
     # the 16x16x32 build sums 32 k inside one MFMA: equal to fp32 rounding, not bit for bit; against float64 both are equally close
     ref64 = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), st, pd)
     ref64 = ref64.permute(0, 2, 3, 1) + (res.double() if use_res else 0)
@@ -62,12 +61,12 @@ for name, B, H, W, Cin, Cout, k, st, pd, use_res in LAYERS:
         err[f"p16/reserve{r}"] = float((outs[(3, r)].double() - ref64).abs().max()) / scale
         assert torch.isfinite(outs[(3, r)]).all()
         assert err[f"p16/reserve{r}"] <= 3 * max(err["128x128"], 1e-7), (name, err)
-    assert torch.equal(outs[(5, 0)], outs[(3, reserves[0])]), f"{name}: the patch-resident 16x16x32 kernel must be bit-identical to the plain one"
-    err["winograd (3x3 s1 p1) / p16"] = float((outs[(4, 0)].double() - ref64).abs().max()) / scale
-    assert torch.isfinite(outs[(4, 0)]).all() and err["winograd (3x3 s1 p1) / p16"] <= 4 * max(err["128x128"], 1e-7), (name, err)
-    print(f"{name}: M={B * OH * OW} N={Cout} K={k[0] * k[1] * Cin}  bit-identical to the 128x128 kernel: {same}; "
+    for r in reserves[1:]:  # the grid (reserved CUs) never shows in the values
+        assert torch.equal(outs[(3, r)], outs[(3, reserves[0])]), name
+    err["fp16x2 / p16"] = float((outs[(8, 0)].double() - ref64).abs().max()) / scale
+    assert torch.isfinite(outs[(8, 0)]).all() and err["fp16x2 / p16"] <= 2e-3, (name, err)
+    print(f"{name}: M={B * OH * OW} N={Cout} K={k[0] * k[1] * Cin}  "
           f"max error / max |y| against float64: { {k_: f'{v:.2e}' for k_, v in err.items()} }", flush=True)
-    assert all(same.values()) or os.environ.get("D2T_CONV_ABL"), name
     if os.environ.get("D2T_CONV_ABL"):
         break  # ablation probes: the dominant shape only
 print("ok")

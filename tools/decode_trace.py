@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Debug timeline of ONE decode step loop running beside the encoders of the following batches (env D2T_DECODE_TRACE=1):
+"""Debug timeline of ONE decode step loop running beside the encoders of the following batches (probe build of the library,
+D2T_PROBES=1 bash doc2tex_amd/csrc/build.sh, selected with D2T_PROBE_LIB; env D2T_DECODE_TRACE=1):
 per kernel node of the captured loop, first block start / last block end (s_memrealtime, 10 ns ticks).
-usage: D2T_DECODE_TRACE=1 python tools/decode_trace.py [group] [conv_kernel] [encoders_alongside]"""
+usage: D2T_PROBE_LIB=doc2tex_amd/csrc/libd2t_probe.so D2T_DECODE_TRACE=1 python tools/decode_trace.py [group] [conv_kernel] [encoders_alongside]"""
 import ctypes as C
 import os
 import sys
@@ -12,11 +13,10 @@ import torch
 
 from doc2tex_amd import Model, _lib, synth
 
-if os.environ.get("D2T_PROBE_LIB"):  # a probe build of the library (D2T_PROBES=1, e.g. doc2tex_amd/csrc/libd2t_probe.so): phase-ablation switches
-    _lib.LIB_PATH = os.path.abspath(os.environ["D2T_PROBE_LIB"])
+_lib.LIB_PATH = os.path.abspath(os.environ.get("D2T_PROBE_LIB", "doc2tex_amd/csrc/libd2t_probe.so"))  # the trace needs a probe build
 
 group = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-kernel = sys.argv[2] if len(sys.argv) > 2 else "pipelined"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "pipelined16"
 alongside = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 cfg = synth.make_config("C2", device="cuda")
 m = Model(cfg)

@@ -12,7 +12,7 @@ from doc2tex_amd import _lib
 if os.environ.get("D2T_PROBE_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["D2T_PROBE_LIB"])
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-kind = int(sys.argv[2]) if len(sys.argv) > 2 else 3  # 3: pipelined 16x16x32, 6: band-resident
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 3  # 3: pipelined 16x16x32 (split-bf16), 8: the same in fp16x2 arithmetic
 lib = _lib.require_device()
 B, H, W, Cin, Cout = 64, 16, 129, 512, 512
 g = torch.Generator().manual_seed(0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How much of the 1e-3 logits bar does fp16x2 use?  Engine (fp16x2 and split-bf16) against the CPU oracle on fresh crops and
 fresh weight seeds, per config: max |dlogit| and whether the greedy tokens are exact.
-usage (GPU box): python tools/probe/fp16x2_margin.py [config:B:H:W:L:n_image_seeds:n_weight_seeds ...]"""
+usage (GPU box): [MARGIN_PRECS=bf16x3,fp16x2,mixed:4,mixed:8] python tools/probe/fp16x2_margin.py [config:B:H:W:L:n_image_seeds:n_weight_seeds ...]
+("mixed:N" = conv_precision 'mixed' with N units on the two-MFMA arithmetic)"""
 import json
 import os
 import sys
@@ -22,8 +23,10 @@ torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
 for spec in specs:
     name, B, H, W, L, ni, nw = spec.split(":")
     B, H, W, L, ni, nw = int(B), int(H), int(W), int(L), int(ni), int(nw)
-    worst = {"fp16x2": 0.0, "bf16x3": 0.0}
-    exact = {"fp16x2": True, "bf16x3": True}
+    PRECS = os.environ.get("MARGIN_PRECS", "fp16x2,bf16x3").split(",")
+    worst = {k: 0.0 for k in PRECS}
+    exact = {k: True for k in PRECS}
+    flips = {k: 0 for k in PRECS}
     for ws in range(nw):
         wseed = 1234 + 17 * ws
         cfg, m = engine_model(name, L, wseed, 0.0, beam_size=1)
@@ -34,12 +37,15 @@ for spec in specs:
             text = torch.full((B, 1), R.GO, dtype=torch.long)
             with torch.no_grad():
                 op, ol, _ = R.forward(ocfg, sd, img, text, is_test=False, faithful=False)
-                for prec in ("fp16x2", "bf16x3"):
-                    m.conv_precision = prec
+                for prec in PRECS:
+                    m.conv_precision = prec.split(":")[0]
+                    if ":" in prec:
+                        m.mixed_units = int(prec.split(":")[1])
                     p, l, _ = m(img.cuda(), text.cuda(), is_train=False)
                     d = float((l.cpu() - ol).abs().max())
                     worst[prec] = max(worst[prec], d)
                     exact[prec] &= bool(torch.equal(p.cpu(), op))
+                    flips[prec] += int(not torch.equal(p.cpu(), op))
                     print(f"  {name} wseed {wseed} image seed {9000 + 31 * k + ws} {prec}: max |dlogit| {d:.2e}, tokens exact {torch.equal(p.cpu(), op)}", flush=True)
-    print(f"{name} ({B}x{H}x{W}, {L + 1} steps, {ni} x {nw} runs): fp16x2 worst {worst['fp16x2']:.2e} (tokens exact {exact['fp16x2']}), "
-          f"bf16x3 worst {worst['bf16x3']:.2e} (tokens exact {exact['bf16x3']})", flush=True)
+    print(f"{name} ({B}x{H}x{W}, {L + 1} steps, {ni} x {nw} runs): " +
+          ", ".join(f"{k} worst {worst[k]:.2e} ({flips[k]} runs with a token flip)" for k in PRECS), flush=True)

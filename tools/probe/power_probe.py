@@ -8,7 +8,7 @@ g = torch.Generator().manual_seed(0)
 for name, make in (("random", lambda *s: torch.randn(*s, generator=g)), ("zeros", lambda *s: torch.zeros(*s))):
     x = make(B, H, W, Cin).cuda(); w = (make(Cout, 3, 3, Cin) * 0.02).cuda(); b = make(Cout).cuda()
     y = torch.empty(B, H, W, Cout, device="cuda")
-    assert lib.d2t_op_set_conv_kernel(1, 0) == 0
+    assert lib.d2t_op_set_conv_kernel(3, 0) == 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     # the op entry point repacks weights each call; time 40 back-to-back calls and report the mean of the last 20
     ts = []
