@@ -99,6 +99,9 @@ __device__ __forceinline__ int xcd_logical_tile() {
 // Epilogue of one wave's MI x NJ grid of 32x32 accumulators whose top-left output element is
 // (mw, nw): bias (folded BN), residual, activation, positional-table add, row / head-split remaps.
 // C/D map of v_mfma_*_32x32*: col = lane&31 -> n, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> m.
+// (Records here are bf16 hi | lo or, with ConvP::f16, one fp16: the 32x32 kernels never see the mixed-precision formats
+// ConvP::out_fmt / res_fmt -- launch_conv / launch_conv_bf16x3 reject them -- and the three-way format code costs the fp32
+// kernel, which runs at the VGPR limit, 700 bytes of scratch per lane and half its speed.)
 template <int MI, int NJ>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][NJ], int mw, int nw, int r, int h) {
 #pragma unroll
@@ -137,13 +140,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[MI][
         if (p.res) v += p.res[off];
         if (p.res_hi) {
           const size_t ri = plane_idx(row, n, p.Cout);
-          v += join_rec(p.res_hi[ri], p.res_hi[ri + 32], res_fmt(p));
+          v += p.f16 ? f16_bits_to_f32(p.res_hi[ri]) : bf16_bits_to_f32(p.res_hi[ri]) + bf16_bits_to_f32(p.res_hi[ri + 32]);
         }
         v = apply_act(v, p.act);
         if (p.row_add) v += p.row_add[(size_t)(p.row_add_off + in_img) * p.Cout + n];
         if (p.out_hi) {
           uint16_t hi, lo;
-          split_rec(v, hi, lo, out_fmt(p));
+          if (p.f16) { hi = f32_to_f16_bits(v); lo = 0; } else split_f32(v, hi, lo);
           const size_t oi = plane_idx(row, n, p.Cout);
           p.out_hi[oi] = hi;
           p.out_hi[oi + 32] = lo;

@@ -937,6 +937,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   }
 }
 
+#ifdef D2T_PROBES  // round 3's issue order of the two-row kernel, kept for A/B timing (D2T_DECODE_ROW2_NO_PREFETCH) in probe builds
 // ---------------------------------------------------------------------------------------------------------------------
 // The same step for TWO rows per block (greedy decode).  The five row GEMVs read 5 x 256 KB of weights per row, and with two
 // one-row blocks on a CU that is 2.56 MB through the CU's 64 B/clk L2 path per launch -- 18 of the kernel's 69 us (probe
@@ -1137,20 +1138,35 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_kernel(const Dec
   }
 }
 
+#endif  // D2T_PROBES
+
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 4: the two-row kernel with its memory latencies hidden.  rocprofv3 PMC of the kernel above at 384 rows
-// (profiles/r04_pmc_decode.txt): matrix pipes 12 % busy, L2 -> fabric 104 MB per launch = 1.7 TB/s, SQ_WAIT_ANY 49 % of the wave
-// cycles -- neither arithmetic nor bandwidth, but a serial chain of phases that each begin with an exposed round trip (a
-// K / V group of the cache, a GEMV's weight rows from L2, a memory tile of the cross-attention).  Same arithmetic per element
-// in the same order (results bit-identical to decoder_row2_absorbed_kernel), different issue order:
+// The row step for TWO rows per block (greedy decode; the shipped form since round 4).
+//
+// Two rows per block (round 3): the five row GEMVs read 5 x 256 KB of weights per row through the CU's 64 B/clk L2 path; the
+// block's 512 threads fetch every weight element ONCE and apply it to both rows' inputs (two accumulators, eight K groups of
+// 32), the absorbed-query product shares W_k the same way, and the attention phases run per row: waves 0-3 on row 2b, waves
+// 4-7 on row 2b + 1, each wave its own key tiles and 16 KB stage.  Per row the arithmetic and its order are those of
+// decoder_row_absorbed_kernel (K groups of 32 instead of 64 change the association: equal to fp32 rounding).  An odd row
+// count: the last block's second half repeats the last row and keeps its stores to itself -- the same kernel for EVERY row, so
+// a row's result never depends on how many rows share the launch.  156 KB of LDS: one block per CU.
+//
+// Issue order (round 4).  PMC of round 3's form at 384 rows (profiles/r04_pmc_decode.txt): matrix pipes 12 % busy, SQ_WAIT_ANY
+// 49 % of the wave cycles -- a serial chain of phases that each began with an exposed round trip.  Same arithmetic per element
+// in the same order (bit-identical results), but
 //   * a wave's FIRST memory tile is on its way (LDS-DMA) from the kernel's first instruction -- the staging area is idle until
 //     the cross-attention (the GEMV partials of the first two projections live in the absorbed queries' LDS instead);
 //   * inside the cross-attention the NEXT tile travels to registers (16 x 16 bytes per lane) while the matrix cores work on the
 //     current one, and moves to LDS when its reads are done: a tile costs max(arithmetic, round trip), not their sum;
 //   * a GEMV's weight rows (32 x 16 bytes per thread) are requested one phase early: W_o before the self-attention, W_q behind
-//     the W_o products, W_k behind the W_q products, W_v behind the cross-attention loop, W_co behind the W_v products;
+//     the W_o products, W_k behind the W_q products, W_v behind the cross-attention loop, W_co behind the W_v products; the
+//     element-wise phases' few global operands even earlier (the vector-memory counter retires in order);
 //   * the self-attention runs a wave's two heads in ONE loop (twice the K / V groups in flight per round trip);
 //   * block barriers are raw s_barrier behind lgkmcnt(0) (LDS only): a __syncthreads() fence would drain the prefetches.
+// Phase timeline at 384 rows, alone on the chip (probe build, tools/probe/row_phases.py; us per launch): entry .. self-attention
+// 21.3, five GEMVs 9.7, cross-attention 21.9 + 6.0 waiting for the slowest wave, element-wise 3.2 -- 62 in all (round 3: 64.4
+// -> 60.9 in the decode trace).  What is left is bandwidth, not latency: a launch streams 60 MB of K / V cache (HBM) and 102 MB
+// of memory rows (Infinity Cache) through 192 CUs at 24-30 GB/s each, the rate MI355X_MICROARCH.md measures for gathered rows.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifdef D2T_PROBES
 // probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
@@ -1574,10 +1590,12 @@ hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long 
   q.r.probe = probe;
   static const bool one_row = D2T_PROBE_ENV_STR("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
   if (r.anc && (!r.one_row || r.s_Lmax > ANC_MAX)) return hipErrorInvalidValue;  // the two-row kernel reads the cache directly
+  if (one_row || r.one_row) { hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q); return hipGetLastError(); }
+#ifdef D2T_PROBES
   static const bool no_pf = getenv("D2T_DECODE_ROW2_NO_PREFETCH") != nullptr;  // A/B: the round-3 issue order
-  if (one_row || r.one_row) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
-  else if (no_pf) hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
-  else hipLaunchKernelGGL(decoder_row2_absorbed_pf_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
+  if (no_pf) { hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q); return hipGetLastError(); }
+#endif
+  hipLaunchKernelGGL(decoder_row2_absorbed_pf_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
   return hipGetLastError();
 }
 

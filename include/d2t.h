@@ -251,7 +251,7 @@ int d2t_decode_attn_beam(d2t_ctx* ctx, const float* memory, int32_t T, int32_t b
  *                 of the logits grows with the square root of the number of two-MFMA layers (DESIGN.md section 3,
  *                 tools/probe/fp16x2_sim.py); d2t_set_mixed_units changes the count (0 .. 8; 0 = D2T_CONV_BF16X3). */
 enum { D2T_CONV_FP32 = 0, D2T_CONV_BF16X3 = 1, D2T_CONV_FP16X2 = 2, D2T_CONV_MIXED = 3 };
-#define D2T_MIXED_UNITS_DEFAULT 4
+#define D2T_MIXED_UNITS_DEFAULT 3
 int d2t_set_conv_precision(d2t_ctx* ctx, int32_t mode);
 int d2t_set_mixed_units(d2t_ctx* ctx, int32_t units);
 
