@@ -36,6 +36,7 @@ struct ConvW {
   uint16_t *w_h16 = nullptr, *w_l16 = nullptr;  // fp16 hi / lo of w for the fp16x2 kernels (ConvP::f16)
   float* bias = nullptr;
   int Cout = 0, Cin = 0, KH = 0, KW = 0;
+  int K2 = 0;  // K rows of a second (1x1) input concatenated behind the taps (Block::c2cat), else 0
 };
 struct LinW {
   const float* w = nullptr;
@@ -167,6 +168,7 @@ struct d2t_ctx {
   float* skv_alt = nullptr; size_t skv_alt_cap = 0;  // beam: reorder target (ping-pong with skv_cur)
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
   float* beam_ws = nullptr; size_t beam_ws_cap = 0;  // beam logits / scores / tokens / top-k
+  char* h_beam = nullptr; size_t h_beam_cap = 0;     // pinned host mirror of the device-side beam search's result block
   // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
   // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
   int beam_shared_tile = 0;

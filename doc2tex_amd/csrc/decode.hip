@@ -752,6 +752,7 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
   const DecRowP& p = q.r;
   if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
+  if (p.rows_ptr && (int)blockIdx.x >= *p.rows_ptr) return;        // device-side beam search: a dead row slot
   decode_wave_priority();
   TraceScope trace_(p.trace);
   // 77 KB: two blocks per CU.  The GEMV partial sums live in the (then idle) tile staging area, the merged context rows
@@ -1797,22 +1798,26 @@ hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
 // ---------------------------------------------------------------------------
 __global__ void embed_tokens_kernel(const float* __restrict__ emb, const float* __restrict__ pe,
                                     const int64_t* __restrict__ tok, const int* __restrict__ step_ptr,
-                                    float* __restrict__ x, int d, float sqrt_d) {
+                                    float* __restrict__ x, int d, float sqrt_d, const int* __restrict__ rows_ptr,
+                                    const int* __restrict__ stop) {
   const int b = blockIdx.x, t = *step_ptr;
+  if ((rows_ptr && b >= *rows_ptr) || (stop && *stop && t >= *stop)) return;
   const int64_t tk = tok[b];
   for (int c = threadIdx.x; c < d; c += blockDim.x)
     x[(size_t)b * d + c] = emb[(size_t)tk * d + c] * sqrt_d + pe[(size_t)t * d + c];
 }
 hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t* tok, const int* step_ptr, float* x,
-                               int M, int d, hipStream_t s) {
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(256), 0, s, emb, pe, tok, step_ptr, x, d, sqrtf((float)d));
+                               int M, int d, hipStream_t s, const int* rows_ptr, const int* stop) {
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(256), 0, s, emb, pe, tok, step_ptr, x, d, sqrtf((float)d), rows_ptr, stop);
   return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits,
                                                         const float* __restrict__ scores, int M, int V, int k,
                                                         float* __restrict__ topv, int* __restrict__ topi,
-                                                        const int* __restrict__ seg, int kmax) {
+                                                        const int* __restrict__ seg, int kmax,
+                                                        const int* __restrict__ step, const int* __restrict__ stop) {
+  if (stop && *stop && *step >= *stop) return;  // device-side beam loop: every sample has finished
   if (seg) {  // batched form: this block's segment of rows
     const int off = seg[blockIdx.x * 3];
     M = seg[blockIdx.x * 3 + 1];
@@ -1878,13 +1883,13 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
 hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
                             hipStream_t s) {
   if (M < 1 || M > 16 || k < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(256), 0, s, logits, scores, M, V, k, topv, topi, nullptr, 0);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(1), dim3(256), 0, s, logits, scores, M, V, k, topv, topi, nullptr, 0, nullptr, nullptr);
   return hipGetLastError();
 }
 hipError_t launch_beam_topk_batch(const float* logits, const float* scores, const int* seg, int N, int V, int kmax,
-                                  float* topv, int* topi, hipStream_t s) {
+                                  float* topv, int* topi, hipStream_t s, const int* step, const int* stop) {
   if (N < 1 || kmax < 1 || kmax > 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(N), dim3(256), 0, s, logits, scores, 0, V, 0, topv, topi, seg, kmax);
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(N), dim3(256), 0, s, logits, scores, 0, V, 0, topv, topi, seg, kmax, step, stop);
   return hipGetLastError();
 }
 
@@ -1911,10 +1916,12 @@ hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, in
 // (read from the host's step pack) the survivors inherit their parent's ancestry and add the parent's row for position
 // t - 1; the kernel also publishes t in the engine's step counter.  One block per row.
 __global__ void beam_ancestry_kernel(const int* __restrict__ anc_old, int* __restrict__ anc_new, const int* __restrict__ prev,
-                                     int stride, const int* __restrict__ step_in, int* __restrict__ step_out) {
+                                     int stride, const int* __restrict__ step_in, int* __restrict__ step_out,
+                                     const int* __restrict__ rows_ptr, const int* __restrict__ stop) {
   const int t = *step_in, row = blockIdx.x;
   if (row == 0 && threadIdx.x == 0) *step_out = t;
   if (!anc_new || t < 1) return;
+  if ((rows_ptr && row >= *rows_ptr) || (stop && *stop && t >= *stop)) return;
   const int p = prev[row];
   const int* src = anc_old + (size_t)p * stride;
   int* dst = anc_new + (size_t)row * stride;
@@ -1922,9 +1929,91 @@ __global__ void beam_ancestry_kernel(const int* __restrict__ anc_old, int* __res
   if (threadIdx.x == 0) dst[t - 1] = p;
 }
 hipError_t launch_beam_ancestry(const int* anc_old, int* anc_new, const int* prev, int rows, int stride, const int* step_in,
-                                int* step_out, hipStream_t s) {
+                                int* step_out, hipStream_t s, const int* rows_ptr, const int* stop) {
   if (rows < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(beam_ancestry_kernel, dim3(rows), dim3(64), 0, s, anc_old, anc_new, prev, stride, step_in, step_out);
+  hipLaunchKernelGGL(beam_ancestry_kernel, dim3(rows), dim3(64), 0, s, anc_old, anc_new, prev, stride, step_in, step_out, rows_ptr, stop);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-side beam bookkeeping (round 4): Beam.advance (tools/beam.py:68-105) for every sample of a batched beam search in ONE
+// single-block launch per step, so that the step loop needs no host round trip and can be captured as a graph.
+// Thread i owns sample i (i, i + 256, ...).  Pass 1: its `live` candidates in order -- prev = idx / V, word = idx % V; a
+// candidate ending in [s] joins the sample's completed set (step, parent row, score), the others become next step's
+// hypotheses; a sample with `beam` completed hypotheses is finished (Beam.done) and its rows drop out.  Pass 2: the samples'
+// new row counts are prefix-summed (rows stay compact, in sample order, as the host version kept them).  Pass 3: the new rows'
+// token / score / sample / parent, and the (parent, token) history record the host walks back through at the end.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_dev_init_kernel(const BeamDev b, long long go_token) {
+  for (int i = threadIdx.x; i < b.N; i += 256) {
+    b.seg[3 * i] = i; b.seg[3 * i + 1] = 1; b.seg[3 * i + 2] = b.beam;
+    b.tok[i] = go_token; b.scores[i] = 0.f; b.map[i] = i; b.prev[i] = i;
+    b.comp_n[i] = 0; b.fin[i] = 0;
+  }
+  if (threadIdx.x == 0) { b.ctrl[0] = 0; b.ctrl[1] = b.N; b.ctrl[2] = 0; b.ctrl[3] = 0; }
+}
+hipError_t launch_beam_dev_init(const BeamDev& b, int64_t go_token, hipStream_t s) {
+  hipLaunchKernelGGL(beam_dev_init_kernel, dim3(1), dim3(256), 0, s, b, (long long)go_token);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void beam_dev_advance_kernel(const BeamDev b) {
+  constexpr int KMAX = 16, SPT = 4;  // beam <= 16; up to 4 samples per thread (N <= 1024)
+  __shared__ int s_new[1024], s_off[1024];
+  const int t = b.ctrl[0];
+  if (b.ctrl[2] && t >= b.ctrl[2]) return;  // every sample finished at an earlier step
+  int n_par[SPT][KMAX], n_word[SPT][KMAX];
+  float n_val[SPT][KMAX];
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    if (i >= b.N) break;
+    int newM = 0;
+    if (!b.fin[i] && b.seg[3 * i + 1] > 0) {
+      const int off = b.seg[3 * i], live = b.seg[3 * i + 2];
+      int cn = b.comp_n[i];
+      for (int r = 0; r < live; ++r) {
+        const int idx = b.topi[(size_t)i * b.beam + r], prev = idx / b.V, word = idx - prev * b.V;
+        const float val = b.topv[(size_t)i * b.beam + r];
+        if (word == b.end_token) {
+          b.comp_t[(size_t)i * b.beam + cn] = t; b.comp_par[(size_t)i * b.beam + cn] = off + prev; b.comp_score[(size_t)i * b.beam + cn] = val;
+          ++cn;
+        } else {
+          n_par[q][newM] = off + prev; n_word[q][newM] = word; n_val[q][newM] = val;
+          ++newM;
+        }
+      }
+      b.comp_n[i] = cn;
+      if (cn == b.beam) { b.fin[i] = 1; newM = 0; }
+    }
+    s_new[i] = newM;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // (N <= 1024 small integers: a serial scan is a microsecond)
+    int run = 0;
+    for (int i = 0; i < b.N; ++i) { s_off[i] = run; run += s_new[i]; }
+    b.ctrl[0] = t + 1;
+    b.ctrl[1] = run;
+    b.ctrl[3] = t + 1;
+    if (run == 0) b.ctrl[2] = t + 1;  // nothing left to extend: the remaining steps of the loop return at once
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    const int i = threadIdx.x + 256 * q;
+    if (i >= b.N) break;
+    const int off = s_off[i], newM = s_new[i];
+    for (int j = 0; j < newM; ++j) {
+      const int row = off + j;
+      b.tok[row] = n_word[q][j]; b.scores[row] = n_val[q][j]; b.map[row] = i; b.prev[row] = n_par[q][j];
+      b.hist_par[(size_t)t * b.cap + row] = n_par[q][j];
+      b.hist_tok[(size_t)t * b.cap + row] = n_word[q][j];
+    }
+    b.seg[3 * i] = off; b.seg[3 * i + 1] = newM; b.seg[3 * i + 2] = b.fin[i] ? 0 : b.beam - b.comp_n[i];
+  }
+}
+hipError_t launch_beam_dev_advance(const BeamDev& b, hipStream_t s) {
+  if (b.N < 1 || b.N > 1024 || b.beam < 1 || b.beam > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(beam_dev_advance_kernel, dim3(1), dim3(256), 0, s, b);
   return hipGetLastError();
 }
 

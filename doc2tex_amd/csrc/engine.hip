@@ -28,22 +28,34 @@ int pack_conv(d2t_ctx* c, const std::string& conv, const std::string& bn, ConvW*
   HIPCHK(c, launch_pack_conv(w->p, cb ? cb->p : nullptr, g ? g->p : nullptr, b ? b->p : nullptr, mu ? mu->p : nullptr,
                              var ? var->p : nullptr, 1e-5f, out->w, out->bias, out->Cout, out->Cin, out->KH, out->KW,
                              s));
+  out->w_h16 = out->w_l16 = nullptr;  // fp16 hi / lo planes: made on first use (f16_planes), only the two-MFMA modes read them
   if (out->Cin % 32 == 0) {  // bf16 hi/lo planes of the folded weights (bf16x3 kernel)
-    void *ph, *pl;
-    if ((rc = dev_alloc(c, &ph, w->numel * 2)) || (rc = dev_alloc(c, &pl, w->numel * 2))) return rc;
+    void *ph = nullptr, *pl = nullptr;
+    if ((rc = dev_alloc(c, &ph, w->numel * 2))) return rc;
     c->owned.push_back(ph);
+    if ((rc = dev_alloc(c, &pl, w->numel * 2))) return rc;
     c->owned.push_back(pl);
     out->w_hi = (uint16_t*)ph;
     out->w_lo = (uint16_t*)pl;
     HIPCHK(c, launch_split_bf16(out->w, out->w_hi, out->w_lo, w->numel, s));
-    void *qh, *ql;  // fp16 hi / lo planes (fp16x2 mode)
-    if ((rc = dev_alloc(c, &qh, w->numel * 2)) || (rc = dev_alloc(c, &ql, w->numel * 2))) return rc;
-    c->owned.push_back(qh);
-    c->owned.push_back(ql);
-    out->w_h16 = (uint16_t*)qh;
-    out->w_l16 = (uint16_t*)ql;
-    HIPCHK(c, launch_split_f16(out->w, out->w_h16, out->w_l16, w->numel, s));
   }
+  return D2T_OK;
+}
+// fp16 hi / lo planes of a packed convolution weight (fp16x2 / mixed precision), created the first time a launch needs them:
+// contexts that never leave split-bf16 (the default; training; fp32) do not pay their memory
+int f16_planes(d2t_ctx* c, ConvW& w, hipStream_t s) {
+  if (w.w_h16) return D2T_OK;
+  if (!w.w || w.Cin % 32) return fail(c, D2T_ESTATE, "no fp16 planes for this layer");
+  const size_t n = (size_t)w.Cout * w.KH * w.KW * w.Cin + (size_t)w.Cout * w.K2;
+  void *qh = nullptr, *ql = nullptr;
+  int rc;
+  if ((rc = dev_alloc(c, &qh, n * 2))) return rc;
+  c->owned.push_back(qh);
+  if ((rc = dev_alloc(c, &ql, n * 2))) return rc;
+  c->owned.push_back(ql);
+  HIPCHK(c, launch_split_f16(w.w, (uint16_t*)qh, (uint16_t*)ql, n, s));
+  w.w_h16 = (uint16_t*)qh;
+  w.w_l16 = (uint16_t*)ql;
   return D2T_OK;
 }
 int get_lin(d2t_ctx* c, const std::string& k, LinW* out, int N, int K, bool bias = true) {
@@ -124,7 +136,7 @@ Act conv(d2t_ctx* c, hipStream_t s, hipError_t* err, const Act& x, const ConvW& 
   if (c->conv_bf16x3) { p.w_hi = w.w_hi; p.w_lo = w.w_lo; }
   if (x.split) { p.in_hi = x.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = x.p; }
   if (x.split && x.fmt != 0) {  // fp16 records in: the two-MFMA kernels (x16 * w_lo + x16 * w_hi), fp16 hi / lo weight planes
-    if (!w.w_h16) { if (*err == hipSuccess) *err = hipErrorInvalidValue; return y; }
+    if (f16_planes(c, const_cast<ConvW&>(w), s) != D2T_OK) { if (*err == hipSuccess) *err = hipErrorOutOfMemory; return y; }  // (w lives in *c)
     p.f16 = 1;
     p.w_hi = w.w_h16; p.w_lo = w.w_l16;
   }
@@ -415,6 +427,7 @@ void d2t_destroy(d2t_ctx* c) {
   if (c->skv) hipFree(c->skv);
   if (c->skv_alt) hipFree(c->skv_alt);
   if (c->beam_ws) hipFree(c->beam_ws);
+  if (c->h_beam) hipHostFree(c->h_beam);
   if (c->beam_qp) hipFree(c->beam_qp);
   if (c->dws) hipFree(c->dws);
   if (c->dstate) hipFree(c->dstate);
@@ -509,21 +522,22 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
         if (b.c2.w_hi && b.down.w_hi && b.down.KH == 1 && b.down.KW == 1 && b.down.Cout == b.c2.Cout) {
           // conv2 | shortcut concatenated along K (both already folded and in the kernels' K order: a 1x1 layer's is plain)
           const int Co = b.c2.Cout, K2 = b.c2.KH * b.c2.KW * b.c2.Cin, Kd = b.down.Cin;
-          void *pw, *pb, *ph, *pl, *qh, *ql;
+          void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
           const size_t n = (size_t)Co * (K2 + Kd);
-          if ((rc = dev_alloc(c, &pw, n * 4)) || (rc = dev_alloc(c, &pb, (size_t)Co * 4)) || (rc = dev_alloc(c, &ph, n * 2)) ||
-              (rc = dev_alloc(c, &pl, n * 2)) || (rc = dev_alloc(c, &qh, n * 2)) || (rc = dev_alloc(c, &ql, n * 2)))
-            return rc;
-          for (void* q : {pw, pb, ph, pl, qh, ql}) c->owned.push_back(q);
+          const size_t bytes[4] = {n * 4, (size_t)Co * 4, n * 2, n * 2};
+          for (int q = 0; q < 4; ++q) {  // (each buffer is owned as soon as it exists: nothing leaks when a later one fails)
+            if ((rc = dev_alloc(c, &bufs[q], bytes[q]))) return rc;
+            c->owned.push_back(bufs[q]);
+          }
+          void *pw = bufs[0], *pb = bufs[1], *ph = bufs[2], *pl = bufs[3];
           b.c2cat = b.c2;
           b.c2cat.w = (float*)pw; b.c2cat.bias = (float*)pb; b.c2cat.w_hi = (uint16_t*)ph; b.c2cat.w_lo = (uint16_t*)pl;
-          b.c2cat.w_h16 = (uint16_t*)qh; b.c2cat.w_l16 = (uint16_t*)ql;
+          b.c2cat.w_h16 = b.c2cat.w_l16 = nullptr; b.c2cat.K2 = Kd;  // (K2: the K rows of the second, 1x1 input)
           HIPCHK(c, hipMemcpy2DAsync(pw, (size_t)(K2 + Kd) * 4, b.c2.w, (size_t)K2 * 4, (size_t)K2 * 4, Co, hipMemcpyDeviceToDevice, s));
           HIPCHK(c, hipMemcpy2DAsync((float*)pw + K2, (size_t)(K2 + Kd) * 4, b.down.w, (size_t)Kd * 4, (size_t)Kd * 4, Co,
                                      hipMemcpyDeviceToDevice, s));
           HIPCHK(c, launch_add_rows(b.c2.bias, b.down.bias, b.c2cat.bias, Co, s));
           HIPCHK(c, launch_split_bf16(b.c2cat.w, b.c2cat.w_hi, b.c2cat.w_lo, n, s));
-          HIPCHK(c, launch_split_f16(b.c2cat.w, b.c2cat.w_h16, b.c2cat.w_l16, n, s));
         } else {
           b.c2cat.w = nullptr;
         }
@@ -930,7 +944,10 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.w = c->patch.w; p.bias = c->patch.bias; p.out = X;
     if (c->conv_bf16x3) { p.w_hi = c->patch.w_hi; p.w_lo = c->patch.w_lo; }
     if (f.split) { p.in_hi = f.planes(); p.zero16 = c->zero_page; p.max_blocks = c->conv_max_blocks; } else { p.in = f.p; }
-    if (f.split && f.fmt != 0 && c->patch.w_h16) { p.f16 = 1; p.w_hi = c->patch.w_h16; p.w_lo = c->patch.w_l16; }  // fp16 records from the backbone
+    if (f.split && f.fmt != 0) {  // fp16 records from the backbone
+      if ((rc = f16_planes(c, c->patch, s))) return rc;
+      p.f16 = 1; p.w_hi = c->patch.w_h16; p.w_lo = c->patch.w_l16;
+    }
     p.pipelined = c->conv_pipelined; p.reserved_cus = c->reserved_cus; p.split_tail = !c->decode_in_flight || D2T_PROBE_ENV("D2T_CONV_TAIL_ALWAYS");
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
@@ -1064,7 +1081,7 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
 hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int T, int kvB, bool shared_mem,
                        float* logits, long long logit_row_stride, long long logit_step_stride, int ckvB = -1,
                        const int* row_map = nullptr, const int* stop = nullptr, int beam = 0, const int* seg = nullptr,
-                       const int* anc = nullptr) {
+                       const int* anc = nullptr, const int* rows_ptr = nullptr) {
   const d2t_config& g = c->cfg;
   const int d = g.dec_dim, heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   const int* step = c->dstate;
@@ -1094,6 +1111,7 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     r.trace = trace_slot(c);
     r.stop_at = stop;
     r.anc = anc; r.anc_stride = Lmax; r.one_row = beam > 0;
+    r.rows_ptr = rows_ptr;
     if (c->dec_absorbed && c->beam_shared_tile && beam > 0 && beam <= 6 && c->beam_qp && (shared_mem || row_map))
       TRY(launch_decoder_row_beam(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, c->beam_qp,
                                   c->beam_qp + (size_t)kvB * 8 * d, seg, shared_mem ? 1 : ckvB, s));
@@ -1754,6 +1772,167 @@ int d2t_decode_wait_ticket(d2t_ctx* c, int64_t ticket, d2t_stream stream, int32_
   return D2T_OK;
 }
 
+
+namespace {
+// forward_beam (tfm.py:145-186) + Beam (tools/beam.py:38-140) for N samples with the bookkeeping ON THE DEVICE (round 4):
+// the hypotheses of all samples are rows of one step loop, every kernel of a step is launched for the full N x beam row slots
+// and reads the live row count / the stop step from the state block (kernels.h BeamDev), beam_dev_advance_kernel does
+// Beam.advance for every sample after the per-sample top-k -- no host round trip in the loop, which is therefore ONE captured
+// graph per (N, T, beam).  The host walks the (parent, token) history back once at the end.  Needs the absorbed row kernel
+// with ancestry rows (no cache copy).  Row results are those of the host-side loop bit for bit (same kernels per row).
+int beam_device_impl(d2t_ctx* c, const float* memory, int N, int T, int beam_size, int64_t* seq_out, int32_t* len_out,
+                     float* score_out, hipStream_t user) {
+  const d2t_config& g = c->cfg;
+  const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = N * beam_size, Lmax = g.max_seq_len + 2;
+  if (N > 1024) return fail(c, D2T_EINVAL, "batched beam search takes at most 1024 samples per call");
+  select_chain(c, 0);
+  hipStream_t s = c->dstream;
+  DecBufs bf;
+  int rc = dec_prepare(c, cap, T, &bf);
+  if (rc) return rc;
+  // workspace (4-byte words unless noted): logits [cap][V] | topv [cap] | topi [cap] | tok [cap] i64 | scores | map | prev [cap]
+  // | seg [N][3] | ctrl [8] | comp_n, fin [N] | comp_t, comp_par, comp_score [N][beam] | hist_par, hist_tok [S][cap] | anc [2][cap][Lmax]
+  size_t w = 0;
+  auto take = [&](size_t words) { const size_t at = w; w += (words + 3) & ~(size_t)3; return at; };
+  const size_t o_logits = take((size_t)cap * V), o_topv = take(cap), o_topi = take(cap), o_tok = take(2 * (size_t)cap);
+  const size_t o_res = w;  // ---- from here to o_anc: the block copied back to the host at the end ----
+  const size_t o_scores = take(cap), o_seg = take(3 * (size_t)N), o_ctrl = take(8), o_compn = take(N), o_fin = take(N);
+  const size_t o_ct = take(cap), o_cp = take(cap), o_cs = take(cap), o_hp = take((size_t)S * cap), o_ht = take((size_t)S * cap);
+  const size_t o_map = take(cap), o_prev = take(cap);
+  const size_t res_words = o_map - o_res;
+  const size_t o_anc = take(2 * (size_t)cap * Lmax);
+  if ((rc = ensure(c, &c->beam_ws, &c->beam_ws_cap, w * 4 + 64))) return rc;
+  float* base = c->beam_ws;
+  float* d_logits = base + o_logits;
+  BeamDev b{};
+  b.ctrl = reinterpret_cast<int*>(base + o_ctrl);
+  b.tok = reinterpret_cast<int64_t*>(base + o_tok);
+  b.scores = base + o_scores;
+  b.map = reinterpret_cast<int*>(base + o_map);
+  b.prev = reinterpret_cast<int*>(base + o_prev);
+  b.seg = reinterpret_cast<int*>(base + o_seg);
+  b.comp_n = reinterpret_cast<int*>(base + o_compn);
+  b.fin = reinterpret_cast<int*>(base + o_fin);
+  b.comp_t = reinterpret_cast<int*>(base + o_ct);
+  b.comp_par = reinterpret_cast<int*>(base + o_cp);
+  b.comp_score = base + o_cs;
+  b.hist_par = reinterpret_cast<int*>(base + o_hp);
+  b.hist_tok = reinterpret_cast<int*>(base + o_ht);
+  b.topv = base + o_topv;
+  b.topi = reinterpret_cast<const int*>(base + o_topi);
+  b.N = N; b.beam = beam_size; b.cap = cap; b.V = V; b.S = S; b.end_token = TOK_END;
+  int* d_anc[2] = {reinterpret_cast<int*>(base + o_anc), reinterpret_cast<int*>(base + o_anc) + (size_t)cap * Lmax};
+  const int* rows_ptr = b.ctrl + 1;
+  const int* stop = b.ctrl + 2;
+  if (c->h_beam_cap < res_words * 4) {
+    if (c->h_beam) hipHostFree(c->h_beam);
+    c->h_beam = nullptr; c->h_beam_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_beam), res_words * 4, hipHostMallocDefault) != hipSuccess)
+      return fail(c, D2T_ENOMEM, "hipHostMalloc failed");
+    c->h_beam_cap = res_words * 4;
+  }
+  HIPCHK(c, hipEventRecord(c->ev_in, user));
+  HIPCHK(c, hipStreamWaitEvent(s, c->ev_in, 0));
+  c->ckv = c->ckv2[0];  // the internal stream is in order, so earlier decodes are done with the slot
+  HIPCHK(c, cross_kv(c, s, memory, N, T));
+  c->skv_cur = c->skv;
+  auto enqueue_loop = [&](hipStream_t st) -> hipError_t {
+    hipError_t e;
+#define LTRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    LTRY(hipMemsetAsync(c->dstate, 0, (size_t)(4 + cap) * 4, st));
+    LTRY(launch_beam_dev_init(b, TOK_GO, st));
+    for (int step = 0; step < S; ++step) {
+      LTRY(launch_beam_ancestry(d_anc[(step + 1) & 1], d_anc[step & 1], b.prev, cap, Lmax, b.ctrl, c->dstate, st, rows_ptr, stop));
+      LTRY(launch_embed_tokens(c->word_embed, c->word_pe, b.tok, c->dstate, bf.x, cap, d, st, rows_ptr, stop));
+      LTRY(decode_step(c, st, bf, cap, T, cap, false, d_logits, V, 0, N, b.map, stop, beam_size, b.seg, d_anc[step & 1], rows_ptr));
+      LTRY(launch_beam_topk_batch(d_logits, b.scores, b.seg, N, V, beam_size, base + o_topv, reinterpret_cast<int*>(base + o_topi), st,
+                                  c->dstate, stop));
+      LTRY(launch_beam_dev_advance(b, st));
+    }
+#undef LTRY
+    return hipSuccess;
+  };
+  const bool use_graph = D2T_PROBE_ENV_STR("D2T_NO_GRAPH") == nullptr;
+  if (use_graph) {
+    d2t_ctx::GraphKey k;
+    memset(&k, 0, sizeof k);
+    k.B = cap; k.T = T; k.steps = S; k.tok = nullptr; k.logits = base; k.ckv = c->ckv; k.dws = c->dws; k.skv = c->skv; k.dstate = c->dstate;
+    k.variant = 3 | ((long long)N << 8) | ((long long)beam_size << 40);  // (bits 0-1 = 3: the device-side beam loop)
+    hipGraphExec_t exec = nullptr;
+    for (size_t i = 0; i < c->graphs.size(); ++i)
+      if (memcmp(&k, &c->graphs[i].key, sizeof k) == 0) {
+        exec = c->graphs[i].exec;
+        if (i + 1 != c->graphs.size()) std::swap(c->graphs[i], c->graphs.back());
+        break;
+      }
+    if (!exec) {
+      hipGraph_t gr = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      hipError_t e = enqueue_loop(s);
+      hipError_t e2 = hipStreamEndCapture(s, &gr);
+      if (e != hipSuccess || e2 != hipSuccess) {
+        if (gr) hipGraphDestroy(gr);
+        return fail(c, D2T_EHIP, "beam graph capture: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+      }
+      e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
+      hipGraphDestroy(gr);
+      if (e != hipSuccess) return fail(c, D2T_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      if (c->graphs.size() >= 40) {
+        HIPCHK(c, sync_chains(c));
+        hipGraphExecDestroy(c->graphs.front().exec);
+        c->graphs.erase(c->graphs.begin());
+      }
+      c->graphs.push_back({k, exec});
+    }
+    HIPCHK(c, hipGraphLaunch(exec, s));
+  } else {
+    HIPCHK(c, enqueue_loop(s));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_beam, base + o_res, res_words * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  // ---- host: pick every sample's best hypothesis (beam.py:107-140) and walk its tokens back through the history ----
+  const char* hb = c->h_beam;
+  auto hw = [&](size_t off) { return reinterpret_cast<const int*>(hb + (off - o_res) * 4); };
+  const float* h_scores = reinterpret_cast<const float*>(hw(o_scores));
+  const int *h_seg = hw(o_seg), *h_ctrl = hw(o_ctrl), *h_compn = hw(o_compn), *h_ct = hw(o_ct), *h_cp = hw(o_cp);
+  const float* h_cs = reinterpret_cast<const float*>(hw(o_cs));
+  const int *h_hp = hw(o_hp), *h_ht = hw(o_ht);
+  const int steps_run = h_ctrl[3];
+  for (int i = 0; i < N; ++i) {
+    int64_t* out = seq_out + (size_t)i * S;
+    const int nc = h_compn[i];
+    int row, last_step, n;  // the hypothesis ends with the history record (last_step, row); n tokens are returned
+    float score;
+    if (nc > 0) {
+      int best = 0;
+      for (int j = 1; j < nc; ++j)
+        if ((double)h_cs[(size_t)i * beam_size + j] / (double)(h_ct[(size_t)i * beam_size + j] + 1) >
+            (double)h_cs[(size_t)i * beam_size + best] / (double)(h_ct[(size_t)i * beam_size + best] + 1))
+          best = j;
+      const int t = h_ct[(size_t)i * beam_size + best];
+      n = std::min(t + 1, S);
+      for (int j = 0; j < n; ++j) out[j] = TOK_PAD;
+      if (t < n) out[t] = TOK_END;
+      row = h_cp[(size_t)i * beam_size + best];
+      last_step = t - 1;
+      score = h_cs[(size_t)i * beam_size + best];
+    } else {  // Beam.set_hypothesis (beam.py:132-140): the first live hypothesis, padded to max_seq_len + 1
+      n = S;
+      for (int j = 0; j < n; ++j) out[j] = TOK_PAD;
+      if (h_seg[3 * i + 1] > 0) { row = h_seg[3 * i]; last_step = steps_run - 1; score = h_scores[row]; }
+      else { row = -1; last_step = -1; score = 0.f; }
+    }
+    for (int p = last_step; p >= 0 && row >= 0; --p) {
+      if (p < n) out[p] = h_ht[(size_t)p * cap + row];
+      row = h_hp[(size_t)p * cap + row];
+    }
+    len_out[i] = n;
+    score_out[i] = score;
+  }
+  return D2T_OK;
+}
+}  // namespace
+
 int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_size, int64_t* seq_out, int32_t* len_out,
                     float* score_out, d2t_stream stream) {
   DevGuard dg_(c);
@@ -1770,6 +1949,10 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = beam_size;
   const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   if ((long long)cap * V > 16 * 4096) return fail(c, D2T_EINVAL, "beam_size * vocab too large");
+  // the absorbed d_model-256 decoder: the device-side loop of the batched search with one sample (the same row kernels, so
+  // batched == per-sample bit for bit), one graph launch per call instead of ~4000 kernel launches and 151 host round trips
+  if (c->dec_absorbed && !c->beam_shared_tile && Lmax <= 512 && D2T_PROBE_ENV_STR("D2T_BEAM_HOST") == nullptr)
+    return beam_device_impl(c, memory, 1, T, beam_size, seq_out, len_out, score_out, (hipStream_t)stream);
   select_chain(c, 0);
   hipStream_t user = (hipStream_t)stream, s = c->dstream;
   DecBufs bf;
@@ -1895,6 +2078,8 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = N * beam_size;
   const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
   if ((long long)beam_size * V > 16 * 4096) return fail(c, D2T_EINVAL, "beam_size * vocab too large");
+  if (c->dec_absorbed && !c->beam_shared_tile && Lmax <= 512 && N <= 1024 && D2T_PROBE_ENV_STR("D2T_BEAM_HOST") == nullptr)
+    return beam_device_impl(c, memory, N, T, beam_size, seq_out, len_out, score_out, (hipStream_t)stream);
   select_chain(c, 0);
   hipStream_t user = (hipStream_t)stream, s = c->dstream;
   DecBufs bf;

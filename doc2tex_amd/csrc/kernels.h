@@ -244,6 +244,7 @@ struct DecRowP {
   // (launch_beam_ancestry); nullptr = every hypothesis owns its cache row.  one_row: one row per block (the faster form at
   // 5 x 128 hypothesis rows; also what keeps batched and per-sample beam search bit-identical)
   const int* anc; int anc_stride; int one_row;
+  const int* rows_ptr;                // optional (device-side beam search): blocks of rows >= *rows_ptr return at once
 };
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 // the same step with the cross-attention taken over the encoder memory itself (absorbed K / V projections, decode.hip):
@@ -284,18 +285,42 @@ hipError_t launch_argmax_embed(const ArgmaxP& p, hipStream_t s);
 // ---- beam search helpers (tools/beam.py semantics, one sample) ----
 // x[i] = emb[tok[i]]*sqrt(d) + pe[*step]
 hipError_t launch_embed_tokens(const float* emb, const float* pe, const int64_t* tok, const int* step_ptr, float* x,
-                               int M, int d, hipStream_t s);
+                               int M, int d, hipStream_t s, const int* rows_ptr = nullptr, const int* stop = nullptr);
 // cand[i*V+v] = score[i] + log_softmax(logits[i])[v]; the k best (value desc, flat index asc on ties)
 // are written to topv[k], topi[k].  One block; M*V <= 16 * 4096.
 hipError_t launch_beam_topk(const float* logits, const float* scores, int M, int V, int k, float* topv, int* topi,
                             hipStream_t s);
 // the same for N independent segments of rows: seg[i] = {first row, rows, k}; results at topv/topi[i * kmax ...]
 hipError_t launch_beam_topk_batch(const float* logits, const float* scores, const int* seg, int N, int V, int kmax,
-                                  float* topv, int* topi, hipStream_t s);
+                                  float* topv, int* topi, hipStream_t s, const int* step = nullptr, const int* stop = nullptr);
+// Device-side beam bookkeeping (round 4; tools/beam.py:68-105 without a host round trip).  State block `BeamDev`: every array lives
+// in engine memory; the step loop's kernels are launched for `cap` rows and read the live row count / the stop step from it.
+struct BeamDev {
+  int* ctrl;            // [0] step, [1] live rows, [2] stop-at step (0 = none), [3] steps run
+  int64_t* tok;         // [cap] last token of every live hypothesis row
+  float* scores;        // [cap]
+  int* map;             // [cap] sample of a row
+  int* prev;            // [cap] parent row (previous step's row order)
+  int* seg;             // [N][3] first row, live rows, candidates wanted (beam - completed)
+  int* comp_n;          // [N] completed hypotheses
+  int* fin;             // [N] sample finished (beam completed hypotheses)
+  int* comp_t;          // [N][beam] step at which a hypothesis completed
+  int* comp_par;        // [N][beam] its parent row (that step's row order)
+  float* comp_score;    // [N][beam]
+  int* hist_par;        // [S][cap] parent row of the hypothesis a step created at row r (the next step's row order)
+  int* hist_tok;        // [S][cap] its token
+  const float* topv; const int* topi;   // [N][beam] candidates of the step (launch_beam_topk_batch)
+  int N, beam, cap, V, S, end_token;
+};
+hipError_t launch_beam_dev_init(const BeamDev& b, int64_t go_token, hipStream_t s);
+hipError_t launch_beam_dev_advance(const BeamDev& b, hipStream_t s);
+// anc_new[row][0 .. t-2] = anc_old[prev[row]][...], anc_new[row][t-1] = prev[row] (t = *step_in, published to *step_out):
+// which cache row holds each earlier position of hypothesis `row`.  rows_ptr / stop (optional): the device-side beam loop's
+// guards -- rows >= *rows_ptr are skipped, and nothing happens once *stop != 0 and t >= *stop.
+hipError_t launch_beam_ancestry(const int* anc_old, int* anc_new, const int* prev, int rows, int stride, const int* step_in,
+                                int* step_out, hipStream_t s, const int* rows_ptr = nullptr, const int* stop = nullptr);
 // dst[slab][i][...] = src[slab][prev[i]][...] for the first `rows` positions of every head
 // (self-attention KV cache reorder after a beam step); caches are [slabs][cap][heads][Lmax][hd].
-hipError_t launch_beam_ancestry(const int* anc_old, int* anc_new, const int* prev, int rows, int stride, const int* step_in,
-                                int* step_out, hipStream_t s);
 hipError_t launch_cache_gather(const float* src, float* dst, const int* prev, int slabs, int cap, int M, int heads,
                                int Lmax, int hd, int rows, hipStream_t s);
 

@@ -93,3 +93,14 @@ class PrefetchLoader:
         if isinstance(y, torch.Tensor) and y.is_cuda:
             y.record_stream(cur)
         return y, target, names
+
+
+class LMDB_Dataset:
+    """Import shim (round 3 removed the LMDB reader: nothing in this image can pin it against the real format).  Code
+    that still says `from doc2tex_amd.data import LMDB_Dataset` gets a clear pointer instead of an AttributeError: the
+    reference's own reader (doc2tex/data/lmdb_dataset.py) needs py-lmdb and works unchanged in front of PrefetchLoader."""
+
+    def __init__(self, *args, **kwargs):
+        raise ImportError("doc2tex_amd.data.LMDB_Dataset was removed (DESIGN.md, out of scope: the on-disk format cannot be pinned "
+                          "here).  Use the reference's doc2tex.data.lmdb_dataset.LMDB_Dataset (needs py-lmdb) and wrap its "
+                          "DataLoader in doc2tex_amd.data.PrefetchLoader.")

@@ -61,3 +61,9 @@ def test_prefetch_loader_feeds_the_recognizer():
     assert [i for i, _ in seen] == list(range(6))
     for i, p in seen:
         assert torch.equal(p, ref[i])
+
+
+def test_lmdb_dataset_shim_names_the_replacement():
+    from doc2tex_amd.data import LMDB_Dataset
+    with pytest.raises(ImportError, match="PrefetchLoader"):
+        LMDB_Dataset("/nonexistent")
