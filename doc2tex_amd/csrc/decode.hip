@@ -1201,16 +1201,16 @@ __device__ __forceinline__ void gemv2_fma(const float4 (&w)[32], const float* in
 }
 
 // row_attention<32, U> for TWO heads of one row in one loop (per head the same keys per lane in the same order)
-template <int U>
+template <int U, int HD = 32>
 __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], const float* const (&Kc)[2], const float* const (&Vc)[2],
                                                  const float* const (&curk)[2], const float* const (&curv)[2], int t, int L,
                                                  float* const (&out)[2], int lane) {
-  constexpr int HD = 32, LPK = HD / 4, KPI = 64 / LPK;
+  constexpr int LPK = HD / 4, KPI = 64 / LPK;
   const int kig = lane / LPK, ch = lane % LPK;
   float4 q4[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) q4[h] = *reinterpret_cast<const float4*>(q[h] + ch * 4);
-  const float scale = 0.17677669529663687f;
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   const int nit = (L + KPI - 1) / KPI;
@@ -1222,8 +1222,8 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
       const int jj = j < L ? j : 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float* kr = jj == t ? curk[h] : Kc[h] + (size_t)jj * HD;
-        const float* vr = jj == t ? curv[h] : Vc[h] + (size_t)jj * HD;
+        const float* kr = (curk[h] && jj == t) ? curk[h] : Kc[h] + (size_t)jj * HD;
+        const float* vr = (curv[h] && jj == t) ? curv[h] : Vc[h] + (size_t)jj * HD;
         k4[h][u] = *reinterpret_cast<const float4*>(kr + ch * 4);
         v4[h][u] = *reinterpret_cast<const float4*>(vr + ch * 4);
       }
@@ -1782,11 +1782,143 @@ hipError_t launch_decoder_row_beam(const DecRowP& r, const float* mem, long long
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// decoder_row_kernel for TWO rows per block (round 4; d_model 512 = config C1's decoder).  rocprofv3 of C1's serving run: the
+// one-row kernel is 43 % of the kernel time at 62.8 us per launch, and a third of that is the three row GEMVs pulling 3 x 1 MB
+// of weights through the CU's 64 B/clk L2 path for ONE row.  Here the block's 512 threads fetch every weight element once and
+// apply it to both rows' inputs (two accumulators; the same K groups of D / 4 in the same order: per row bit-identical to the
+// one-row kernel), and each wave runs ITS head of both rows in one attention loop (twice the K / V groups in flight per round
+// trip, row_attention_2h).  An odd row count: the last block's second half repeats the last row and keeps its stores to itself.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int HD>
+__global__ __launch_bounds__(512, 1) void decoder_row2_kernel(const DecRowP p) {
+  constexpr int NTH = 512, LPR = D / 4, G = NTH / LPR, KG = D / G;
+  static_assert(D / HD == 8 && NTH / 64 == 8, "one wave per head");
+  if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
+  decode_wave_priority();
+  TraceScope trace_(p.trace);
+  __shared__ __attribute__((aligned(16))) float a_s[2][D], y_s[2][D], x1_s[2][D], q2_s[2][D], part_s[2][G * D];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int t = *p.step_ptr;
+  int b[2];
+  bool valid[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    valid[r] = 2 * (int)blockIdx.x + r < p.M;
+    b[r] = valid[r] ? 2 * blockIdx.x + r : p.M - 1;
+  }
+  // one GEMV for both rows: thread (lr, g) -> columns 4 lr .. 4 lr + 3, k in [g KG, (g + 1) KG)
+  auto gemv2 = [&](const float* in0, const float* in1, const float* __restrict__ Wt) {
+    const int lr = tid % LPR, g = tid / LPR;
+    const float* w = Wt + (size_t)(g * KG) * D + lr * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll 16
+    for (int k = 0; k < KG; ++k) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * D);
+      const float x0 = in0[g * KG + k], x1 = in1[g * KG + k];
+      a0.x = fmaf(x0, w4.x, a0.x); a0.y = fmaf(x0, w4.y, a0.y); a0.z = fmaf(x0, w4.z, a0.z); a0.w = fmaf(x0, w4.w, a0.w);
+      a1.x = fmaf(x1, w4.x, a1.x); a1.y = fmaf(x1, w4.y, a1.y); a1.z = fmaf(x1, w4.z, a1.z); a1.w = fmaf(x1, w4.w, a1.w);
+    }
+    *reinterpret_cast<float4*>(part_s[0] + g * D + lr * 4) = a0;
+    *reinterpret_cast<float4*>(part_s[1] + g * D + lr * 4) = a1;
+  };
+  // ---- self-attention: wave = head, both rows in one loop ----
+  {
+    const int head = wave;
+    const float *qh[2], *Kh[2], *Vh[2], *ck[2], *cv[2];
+    float* oh[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float* qkv = p.qkv + (size_t)b[r] * p.qkv_stride;
+      float* Kc = p.sk + (size_t)b[r] * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      float* Vc = p.sv + (size_t)b[r] * p.s_batch_stride + (size_t)head * p.s_Lmax * HD;
+      ck[r] = qkv + D + head * HD;
+      cv[r] = qkv + 2 * D + head * HD;
+      if (lane < HD && valid[r]) {
+        Kc[(size_t)t * HD + lane] = ck[r][lane];
+        Vc[(size_t)t * HD + lane] = cv[r][lane];
+      }
+      qh[r] = qkv + head * HD; Kh[r] = Kc; Vh[r] = Vc; oh[r] = a_s[r] + head * HD;
+    }
+    row_attention_2h<4, HD>(qh, Kh, Vh, ck, cv, t, t + 1, oh, lane);
+  }
+  __syncthreads();
+  gemv2(a_s[0], a_s[1], p.wo_t);
+  __syncthreads();
+  for (int i = tid; i < 2 * D; i += NTH) {
+    const int r = i / D, c = i % D;
+    float v = p.bo[c] + p.xres[(size_t)(r ? b[1] : b[0]) * D + c];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[r][g * D + c];
+    y_s[r][c] = v;
+  }
+  __syncthreads();
+  if (wave < 2) {  // LN1, two-pass, one wave per row
+    const int r = wave;
+    constexpr int V = D / 64;
+    float v[V], sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = y_s[r][i * 64 + lane]; sm += v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    const float mean = sm * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.f / sqrtf(q * (1.f / D) + p.eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = i * 64 + lane;
+      x1_s[r][c] = v[i] * rstd * p.ln1_g[c] + p.ln1_b[c];
+    }
+  }
+  __syncthreads();
+  gemv2(x1_s[0], x1_s[1], p.wq_t);
+  __syncthreads();
+  for (int i = tid; i < 2 * D; i += NTH) {
+    const int r = i / D, c = i % D;
+    float v = p.bq[c];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[r][g * D + c];
+    q2_s[r][c] = v;
+  }
+  __syncthreads();
+  // ---- cross-attention over the projected memory K / V: wave = head, both rows in one loop ----
+  {
+    const int head = wave;
+    const float *qh[2], *Kh[2], *Vh[2];
+    const float* none[2] = {nullptr, nullptr};
+    float* oh[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int cb = p.c_row_map ? p.c_row_map[b[r]] : b[r];
+      Kh[r] = p.ck + (size_t)cb * p.c_batch_stride + (size_t)head * p.T * HD;
+      Vh[r] = p.cv + (size_t)cb * p.c_batch_stride + (size_t)head * p.T * HD;
+      qh[r] = q2_s[r] + head * HD; oh[r] = a_s[r] + head * HD;
+    }
+    row_attention_2h<8, HD>(qh, Kh, Vh, none, none, -1, p.T, oh, lane);
+  }
+  __syncthreads();
+  gemv2(a_s[0], a_s[1], p.wco_t);
+  __syncthreads();
+  for (int i = tid; i < 2 * D; i += NTH) {
+    const int r = i / D, c = i % D;
+    float v = p.bco[c] + x1_s[r][c];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v += part_s[r][g * D + c];
+    if (r ? valid[1] : valid[0]) p.y2[(size_t)(r ? b[1] : b[0]) * D + c] = v;
+  }
+}
+
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s) {
   if (p.heads != 8) return hipErrorInvalidValue;
   const bool small = decode_small() != 0;
   if (p.D == 256 && small) hipLaunchKernelGGL((decoder_row_kernel<256, 32, 256>), dim3(p.M), dim3(256), 0, s, p);
   else if (p.D == 256) hipLaunchKernelGGL((decoder_row_kernel<256, 32, 512>), dim3(p.M), dim3(512), 0, s, p);
+  else if (p.D == 512 && !p.anc && !p.one_row && !D2T_PROBE_ENV_STR("D2T_DECODE_ONE_ROW_BLOCKS"))
+    hipLaunchKernelGGL((decoder_row2_kernel<512, 64>), dim3((p.M + 1) / 2), dim3(512), 0, s, p);
   else if (p.D == 512) hipLaunchKernelGGL((decoder_row_kernel<512, 64, 512>), dim3(p.M), dim3(512), 0, s, p);
   else return hipErrorInvalidValue;
   return hipGetLastError();
