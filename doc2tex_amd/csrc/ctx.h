@@ -169,6 +169,7 @@ struct d2t_ctx {
   float* skv_cur = nullptr;                          // cache decode_step reads / appends
   float* beam_ws = nullptr; size_t beam_ws_cap = 0;  // beam logits / scores / tokens / top-k
   char* h_beam = nullptr; size_t h_beam_cap = 0;     // pinned host mirror of the device-side beam search's result block
+  bool cross_fp32 = false;  // probe builds: the greedy decode's cross-attention on the fp32 MFMA instead of split-bf16
   // beam search: 1 = one cross-attention block per SAMPLE serving all its hypotheses from one staged memory tile
   // (d2t_set_beam_shared_tile; measured slower than one block per hypothesis row at 128 samples x 5: DESIGN.md 5.4), 0 = per row
   int beam_shared_tile = 0;

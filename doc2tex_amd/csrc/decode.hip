@@ -737,6 +737,10 @@ struct DecRow2P {
   // beam search (MODE 1 / 2): the row kernel split around the per-SAMPLE cross-attention kernel
   float* qp;            // [rows][8][D]: MODE 1 writes the absorbed queries, beam_cross_kernel replaces them with the context rows
   float* x1;            // [rows][D]: LN1 output (the residual of the cross-attention block), MODE 1 -> MODE 2
+  // round 4: the memory rows as two bf16 planes (hi = upper 16 bits, lo = bf16(x - hi); launch_split_bf16) for the greedy
+  // two-row kernel's split-bf16 cross-attention (nullptr: the fp32 rows above on the fp32 MFMA)
+  const uint16_t* mem_hi;   // [samples][T][D]
+  const uint16_t* mem_lo;   // [samples][T][D]
 };
 
 #ifdef D2T_PROBES
@@ -1169,16 +1173,6 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_kernel(const Dec
 // -> 60.9 in the decode trace).  What is left is bandwidth, not latency: a launch streams 60 MB of K / V cache (HBM) and 102 MB
 // of memory rows (Infinity Cache) through 192 CUs at 24-30 GB/s each, the rate MI355X_MICROARCH.md measures for gathered rows.
 // ---------------------------------------------------------------------------------------------------------------------
-#ifdef D2T_PROBES
-// probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
-__device__ unsigned long long d2t_row_phase[32];
-#define ROW_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
-    atomicAdd(&d2t_row_phase[k], now_ - phase_t_); phase_t_ = now_; } } while (0)
-#define ROW_PHASE_INIT() unsigned long long phase_t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_row_phase[31], 1ull)
-#else
-#define ROW_PHASE(k) do { } while (0)
-#define ROW_PHASE_INIT() do { } while (0)
-#endif
 #define ROW_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 // weight rows of one two-row GEMV: thread (lr = tid % 64, g = tid / 64) holds Wt[32 g + k][4 lr .. 4 lr + 3], k = 0 .. 31
@@ -1201,10 +1195,14 @@ __device__ __forceinline__ void gemv2_fma(const float4 (&w)[32], const float* in
 }
 
 // row_attention<32, U> for TWO heads of one row in one loop (per head the same keys per lane in the same order)
-template <int U, int HD = 32>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_first_issue` runs once, right behind the first iteration's K / V loads: the caller's own prefetches (first memory tile,
+// first GEMV's weight rows) then queue BEHIND those loads instead of in front of them, and their issue time is covered by the
+// first round trip (the vector-memory counter retires in order: what is issued first is awaited first)
+template <int U, int HD = 32, class Hook = NoHook>
 __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], const float* const (&Kc)[2], const float* const (&Vc)[2],
                                                  const float* const (&curk)[2], const float* const (&curv)[2], int t, int L,
-                                                 float* const (&out)[2], int lane) {
+                                                 float* const (&out)[2], int lane, Hook after_first_issue = Hook()) {
   constexpr int LPK = HD / 4, KPI = 64 / LPK;
   const int kig = lane / LPK, ch = lane % LPK;
   float4 q4[2];
@@ -1214,8 +1212,8 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   const int nit = (L + KPI - 1) / KPI;
-  for (int it0 = 0; it0 < nit; it0 += U) {
-    float4 k4[2][U], v4[2][U];
+  float4 k4[2][U], v4[2][U];
+  auto issue = [&](int it0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = (it0 + u) * KPI + kig;
@@ -1228,6 +1226,13 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
         v4[h][u] = *reinterpret_cast<const float4*>(vr + ch * 4);
       }
     }
+  };
+  issue(0);
+  __builtin_amdgcn_sched_barrier(0);
+  after_first_issue();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int it0 = 0; it0 < nit; it0 += U) {
+    if (it0 > 0) issue(it0);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1269,6 +1274,24 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
   }
 }
 
+#ifdef D2T_PROBES
+// probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
+__device__ unsigned long long d2t_row_phase[32];
+#define ROW_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_row_phase[k], now_ - phase_t_); phase_t_ = now_; } } while (0)
+#define ROW_PHASE_INIT() unsigned long long phase_t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_row_phase[31], 1ull)
+#else
+#define ROW_PHASE(k) do { } while (0)
+#define ROW_PHASE_INIT() do { } while (0)
+#endif
+#ifdef D2T_PROBES
+#define WAVE_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_row_phase[k], now_ - wave_t_); wave_t_ = now_; } } while (0)
+#define WAVE_PHASE_INIT() unsigned long long wave_t_ = __builtin_amdgcn_s_memrealtime()
+#else
+#define WAVE_PHASE(k) do { } while (0)
+#define WAVE_PHASE_INIT() do { } while (0)
+#endif
 // LDS-DMA of key tile `tile` of `mem` into a wave's 16 KB stage (the layout cross_absorbed_wave reads)
 __device__ __forceinline__ void cross_tile_dma(const float* __restrict__ mem, int T, int tile, unsigned char* stage, int lane) {
   const int j0 = tile << 4;
@@ -1277,6 +1300,138 @@ __device__ __forceinline__ void cross_tile_dma(const float* __restrict__ mem, in
     const int j = j0 + i < T ? j0 + i : T - 1;
     __builtin_amdgcn_global_load_lds(mem + (size_t)j * 256 + ((lane ^ i) << 2), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross-attention on split-bf16 MFMAs (round 4).  Inside the loop below the fp32-MFMA form is bound by the matrix pipe:
+// 128 v_mfma_f32_16x16x4_f32 per tile at 32 cycles, two waves per SIMD, and only 8 of the 16 columns (heads) of every tile
+// useful -- 15 of the loop's 28 us (probe build, tools/probe/row_phases.py).  The same products on the bf16 pipe, every fp32
+// operand as hi + lo (three MFMAs per product, lo*hi + hi*lo + hi*hi: the arithmetic of the encoder's GEMMs):
+//     S^T [16 keys x 16 (8 heads + 8 idle)] = M_tile [16 x 256] . Q'^T      8 K-steps x 3 v_mfma_f32_16x16x32_bf16   (24)
+//     ctx [16 (8 heads + 8 idle) x 256]    += P [16 x 16 keys] . M_tile     16 column blocks x 3 v_mfma_f32_16x16x16_bf16 (48)
+// 72 MFMAs of 16 cycles instead of 128 of 32.  The memory rows arrive as two bf16 planes (hi = upper 16 bits, lo = bf16(x - hi):
+// x to 16 significant bits; launch_split_bf16 at cross_kv time); a tile = 16 rows x 512 B of hi | 16 x 512 B of lo in the wave's
+// 16 KB stage, 16-byte chunk c of row r at position c ^ r (conflict-free ds_read_b128 of the score product's A operand; the
+// weighted sum's B operand [keys x channels] comes out of the same image with ds_read_b64_tr_b16).  The absorbed queries
+// are split the same way when they are stored.  The score product's result layout (lane = (key group, head), registers =
+// keys 4g..4g+3) is the A-operand layout of the 16x16x16 form, so P never moves between lanes, as before.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ds4 __attribute__((ext_vector_type(4)));
+typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ds4* lds_ds4_ptr;
+__device__ __forceinline__ void split16(float x, unsigned& hi, unsigned& lo) {  // hi = upper 16 bits, lo = bf16_rne(x - hi)
+  const unsigned u = __float_as_uint(x);
+  hi = u >> 16;
+  const __bf16 l = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
+  lo = *reinterpret_cast<const unsigned short*>(&l);
+}
+// global source of the 16 bytes lane `lane` holds of piece i (0..15) of tile `tile`: pieces 0-7 = two hi rows each, 8-15 = lo
+__device__ __forceinline__ const uint16_t* bx3_piece_src(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
+                                                         int i, int lane) {
+  const int row = 2 * (i & 7) + (lane >> 5);
+  const int jr = (tile << 4) + row, j = jr < T ? jr : T - 1;  // rows past the end: a valid row, its probability is forced to zero
+  return (i < 8 ? mh : ml) + (size_t)j * 256 + (((lane & 31) ^ row) << 3);
+}
+__device__ __forceinline__ void bx3_tile_dma(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
+                                             unsigned char* stage, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    __builtin_amdgcn_global_load_lds(bx3_piece_src(mh, ml, T, tile, i, lane), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
+}
+// this wave's share of the cross-attention of one query row: acc[cb][reg] = ctx[head 4 g + reg][channel 16 cb + col] (unnormalised)
+template <int NW>
+__device__ __forceinline__ void cross_absorbed_wave_bx3(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T,
+                                                        const unsigned char* qp_b, unsigned char* stage, int wave, int lane,
+                                                        float& m_run, float& l_run, f32x4 (&acc)[16]) {
+  const int col = lane & 15, g = lane >> 4, hrow = col & 7;
+  m_run = -INFINITY;
+  l_run = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < 16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 15) >> 4;
+  // transposing-read addresses of the weighted sum's B operand: lane 4 q' + p of a 16-lane group supplies row 4 g + q' of the
+  // block, channels 4 p .. 4 p + 3 of the column block; with the row's chunk swizzle: chunk (2 cb + (p >> 1)) ^ row
+  const int trow = 4 * g + ((lane & 15) >> 2), tp = lane & 3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile (issued at kernel entry) has landed
+  WAVE_PHASE_INIT();
+  for (int tile = wave; tile < ntiles; tile += NW) {
+    const int j0 = tile << 4;
+    const int nxt = tile + NW;
+    WAVE_PHASE(13);
+    du32x4 pf[16];
+    if (nxt < ntiles) {  // wave-uniform: the next tile travels to registers during this tile's arithmetic
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pf[i] = *reinterpret_cast<const du32x4*>(bx3_piece_src(mh, ml, T, nxt, i, lane));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pf[i] = du32x4{0u, 0u, 0u, 0u};
+    }
+    WAVE_PHASE(14);
+    // ---- S^T[key = 4 g' + reg][head = col]: A = tile rows (key = col), B = absorbed queries (head = col & 7) ----
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int ch = 4 * ks + g;  // logical 16-byte chunk (8 channels) of this lane's k-group
+      const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(stage + col * 512 + ((ch ^ col) << 4));
+      const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(stage + 8192 + col * 512 + ((ch ^ col) << 4));
+      const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(qp_b + hrow * 512 + ((ch ^ hrow) << 4));
+      const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(qp_b + 4096 + hrow * 512 + ((ch ^ hrow) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sacc, 0, 0, 0);
+    }
+    // ---- online softmax: this lane holds keys j0 + 4 g + reg of head `col` ----
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
+      mx = fmaxf(mx, sv[reg]);
+    }
+    WAVE_PHASE(15);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // a tile holds at least one valid key: finite
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 for the first tile
+    float ps = 0.f;
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float pv = expf(sv[reg] - m_new);  // exp(-inf) = 0 for keys past the end
+      ps += pv;
+      split16(pv, ph[reg], pl[reg]);
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    float ar[4];  // the accumulators hold ctx[head = 4 g + reg][...]: their scale is the alpha of THAT head (lane 4 g + reg has it)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ar[reg] = __shfl(alpha, 4 * g + reg, 64);
+#pragma unroll
+    for (int cb = 0; cb < 16; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[cb][reg] *= ar[reg];
+    const ds4 pah = {(short)ph[0], (short)ph[1], (short)ph[2], (short)ph[3]}, pal = {(short)pl[0], (short)pl[1], (short)pl[2], (short)pl[3]};
+    WAVE_PHASE(16);
+    // ---- ctx[head][16 cb + col] += sum_keys P[head][key] m[key][channel]: A = P (head = col, keys 4 g .. 4 g + 3), B by transposing reads ----
+#pragma unroll
+    for (int cb = 0; cb < 16; ++cb) {
+      const int off = trow * 512 + (((2 * cb + (tp >> 1)) ^ trow) << 4) + (tp & 1) * 8;
+      const ds4 bh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + off));
+      const ds4 bl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + 8192 + off));
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pal, bh, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bl, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bh, acc[cb], 0, 0, 0);
+    }
+    WAVE_PHASE(17);
+    if (nxt < ntiles) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads have returned: the stage may be overwritten
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<du32x4*>(stage + i * 1024 + lane * 16) = pf[i];
+    }
+    WAVE_PHASE(18);
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
 }
 
 // cross_absorbed_wave<NW> with the tile stream pipelined: the wave's first tile was started with cross_tile_dma long before;
@@ -1294,9 +1449,11 @@ __device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__
     for (int e = 0; e < 4; ++e) acc[w][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (T + 15) >> 4;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile (issued at kernel entry) has landed
+  WAVE_PHASE_INIT();
   for (int tile = wave; tile < ntiles; tile += NW) {
     const int j0 = tile << 4;
     const int nxt = tile + NW;
+    WAVE_PHASE(13);
     f32x4 pf[16];
     if (nxt < ntiles) {  // wave-uniform
 #pragma unroll
@@ -1308,6 +1465,7 @@ __device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < 16; ++i) pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    WAVE_PHASE(14);
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -1324,6 +1482,7 @@ __device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__
       sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
       mx = fmaxf(mx, sv[reg]);
     }
+    WAVE_PHASE(15);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
@@ -1345,6 +1504,7 @@ __device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) acc[w][e][reg] *= ar[reg];
+    WAVE_PHASE(16);
 #pragma unroll
     for (int sk = 0; sk < 4; ++sk) {
       const int key = 4 * g + sk;
@@ -1357,17 +1517,20 @@ __device__ __forceinline__ void cross_absorbed_wave_pf(const float* __restrict__
         acc[w][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[sk], b4.w, acc[w][3], 0, 0, 0);
       }
     }
+    WAVE_PHASE(17);
     if (nxt < ntiles) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads have returned: the stage may be overwritten
 #pragma unroll
       for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(stage + i * 1024 + lane * 16) = pf[i];
     }
+    WAVE_PHASE(18);
   }
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
 }
 
-__global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const DecRow2P q) {
+template <bool BX3>  // BX3: the cross-attention on split-bf16 MFMAs over DecRow2P::mem_hi / mem_lo (cross_absorbed_wave_bx3)
+__device__ __forceinline__ void decoder_row2_absorbed_pf_body(const DecRow2P& q) {
   constexpr int D = 256, HD = 32, G = 8;
   const DecRowP& p = q.r;
   if (p.stop_at && *p.stop_at && *p.step_ptr >= *p.stop_at) return;  // block-uniform
@@ -1393,7 +1556,8 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const 
   const int cb = p.c_row_map ? p.c_row_map[b] : b;
   const float* const mem = q.mem + (size_t)cb * q.mem_stride;
   unsigned char* const stage = stage_s + wave * 16384;
-  if (w4i < ((p.T + 15) >> 4)) cross_tile_dma(mem, p.T, w4i, stage, lane);
+  const uint16_t* const mh = BX3 ? q.mem_hi + (size_t)cb * q.mem_stride : nullptr;
+  const uint16_t* const ml = BX3 ? q.mem_lo + (size_t)cb * q.mem_stride : nullptr;
   // the element-wise phases' few global operands, requested BEFORE the weight prefetches: the vector-memory counter retires in
   // order, so a small load issued behind a 256 KB prefetch would wait for all of it
   const float bo_v = p.bo[tcol] + p.xres[(size_t)brow * D + tcol], bq_v = p.bq[tcol], bv_v = q.bv[tcol], bco_v = p.bco[tcol];
@@ -1401,7 +1565,16 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const 
 #pragma unroll
   for (int i = 0; i < 4; ++i) { ln_g[i] = p.ln1_g[i * 64 + lane]; ln_b[i] = p.ln1_b[i * 64 + lane]; }
   float4 W[32];
-  gemv2_load(p.wo_t, gg, lr, W);
+  // this wave's first memory tile (LDS-DMA) and the first GEMV's weight rows: issued from inside the self-attention, right
+  // behind its first K / V loads (their 48 instructions' issue time -- ~100 ns each with the CU's vector-memory path busy --
+  // then passes under that first round trip instead of in front of it)
+  auto prefetch = [&]() {
+    if (w4i < ((p.T + 15) >> 4)) {
+      if constexpr (BX3) bx3_tile_dma(mh, ml, p.T, w4i, stage, lane);
+      else cross_tile_dma(mem, p.T, w4i, stage, lane);
+    }
+    gemv2_load(p.wo_t, gg, lr, W);
+  };
   // ---- self-attention over the cache, this wave's two heads in one loop ----
   {
     const float* qkv = p.qkv + (size_t)b * p.qkv_stride;
@@ -1420,7 +1593,7 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const 
       }
       qh[hp] = qkv + head * HD; Kh[hp] = Kc; Vh[hp] = Vc; oh[hp] = a_s[half] + head * HD;
     }
-    row_attention_2h<4>(qh, Kh, Vh, ck, cv, t, t + 1, oh, lane);
+    row_attention_2h<4, 32>(qh, Kh, Vh, ck, cv, t, t + 1, oh, lane, prefetch);
   }
   ROW_SYNC();
   ROW_PHASE(0);
@@ -1485,29 +1658,57 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const 
     const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
     float4 a0, a1;
     gemv2_fma(W, q2_s[0] + gg * HD, q2_s[1] + gg * HD, a0, a1);
-    const int o = gg * D + ((lr ^ gg) << 2);
-    *reinterpret_cast<float4*>(qp_s[0] + o) = make_float4(a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale);
-    *reinterpret_cast<float4*>(qp_s[1] + o) = make_float4(a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale);
+    if constexpr (BX3) {  // hi / lo bf16 planes: head gg's row of 512 B, 16-byte chunk (lr >> 1) ^ gg, its half lr & 1
+      const float v0[4] = {a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale}, v1[4] = {a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale};
+      const int ob = gg * 512 + (((lr >> 1) ^ gg) << 4) + (lr & 1) * 8;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split16(r ? v1[e] : v0[e], hi[e], lo[e]);
+        unsigned char* base = reinterpret_cast<unsigned char*>(qp_s[r]);
+        *reinterpret_cast<uint2*>(base + ob) = make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16);
+        *reinterpret_cast<uint2*>(base + 4096 + ob) = make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);
+      }
+    } else {
+      const int o = gg * D + ((lr ^ gg) << 2);
+      *reinterpret_cast<float4*>(qp_s[0] + o) = make_float4(a0.x * scale, a0.y * scale, a0.z * scale, a0.w * scale);
+      *reinterpret_cast<float4*>(qp_s[1] + o) = make_float4(a1.x * scale, a1.y * scale, a1.z * scale, a1.w * scale);
+    }
   }
   ROW_SYNC();
   ROW_PHASE(6);
   // ---- cross-attention over the memory rows of each row's sample: four waves per row ----
   {
     float m_run, l_run;
-    f32x4 acc[4][4];
-    cross_absorbed_wave_pf<4>(mem, p.T, qp_s[half], stage, w4i, lane, m_run, l_run, acc);
-    ROW_PHASE(12);
     const int col = lane & 15, g = lane >> 4;
-    if (g == 0 && col < 8) { wm_s[half][w4i][col] = m_run; wl_s[half][w4i][col] = l_run; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* mine = reinterpret_cast<float*>(stage);
-    if (g < 2) {
+    if constexpr (BX3) {
+      f32x4 acc[16];
+      cross_absorbed_wave_bx3<4>(mh, ml, p.T, reinterpret_cast<const unsigned char*>(qp_s[half]), stage, w4i, lane, m_run, l_run, acc);
+      ROW_PHASE(12);
+      if (g == 0 && col < 8) { wm_s[half][w4i][col] = m_run; wl_s[half][w4i][col] = l_run; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (g < 2) {  // acc[cb][reg] = ctx[head 4 g + reg][channel 16 cb + col]
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+        for (int cb = 0; cb < 16; ++cb)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
-              make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+          for (int reg = 0; reg < 4; ++reg) mine[(4 * g + reg) * D + 16 * cb + col] = acc[cb][reg];
+      }
+    } else {
+      f32x4 acc[4][4];
+      cross_absorbed_wave_pf<4>(mem, p.T, qp_s[half], stage, w4i, lane, m_run, l_run, acc);
+      ROW_PHASE(12);
+      if (g == 0 && col < 8) { wm_s[half][w4i][col] = m_run; wl_s[half][w4i][col] = l_run; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (g < 2) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
+                make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+      }
     }
   }
   gemv2_load(q.wv_t, gg, lr, W);  // value projection's rows: on their way during the merge
@@ -1570,6 +1771,9 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const 
   ROW_PHASE(20);
 }
 
+__global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_pf_kernel(const DecRow2P q) { decoder_row2_absorbed_pf_body<false>(q); }
+__global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_bx3_kernel(const DecRow2P q) { decoder_row2_absorbed_pf_body<true>(q); }
+
 #ifdef D2T_PROBES
 }  // namespace d2t
 extern "C" int d2t_debug_row_phases(unsigned long long* out, int reset) {  // probe builds: read (and clear) d2t_row_phase
@@ -1584,9 +1788,9 @@ extern "C" int d2t_debug_row_phases(unsigned long long* out, int reset) {  // pr
 namespace d2t {
 #endif
 hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
-                                       const float* bv, hipStream_t s) {
+                                       const float* bv, hipStream_t s, const uint16_t* mem_hi, const uint16_t* mem_lo) {
   if (r.heads != 8 || r.D != 256 || r.T < 1) return hipErrorInvalidValue;
-  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, nullptr, nullptr};
+  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, nullptr, nullptr, mem_hi, mem_lo};
   static const int probe = D2T_PROBE_ENV("D2T_ROW_PROBE");  // probe builds only: skip phases (results are garbage by construction)
   q.r.probe = probe;
   static const bool one_row = D2T_PROBE_ENV_STR("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
@@ -1596,7 +1800,8 @@ hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long 
   static const bool no_pf = getenv("D2T_DECODE_ROW2_NO_PREFETCH") != nullptr;  // A/B: the round-3 issue order
   if (no_pf) { hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q); return hipGetLastError(); }
 #endif
-  hipLaunchKernelGGL(decoder_row2_absorbed_pf_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
+  if (mem_hi && mem_lo) hipLaunchKernelGGL(decoder_row2_absorbed_bx3_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
+  else hipLaunchKernelGGL(decoder_row2_absorbed_pf_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q);
   return hipGetLastError();
 }
 
@@ -1774,7 +1979,7 @@ __global__ __launch_bounds__(256, 1) void beam_cross_kernel(const BeamCrossP p) 
 hipError_t launch_decoder_row_beam(const DecRowP& r, const float* mem, long long mem_stride, const float* wk, const float* wv_t,
                                    const float* bv, float* qp, float* x1, const int* seg, int nsamples, hipStream_t s) {
   if (r.heads != 8 || r.D != 256 || r.T < 1 || !qp || !x1 || nsamples < 1) return hipErrorInvalidValue;
-  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, qp, x1};
+  DecRow2P q{r, mem, mem_stride, wk, wv_t, bv, qp, x1, nullptr, nullptr};
   hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 1>), dim3(r.M), dim3(256), 0, s, q);
   BeamCrossP c{mem, mem_stride, r.T, qp, seg, r.M, r.step_ptr, r.stop_at};
   hipLaunchKernelGGL(beam_cross_kernel, dim3(nsamples), dim3(256), 0, s, c);

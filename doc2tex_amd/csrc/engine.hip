@@ -393,6 +393,7 @@ int d2t_create(const d2t_config* cfg, d2t_ctx** out) {
   }
   if (!d2t_device_available()) return fail(c, D2T_EHIP, "no HIP device visible");
   HIPCHK(c, hipGetDevice(&c->device));  // the calling thread's current device becomes the context's device
+  c->cross_fp32 = D2T_PROBE_ENV("D2T_DECODE_CROSS_FP32") != 0;  // probe builds, A/B: the greedy cross-attention on the fp32 MFMA
   {  // the decode stream carries a latency-bound chain of small kernels: give it the highest priority so its
      // workgroups are placed first whenever the encoder of the next batch is filling the chip
     int lo = 0, hi = 0;
@@ -1012,7 +1013,8 @@ int dec_prepare(d2t_ctx* c, int B, int T, DecBufs* bufs) {
   const int d = g.dec_dim, Lmax = g.max_seq_len + 2;
   int rc;
   // a slot holds the encoder memory copy [B][T][d] (absorbed cross-attention) or the projected K/V of every layer
-  const size_t slot_bytes = c->dec_absorbed ? (size_t)B * T * d * 4 : (size_t)g.dec_layers * 2 * B * T * d * 4;
+  // (absorbed form: the fp32 rows, and behind them the same rows as bf16 hi / lo planes for the greedy two-row kernel)
+  const size_t slot_bytes = c->dec_absorbed ? (size_t)B * T * d * 8 + 64 : (size_t)g.dec_layers * 2 * B * T * d * 4;
   for (int i = 0; i < (c->n_chains > 2 ? c->n_chains : 2); ++i)
     if ((rc = ensure(c, &c->ckv2[i], &c->ckv2_cap[i], slot_bytes))) return rc;
   if (!c->ckv) c->ckv = c->ckv2[0];
@@ -1057,7 +1059,13 @@ hipError_t cross_kv(d2t_ctx* c, hipStream_t s, const float* memory, int B, int T
   const int d = g.dec_dim;
   // absorbed form: no projection at all -- the step loop reads the memory rows; the slot keeps a copy so that the captured
   // loop holds an engine address and the caller's tensor is free again as soon as this copy has run
-  if (c->dec_absorbed) return hipMemcpyAsync(c->ckv, memory, (size_t)B * T * d * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (c->dec_absorbed) {
+    const size_t n = (size_t)B * T * d;
+    hipError_t e = hipMemcpyAsync(c->ckv, memory, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    uint16_t* hi = reinterpret_cast<uint16_t*>(c->ckv + n);
+    return launch_split_bf16(memory, hi, hi + n, n, s);  // the planes of the split-bf16 cross-attention (decode.hip)
+  }
   ConvP p{};
   p.in = memory; p.w = c->ckv_w; p.bias = c->ckv_b; p.out = c->ckv;
   if (c->conv_bf16x3 && c->ckv_hi) { p.w_hi = c->ckv_hi; p.w_lo = c->ckv_lo; }
@@ -1115,7 +1123,13 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
     if (c->dec_absorbed && c->beam_shared_tile && beam > 0 && beam <= 6 && c->beam_qp && (shared_mem || row_map))
       TRY(launch_decoder_row_beam(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, c->beam_qp,
                                   c->beam_qp + (size_t)kvB * 8 * d, seg, shared_mem ? 1 : ckvB, s));
-    else if (c->dec_absorbed) TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s));
+    else if (c->dec_absorbed) {
+      // greedy rows take the split-bf16 cross-attention over the planes behind the slot's fp32 rows (cross_kv); beam rows (one per
+      // block, ancestry) the fp32 rows on the fp32 MFMA
+      const size_t memn = (size_t)(shared_mem ? 1 : (ckvB > 0 ? ckvB : kvB)) * T * d;
+      const uint16_t* mhi = (beam > 0 || anc || c->cross_fp32) ? nullptr : reinterpret_cast<const uint16_t*>(c->ckv + memn);
+      TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s, mhi, mhi ? mhi + memn : nullptr));
+    }
     else TRY(launch_decoder_row(r, s));
     TRY(skinny(s, Lin{bf.y2, d, &L.l1, nullptr, bf.f, g.dec_ff, ACT_RELU}, M, &L.n2, bf.x2, nullptr, 0, trace_slot(c), stop, step));
     TRY(skinny(s, Lin{bf.f, g.dec_ff, &L.l2, bf.x2, bf.y3, d, ACT_NONE}, M, nullptr, nullptr, nullptr, 0, trace_slot(c), stop, step));

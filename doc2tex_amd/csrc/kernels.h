@@ -249,8 +249,11 @@ struct DecRowP {
 hipError_t launch_decoder_row(const DecRowP& p, hipStream_t s);
 // the same step with the cross-attention taken over the encoder memory itself (absorbed K / V projections, decode.hip):
 // mem [samples][T][256] (row b attends over sample c_row_map[b] or b), wk [256][256] as stored, wv_t [c][o], bv [256]
+// mem_hi / mem_lo (optional, greedy two-row kernel only): the same rows as bf16 hi / lo planes (launch_split_bf16) -> the
+// cross-attention runs on split-bf16 MFMAs
 hipError_t launch_decoder_row_absorbed(const DecRowP& p, const float* mem, long long mem_stride, const float* wk,
-                                       const float* wv_t, const float* bv, hipStream_t s);
+                                       const float* wv_t, const float* bv, hipStream_t s, const uint16_t* mem_hi = nullptr,
+                                       const uint16_t* mem_lo = nullptr);
 // beam search (at most 6 live hypotheses per sample): the row step split around ONE cross-attention block per sample that
 // stages the sample's memory tiles once for all its hypotheses; qp [rows][8][256] and x1 [rows][256] are scratch;
 // seg [nsamples][3] = (first row, live hypotheses, -) per sample, or nullptr / 1 for a single sample (rows [0, p.M))

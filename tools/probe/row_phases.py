@@ -47,3 +47,7 @@ for k in (0, 1, 2, 3, 4, 5, 6, 12, 7, 8, 9, 10, 11, 20):
     tot += us
     print(f"  {NAMES[k]:58s} {us:6.2f} us")
 print(f"  {'sum':58s} {tot:6.2f} us")
+print("inside the cross-attention loop of wave 0 (per launch, all its tiles):")
+for k, nm in ((13, "loop overhead"), (14, "next tile's loads issued"), (15, "score product S^T"),
+              (16, "softmax + accumulator rescale"), (17, "weighted sum P.M"), (18, "next tile awaited + moved to LDS")):
+    print(f"  {nm:58s} {float(buf[k]) / max(1, n) / 100.0:6.2f} us")
