@@ -727,6 +727,156 @@ __device__ __forceinline__ void cross_absorbed_wave(const float* __restrict__ me
   l_run += __shfl_xor(l_run, 32, 64);
 }
 
+#ifdef D2T_PROBES
+// probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
+__device__ unsigned long long d2t_row_phase[32];
+#define ROW_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_row_phase[k], now_ - phase_t_); phase_t_ = now_; } } while (0)
+#define ROW_PHASE_INIT() unsigned long long phase_t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_row_phase[31], 1ull)
+#else
+#define ROW_PHASE(k) do { } while (0)
+#define ROW_PHASE_INIT() do { } while (0)
+#endif
+#ifdef D2T_PROBES
+#define WAVE_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_row_phase[k], now_ - wave_t_); wave_t_ = now_; } } while (0)
+#define WAVE_PHASE_INIT() unsigned long long wave_t_ = __builtin_amdgcn_s_memrealtime()
+#else
+#define WAVE_PHASE(k) do { } while (0)
+#define WAVE_PHASE_INIT() do { } while (0)
+#endif
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross-attention on split-bf16 MFMAs (round 4).  Inside the loop below the fp32-MFMA form is bound by the matrix pipe:
+// 128 v_mfma_f32_16x16x4_f32 per tile at 32 cycles, two waves per SIMD, and only 8 of the 16 columns (heads) of every tile
+// useful -- 15 of the loop's 28 us (probe build, tools/probe/row_phases.py).  The same products on the bf16 pipe, every fp32
+// operand as hi + lo (three MFMAs per product, lo*hi + hi*lo + hi*hi: the arithmetic of the encoder's GEMMs):
+//     S^T [16 keys x 16 (8 heads + 8 idle)] = M_tile [16 x 256] . Q'^T      8 K-steps x 3 v_mfma_f32_16x16x32_bf16   (24)
+//     ctx [16 (8 heads + 8 idle) x 256]    += P [16 x 16 keys] . M_tile     16 column blocks x 3 v_mfma_f32_16x16x16_bf16 (48)
+// 72 MFMAs of 16 cycles instead of 128 of 32.  The memory rows arrive as two bf16 planes (hi = upper 16 bits, lo = bf16(x - hi):
+// x to 16 significant bits; launch_split_bf16 at cross_kv time); a tile = 16 rows x 512 B of hi | 16 x 512 B of lo in the wave's
+// 16 KB stage, 16-byte chunk c of row r at position c ^ r (conflict-free ds_read_b128 of the score product's A operand; the
+// weighted sum's B operand [keys x channels] comes out of the same image with ds_read_b64_tr_b16).  The absorbed queries
+// are split the same way when they are stored.  The score product's result layout (lane = (key group, head), registers =
+// keys 4g..4g+3) is the A-operand layout of the 16x16x16 form, so P never moves between lanes, as before.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ds4 __attribute__((ext_vector_type(4)));
+typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ds4* lds_ds4_ptr;
+__device__ __forceinline__ void split16(float x, unsigned& hi, unsigned& lo) {  // hi = upper 16 bits, lo = bf16_rne(x - hi)
+  const unsigned u = __float_as_uint(x);
+  hi = u >> 16;
+  const __bf16 l = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
+  lo = *reinterpret_cast<const unsigned short*>(&l);
+}
+// global source of the 16 bytes lane `lane` holds of piece i (0..15) of tile `tile`: pieces 0-7 = two hi rows each, 8-15 = lo
+__device__ __forceinline__ const uint16_t* bx3_piece_src(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
+                                                         int i, int lane) {
+  const int row = 2 * (i & 7) + (lane >> 5);
+  const int jr = (tile << 4) + row, j = jr < T ? jr : T - 1;  // rows past the end: a valid row, its probability is forced to zero
+  return (i < 8 ? mh : ml) + (size_t)j * 256 + (((lane & 31) ^ row) << 3);
+}
+__device__ __forceinline__ void bx3_tile_dma(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
+                                             unsigned char* stage, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    __builtin_amdgcn_global_load_lds(bx3_piece_src(mh, ml, T, tile, i, lane), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
+}
+// this wave's share of the cross-attention of one query row: acc[cb][reg] = ctx[head 4 g + reg][channel 16 cb + col] (unnormalised)
+template <int NW>
+__device__ __forceinline__ void cross_absorbed_wave_bx3(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T,
+                                                        const unsigned char* qp_b, unsigned char* stage, int wave, int lane,
+                                                        float& m_run, float& l_run, f32x4 (&acc)[16]) {
+  const int col = lane & 15, g = lane >> 4, hrow = col & 7;
+  m_run = -INFINITY;
+  l_run = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < 16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (T + 15) >> 4;
+  // transposing-read addresses of the weighted sum's B operand: lane 4 q' + p of a 16-lane group supplies row 4 g + q' of the
+  // block, channels 4 p .. 4 p + 3 of the column block; with the row's chunk swizzle: chunk (2 cb + (p >> 1)) ^ row
+  const int trow = 4 * g + ((lane & 15) >> 2), tp = lane & 3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile (issued at kernel entry) has landed
+  WAVE_PHASE_INIT();
+  for (int tile = wave; tile < ntiles; tile += NW) {
+    const int j0 = tile << 4;
+    const int nxt = tile + NW;
+    WAVE_PHASE(13);
+    du32x4 pf[16];
+    if (nxt < ntiles) {  // wave-uniform: the next tile travels to registers during this tile's arithmetic
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pf[i] = *reinterpret_cast<const du32x4*>(bx3_piece_src(mh, ml, T, nxt, i, lane));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pf[i] = du32x4{0u, 0u, 0u, 0u};
+    }
+    WAVE_PHASE(14);
+    // ---- S^T[key = 4 g' + reg][head = col]: A = tile rows (key = col), B = absorbed queries (head = col & 7) ----
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int ch = 4 * ks + g;  // logical 16-byte chunk (8 channels) of this lane's k-group
+      const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(stage + col * 512 + ((ch ^ col) << 4));
+      const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(stage + 8192 + col * 512 + ((ch ^ col) << 4));
+      const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(qp_b + hrow * 512 + ((ch ^ hrow) << 4));
+      const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(qp_b + 4096 + hrow * 512 + ((ch ^ hrow) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sacc, 0, 0, 0);
+    }
+    // ---- online softmax: this lane holds keys j0 + 4 g + reg of head `col` ----
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
+      mx = fmaxf(mx, sv[reg]);
+    }
+    WAVE_PHASE(15);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // a tile holds at least one valid key: finite
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 for the first tile
+    float ps = 0.f;
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float pv = expf(sv[reg] - m_new);  // exp(-inf) = 0 for keys past the end
+      ps += pv;
+      split16(pv, ph[reg], pl[reg]);
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    float ar[4];  // the accumulators hold ctx[head = 4 g + reg][...]: their scale is the alpha of THAT head (lane 4 g + reg has it)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ar[reg] = __shfl(alpha, 4 * g + reg, 64);
+#pragma unroll
+    for (int cb = 0; cb < 16; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[cb][reg] *= ar[reg];
+    const ds4 pah = {(short)ph[0], (short)ph[1], (short)ph[2], (short)ph[3]}, pal = {(short)pl[0], (short)pl[1], (short)pl[2], (short)pl[3]};
+    WAVE_PHASE(16);
+    // ---- ctx[head][16 cb + col] += sum_keys P[head][key] m[key][channel]: A = P (head = col, keys 4 g .. 4 g + 3), B by transposing reads ----
+#pragma unroll
+    for (int cb = 0; cb < 16; ++cb) {
+      const int off = trow * 512 + (((2 * cb + (tp >> 1)) ^ trow) << 4) + (tp & 1) * 8;
+      const ds4 bh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + off));
+      const ds4 bl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + 8192 + off));
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pal, bh, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bl, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bh, acc[cb], 0, 0, 0);
+    }
+    WAVE_PHASE(17);
+    if (nxt < ntiles) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads have returned: the stage may be overwritten
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<du32x4*>(stage + i * 1024 + lane * 16) = pf[i];
+    }
+    WAVE_PHASE(18);
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+}
+
 struct DecRow2P {
   DecRowP r;            // as decoder_row_kernel (ck / cv unused)
   const float* mem;     // [samples][T][D] encoder memory (engine-owned copy)
@@ -751,7 +901,7 @@ struct DecRow2P {
 // MODE 0: the whole row step (greedy).  MODE 1: up to the absorbed queries, which go to q.qp (+ x1 to q.x1).  MODE 2: from
 // the context rows in q.qp on (value projection, output projection, residual) -- the two halves around beam_cross_kernel.
 constexpr int ANC_MAX = 512;  // longest ancestry row held in LDS (DecRowP::anc needs s_Lmax <= ANC_MAX)
-template <int NTH, int MODE>  // D = 256, 8 heads of 32
+template <int NTH, int MODE, bool BX3 = false>  // D = 256, 8 heads of 32; BX3 (MODE 0): the cross-attention on split-bf16 MFMAs
 __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecRow2P q) {
   constexpr int D = 256, HD = 32, NW = NTH / 64, G = NTH / (D / 4), HPW = 8 / NW;
   const DecRowP& p = q.r;
@@ -853,7 +1003,15 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
       }
       const float4 qv = make_float4(accq.x * scale, accq.y * scale, accq.z * scale, accq.w * scale);
       if (MODE == 1) *reinterpret_cast<float4*>(q.qp + ((size_t)b * 8 + h) * D + c4) = qv;
-      else *reinterpret_cast<float4*>(qp_s + h * D + ((((c4 >> 2) ^ h)) << 2)) = qv;
+      else if (BX3) {  // hi / lo bf16 planes (cross_absorbed_wave_bx3): head h's row of 512 B, chunk (c4 >> 3) ^ h, half (c4 >> 2) & 1
+        const float v[4] = {qv.x, qv.y, qv.z, qv.w};
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split16(v[e], hi[e], lo[e]);
+        unsigned char* base = reinterpret_cast<unsigned char*>(qp_s) + h * 512 + (((c4 >> 3) ^ h) << 4) + ((c4 >> 2) & 1) * 8;
+        *reinterpret_cast<uint2*>(base) = make_uint2(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16);
+        *reinterpret_cast<uint2*>(base + 4096) = make_uint2(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);
+      } else *reinterpret_cast<float4*>(qp_s + h * D + ((((c4 >> 2) ^ h)) << 2)) = qv;
     }
   }
   __syncthreads();
@@ -872,21 +1030,38 @@ __global__ __launch_bounds__(NTH, 2) void decoder_row_absorbed_kernel(const DecR
   if (MODE == 0 && !ROW_PROBE(4)) {
     const int cb = p.c_row_map ? p.c_row_map[b] : b;
     float m_run, l_run;
-    f32x4 acc[4][4];
     unsigned char* stage = stage_s + wave * 16384;
-    cross_absorbed_wave<NW>(q.mem + (size_t)cb * q.mem_stride, p.T, qp_s, stage, wave, lane, m_run, l_run, acc);
     const int col = lane & 15, g = lane >> 4;
-    if (g == 0 && col < 8) { wm_s[wave][col] = m_run; wl_s[wave][col] = l_run; }
-    // this wave's un-normalised ctx [8 heads][256] into its (now idle) staging area: lane (g, col) holds heads 4g + reg
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float* mine = reinterpret_cast<float*>(stage);
-    if (g < 2) {
+    if constexpr (BX3) {
+      const uint16_t* mh = q.mem_hi + (size_t)cb * q.mem_stride;
+      const uint16_t* ml = q.mem_lo + (size_t)cb * q.mem_stride;
+      f32x4 acc[16];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wave < ((p.T + 15) >> 4)) bx3_tile_dma(mh, ml, p.T, wave, stage, lane);  // (the stage held GEMV partials until now)
+      cross_absorbed_wave_bx3<NW>(mh, ml, p.T, reinterpret_cast<const unsigned char*>(qp_s), stage, wave, lane, m_run, l_run, acc);
+      if (g == 0 && col < 8) { wm_s[wave][col] = m_run; wl_s[wave][col] = l_run; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (g < 2) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+        for (int cbk = 0; cbk < 16; ++cbk)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
-              make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+          for (int reg = 0; reg < 4; ++reg) mine[(4 * g + reg) * D + 16 * cbk + col] = acc[cbk][reg];
+      }
+    } else {
+      f32x4 acc[4][4];
+      cross_absorbed_wave<NW>(q.mem + (size_t)cb * q.mem_stride, p.T, qp_s, stage, wave, lane, m_run, l_run, acc);
+      if (g == 0 && col < 8) { wm_s[wave][col] = m_run; wl_s[wave][col] = l_run; }
+      // this wave's un-normalised ctx [8 heads][256] into its (now idle) staging area: lane (g, col) holds heads 4g + reg
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (g < 2) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg)
+            *reinterpret_cast<float4*>(mine + (4 * g + reg) * D + 64 * w + 4 * col) =
+                make_float4(acc[w][0][reg], acc[w][1][reg], acc[w][2][reg], acc[w][3][reg]);
+      }
     }
   }
   __syncthreads();
@@ -1274,24 +1449,6 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
   }
 }
 
-#ifdef D2T_PROBES
-// probe builds: block 0 / thread 0 adds the time between consecutive marks (s_memrealtime, 10 ns ticks) to d2t_row_phase[k]
-__device__ unsigned long long d2t_row_phase[32];
-#define ROW_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
-    atomicAdd(&d2t_row_phase[k], now_ - phase_t_); phase_t_ = now_; } } while (0)
-#define ROW_PHASE_INIT() unsigned long long phase_t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_row_phase[31], 1ull)
-#else
-#define ROW_PHASE(k) do { } while (0)
-#define ROW_PHASE_INIT() do { } while (0)
-#endif
-#ifdef D2T_PROBES
-#define WAVE_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
-    atomicAdd(&d2t_row_phase[k], now_ - wave_t_); wave_t_ = now_; } } while (0)
-#define WAVE_PHASE_INIT() unsigned long long wave_t_ = __builtin_amdgcn_s_memrealtime()
-#else
-#define WAVE_PHASE(k) do { } while (0)
-#define WAVE_PHASE_INIT() do { } while (0)
-#endif
 // LDS-DMA of key tile `tile` of `mem` into a wave's 16 KB stage (the layout cross_absorbed_wave reads)
 __device__ __forceinline__ void cross_tile_dma(const float* __restrict__ mem, int T, int tile, unsigned char* stage, int lane) {
   const int j0 = tile << 4;
@@ -1300,138 +1457,6 @@ __device__ __forceinline__ void cross_tile_dma(const float* __restrict__ mem, in
     const int j = j0 + i < T ? j0 + i : T - 1;
     __builtin_amdgcn_global_load_lds(mem + (size_t)j * 256 + ((lane ^ i) << 2), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Cross-attention on split-bf16 MFMAs (round 4).  Inside the loop below the fp32-MFMA form is bound by the matrix pipe:
-// 128 v_mfma_f32_16x16x4_f32 per tile at 32 cycles, two waves per SIMD, and only 8 of the 16 columns (heads) of every tile
-// useful -- 15 of the loop's 28 us (probe build, tools/probe/row_phases.py).  The same products on the bf16 pipe, every fp32
-// operand as hi + lo (three MFMAs per product, lo*hi + hi*lo + hi*hi: the arithmetic of the encoder's GEMMs):
-//     S^T [16 keys x 16 (8 heads + 8 idle)] = M_tile [16 x 256] . Q'^T      8 K-steps x 3 v_mfma_f32_16x16x32_bf16   (24)
-//     ctx [16 (8 heads + 8 idle) x 256]    += P [16 x 16 keys] . M_tile     16 column blocks x 3 v_mfma_f32_16x16x16_bf16 (48)
-// 72 MFMAs of 16 cycles instead of 128 of 32.  The memory rows arrive as two bf16 planes (hi = upper 16 bits, lo = bf16(x - hi):
-// x to 16 significant bits; launch_split_bf16 at cross_kv time); a tile = 16 rows x 512 B of hi | 16 x 512 B of lo in the wave's
-// 16 KB stage, 16-byte chunk c of row r at position c ^ r (conflict-free ds_read_b128 of the score product's A operand; the
-// weighted sum's B operand [keys x channels] comes out of the same image with ds_read_b64_tr_b16).  The absorbed queries
-// are split the same way when they are stored.  The score product's result layout (lane = (key group, head), registers =
-// keys 4g..4g+3) is the A-operand layout of the 16x16x16 form, so P never moves between lanes, as before.
-// ---------------------------------------------------------------------------------------------------------------------
-typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
-typedef short ds4 __attribute__((ext_vector_type(4)));
-typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) ds4* lds_ds4_ptr;
-__device__ __forceinline__ void split16(float x, unsigned& hi, unsigned& lo) {  // hi = upper 16 bits, lo = bf16_rne(x - hi)
-  const unsigned u = __float_as_uint(x);
-  hi = u >> 16;
-  const __bf16 l = (__bf16)(x - __uint_as_float(u & 0xFFFF0000u));
-  lo = *reinterpret_cast<const unsigned short*>(&l);
-}
-// global source of the 16 bytes lane `lane` holds of piece i (0..15) of tile `tile`: pieces 0-7 = two hi rows each, 8-15 = lo
-__device__ __forceinline__ const uint16_t* bx3_piece_src(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
-                                                         int i, int lane) {
-  const int row = 2 * (i & 7) + (lane >> 5);
-  const int jr = (tile << 4) + row, j = jr < T ? jr : T - 1;  // rows past the end: a valid row, its probability is forced to zero
-  return (i < 8 ? mh : ml) + (size_t)j * 256 + (((lane & 31) ^ row) << 3);
-}
-__device__ __forceinline__ void bx3_tile_dma(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T, int tile,
-                                             unsigned char* stage, int lane) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-    __builtin_amdgcn_global_load_lds(bx3_piece_src(mh, ml, T, tile, i, lane), (lds_ptr_dec)(stage + i * 1024), 16, 0, 0);
-}
-// this wave's share of the cross-attention of one query row: acc[cb][reg] = ctx[head 4 g + reg][channel 16 cb + col] (unnormalised)
-template <int NW>
-__device__ __forceinline__ void cross_absorbed_wave_bx3(const uint16_t* __restrict__ mh, const uint16_t* __restrict__ ml, int T,
-                                                        const unsigned char* qp_b, unsigned char* stage, int wave, int lane,
-                                                        float& m_run, float& l_run, f32x4 (&acc)[16]) {
-  const int col = lane & 15, g = lane >> 4, hrow = col & 7;
-  m_run = -INFINITY;
-  l_run = 0.f;
-#pragma unroll
-  for (int cb = 0; cb < 16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ntiles = (T + 15) >> 4;
-  // transposing-read addresses of the weighted sum's B operand: lane 4 q' + p of a 16-lane group supplies row 4 g + q' of the
-  // block, channels 4 p .. 4 p + 3 of the column block; with the row's chunk swizzle: chunk (2 cb + (p >> 1)) ^ row
-  const int trow = 4 * g + ((lane & 15) >> 2), tp = lane & 3;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile (issued at kernel entry) has landed
-  WAVE_PHASE_INIT();
-  for (int tile = wave; tile < ntiles; tile += NW) {
-    const int j0 = tile << 4;
-    const int nxt = tile + NW;
-    WAVE_PHASE(13);
-    du32x4 pf[16];
-    if (nxt < ntiles) {  // wave-uniform: the next tile travels to registers during this tile's arithmetic
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pf[i] = *reinterpret_cast<const du32x4*>(bx3_piece_src(mh, ml, T, nxt, i, lane));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pf[i] = du32x4{0u, 0u, 0u, 0u};
-    }
-    WAVE_PHASE(14);
-    // ---- S^T[key = 4 g' + reg][head = col]: A = tile rows (key = col), B = absorbed queries (head = col & 7) ----
-    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int ch = 4 * ks + g;  // logical 16-byte chunk (8 channels) of this lane's k-group
-      const dbf16x8 ah = *reinterpret_cast<const dbf16x8*>(stage + col * 512 + ((ch ^ col) << 4));
-      const dbf16x8 al = *reinterpret_cast<const dbf16x8*>(stage + 8192 + col * 512 + ((ch ^ col) << 4));
-      const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(qp_b + hrow * 512 + ((ch ^ hrow) << 4));
-      const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(qp_b + 4096 + hrow * 512 + ((ch ^ hrow) << 4));
-      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sacc, 0, 0, 0);
-    }
-    // ---- online softmax: this lane holds keys j0 + 4 g + reg of head `col` ----
-    float sv[4], mx = -INFINITY;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      sv[reg] = (j0 + 4 * g + reg < T) ? sacc[reg] : -INFINITY;
-      mx = fmaxf(mx, sv[reg]);
-    }
-    WAVE_PHASE(15);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // a tile holds at least one valid key: finite
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 for the first tile
-    float ps = 0.f;
-    unsigned ph[4], pl[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const float pv = expf(sv[reg] - m_new);  // exp(-inf) = 0 for keys past the end
-      ps += pv;
-      split16(pv, ph[reg], pl[reg]);
-    }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-    float ar[4];  // the accumulators hold ctx[head = 4 g + reg][...]: their scale is the alpha of THAT head (lane 4 g + reg has it)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) ar[reg] = __shfl(alpha, 4 * g + reg, 64);
-#pragma unroll
-    for (int cb = 0; cb < 16; ++cb)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) acc[cb][reg] *= ar[reg];
-    const ds4 pah = {(short)ph[0], (short)ph[1], (short)ph[2], (short)ph[3]}, pal = {(short)pl[0], (short)pl[1], (short)pl[2], (short)pl[3]};
-    WAVE_PHASE(16);
-    // ---- ctx[head][16 cb + col] += sum_keys P[head][key] m[key][channel]: A = P (head = col, keys 4 g .. 4 g + 3), B by transposing reads ----
-#pragma unroll
-    for (int cb = 0; cb < 16; ++cb) {
-      const int off = trow * 512 + (((2 * cb + (tp >> 1)) ^ trow) << 4) + (tp & 1) * 8;
-      const ds4 bh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + off));
-      const ds4 bl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds4_ptr)(stage + 8192 + off));
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pal, bh, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bl, acc[cb], 0, 0, 0);
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pah, bh, acc[cb], 0, 0, 0);
-    }
-    WAVE_PHASE(17);
-    if (nxt < ntiles) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads have returned: the stage may be overwritten
-#pragma unroll
-      for (int i = 0; i < 16; ++i) *reinterpret_cast<du32x4*>(stage + i * 1024 + lane * 16) = pf[i];
-    }
-    WAVE_PHASE(18);
-  }
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
 }
 
 // cross_absorbed_wave<NW> with the tile stream pipelined: the wave's first tile was started with cross_tile_dma long before;
@@ -1795,7 +1820,11 @@ hipError_t launch_decoder_row_absorbed(const DecRowP& r, const float* mem, long 
   q.r.probe = probe;
   static const bool one_row = D2T_PROBE_ENV_STR("D2T_DECODE_ONE_ROW_BLOCKS") != nullptr;  // A/B: the one-row-per-block form for every row
   if (r.anc && (!r.one_row || r.s_Lmax > ANC_MAX)) return hipErrorInvalidValue;  // the two-row kernel reads the cache directly
-  if (one_row || r.one_row) { hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q); return hipGetLastError(); }
+  if (one_row || r.one_row) {
+    if (mem_hi && mem_lo) hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0, true>), dim3(r.M), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((decoder_row_absorbed_kernel<256, 0>), dim3(r.M), dim3(256), 0, s, q);
+    return hipGetLastError();
+  }
 #ifdef D2T_PROBES
   static const bool no_pf = getenv("D2T_DECODE_ROW2_NO_PREFETCH") != nullptr;  // A/B: the round-3 issue order
   if (no_pf) { hipLaunchKernelGGL(decoder_row2_absorbed_kernel, dim3((r.M + 1) / 2), dim3(512), 0, s, q); return hipGetLastError(); }

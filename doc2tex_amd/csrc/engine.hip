@@ -1124,10 +1124,10 @@ hipError_t decode_step(d2t_ctx* c, hipStream_t s, const DecBufs& bf, int M, int 
       TRY(launch_decoder_row_beam(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, c->beam_qp,
                                   c->beam_qp + (size_t)kvB * 8 * d, seg, shared_mem ? 1 : ckvB, s));
     else if (c->dec_absorbed) {
-      // greedy rows take the split-bf16 cross-attention over the planes behind the slot's fp32 rows (cross_kv); beam rows (one per
-      // block, ancestry) the fp32 rows on the fp32 MFMA
+      // the split-bf16 cross-attention reads the planes behind the slot's fp32 rows (cross_kv): greedy rows (two per block) and beam
+      // rows (one per block, ancestry) alike
       const size_t memn = (size_t)(shared_mem ? 1 : (ckvB > 0 ? ckvB : kvB)) * T * d;
-      const uint16_t* mhi = (beam > 0 || anc || c->cross_fp32) ? nullptr : reinterpret_cast<const uint16_t*>(c->ckv + memn);
+      const uint16_t* mhi = c->cross_fp32 ? nullptr : reinterpret_cast<const uint16_t*>(c->ckv + memn);
       TRY(launch_decoder_row_absorbed(r, c->ckv, shared_mem ? 0 : (long long)T * d, L.ca_wk, L.ca_v_t, L.ca_bv, s, mhi, mhi ? mhi + memn : nullptr));
     }
     else TRY(launch_decoder_row(r, s));
