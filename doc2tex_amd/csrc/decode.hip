@@ -1343,10 +1343,9 @@ __global__ __launch_bounds__(512, 1) void decoder_row2_absorbed_kernel(const Dec
 //     element-wise phases' few global operands even earlier (the vector-memory counter retires in order);
 //   * the self-attention runs a wave's two heads in ONE loop (twice the K / V groups in flight per round trip);
 //   * block barriers are raw s_barrier behind lgkmcnt(0) (LDS only): a __syncthreads() fence would drain the prefetches.
-// Phase timeline at 384 rows, alone on the chip (probe build, tools/probe/row_phases.py; us per launch): entry .. self-attention
-// 21.3, five GEMVs 9.7, cross-attention 21.9 + 6.0 waiting for the slowest wave, element-wise 3.2 -- 62 in all (round 3: 64.4
-// -> 60.9 in the decode trace).  What is left is bandwidth, not latency: a launch streams 60 MB of K / V cache (HBM) and 102 MB
-// of memory rows (Infinity Cache) through 192 CUs at 24-30 GB/s each, the rate MI355X_MICROARCH.md measures for gathered rows.
+// Phase timeline at 384 rows, alone on the chip (probe build, tools/probe/row_phases.py; us per launch), with the cross-attention
+// on split-bf16 MFMAs (cross_absorbed_wave_bx3): entry .. self-attention 21.9, five GEMVs 10.6, cross-attention 18.9, element-wise
+// 3.9 -- 55.3 in all (round 3's kernel: 64.4; this issue order on the fp32 MFMA: 62.7).
 // ---------------------------------------------------------------------------------------------------------------------
 #define ROW_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -1402,12 +1401,16 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
       }
     }
   };
+  WAVE_PHASE_INIT();
   issue(0);
   __builtin_amdgcn_sched_barrier(0);
+  WAVE_PHASE(21);  // first K / V groups issued
   after_first_issue();
   __builtin_amdgcn_sched_barrier(0);
+  WAVE_PHASE(22);  // the caller's prefetches issued
   for (int it0 = 0; it0 < nit; it0 += U) {
     if (it0 > 0) issue(it0);
+    WAVE_PHASE(23);  // (further groups issued)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1427,6 +1430,7 @@ __device__ __forceinline__ void row_attention_2h(const float* const (&q)[2], con
           m[h] = mn;
         }
       }
+    WAVE_PHASE(24);  // groups awaited + scored
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1600,6 +1604,7 @@ __device__ __forceinline__ void decoder_row2_absorbed_pf_body(const DecRow2P& q)
     }
     gemv2_load(p.wo_t, gg, lr, W);
   };
+  ROW_PHASE(19);  // kernel entry: scalar state, small operands
   // ---- self-attention over the cache, this wave's two heads in one loop ----
   {
     const float* qkv = p.qkv + (size_t)b * p.qkv_stride;

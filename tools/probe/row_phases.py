@@ -21,7 +21,7 @@ m.eval().to("cuda")
 m.pipelined, m.decode_chains, m.decode_group, m.reserved_blocks = True, 1, group, 0
 img = synth.synth_images(64, 128, 512, seed=1).cuda()
 text = torch.full((64, 1), 1, dtype=torch.long, device="cuda")
-NAMES = {0: "launch .. self-attention done", 1: "W_o products (+ W_q request)", 2: "reduce + residual", 3: "LN1",
+NAMES = {19: "kernel entry", 0: "entry .. self-attention done", 1: "W_o products (+ W_q request)", 2: "reduce + residual", 3: "LN1",
          4: "W_q products (+ W_k request)", 5: "reduce q", 6: "absorbed queries", 12: "cross-attention loop (wave 0: most tiles)",
          7: "partials to LDS, W_v request, wait for the other waves", 8: "merge", 9: "W_v products (+ W_co request)", 10: "reduce",
          11: "W_co products", 20: "reduce + store"}
@@ -42,11 +42,15 @@ with torch.no_grad():
 n = int(buf[31])
 print(f"{n} launches of the two-row kernel ({group * 64} rows)")
 tot = 0.0
-for k in (0, 1, 2, 3, 4, 5, 6, 12, 7, 8, 9, 10, 11, 20):
+for k in (19, 0, 1, 2, 3, 4, 5, 6, 12, 7, 8, 9, 10, 11, 20):
     us = float(buf[k]) / max(1, n) / 100.0
     tot += us
     print(f"  {NAMES[k]:58s} {us:6.2f} us")
 print(f"  {'sum':58s} {tot:6.2f} us")
+print("inside the first phase (wave 0):")
+for k, nm in ((19, "kernel entry (scalar state, small operands)"), (21, "first K / V groups issued"), (22, "the kernel's prefetches issued (tile DMA, W_o)"),
+              (23, "further groups issued"), (24, "groups awaited + scored")):
+    print(f"  {nm:58s} {float(buf[k]) / max(1, n) / 100.0:6.2f} us")
 print("inside the cross-attention loop of wave 0 (per launch, all its tiles):")
 for k, nm in ((13, "loop overhead"), (14, "next tile's loads issued"), (15, "score product S^T"),
               (16, "softmax + accumulator rescale"), (17, "weighted sum P.M"), (18, "next tile awaited + moved to LDS")):
