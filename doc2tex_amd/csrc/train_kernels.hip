@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const ColRedP p, int row
 #pragma unroll
       for (int k = 0; k < 4; ++k) { mu[k] = p.mean[c + k]; rs[k] = p.rstd[c + k]; }
     }
-#pragma unroll 4
+#pragma unroll 8
     for (long long r = r0 + ty; r < r1; r += 16) {
       const size_t off = (size_t)r * p.C + c;
       const float4 a4 = *reinterpret_cast<const float4*>(p.a + off);

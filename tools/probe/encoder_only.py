@@ -41,3 +41,19 @@ print(f"GEMM launches: {tot:.2f} ms per forward")
 print(f"{'M':>8} {'N':>5} {'K':>5} {'per fwd':>7} {'avg ms':>8} {'ms/fwd':>7} {'TFLOP/s':>8} {'of 2500':>7}")
 for (M, N, K), (n, ms) in acc.items():
     print(f"{M:8d} {N:5d} {K:5d} {n / 10:7.1f} {ms / n:8.4f} {ms / 10:7.3f} {2.0 * M * N * K / (ms / n) / 1e9:8.1f} {2.0 * M * N * K / (ms / n) / 1e9 / 2500:7.3f}")
+
+# decode step loop alone: 384 rows (six batches' memories), synchronous, no encoder beside it
+with torch.no_grad():
+    mem, _, _ = m.forward_encoder(img)
+    mem6 = torch.cat([mem] * 6).contiguous()
+    go6 = torch.full((mem6.shape[0], 1), 1, dtype=torch.long, device="cuda")
+    m.pipelined = False
+    for _ in range(2):
+        m.forward_decoder(mem6, go6, is_train=False, is_test=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m.forward_decoder(mem6, go6, is_train=False, is_test=False)
+    torch.cuda.synchronize()
+    dl = (time.perf_counter() - t0) / 5
+print(f"decode loop alone: {dl * 1e3:.1f} ms per {mem6.shape[0]} rows x 151 steps = {dl * 1e3 / 6:.2f} ms per batch of 64")
