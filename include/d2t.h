@@ -208,7 +208,12 @@ int d2t_decode_wait_ticket(d2t_ctx* ctx, int64_t ticket, d2t_stream stream, int3
 /* ---- beam decode (one sample, fresh beam state per call) ------------------
  * memory [1,T,d].  seq_out: HOST buffer of max_seq_len+1 int64; *len_out its
  * used length; *score_out the hypothesis score (tools/beam.py semantics:
- * best = argmax score/len over completed hypotheses). */
+ * best = argmax score/len over completed hypotheses).
+ * d_model 256 (round 4): Beam.advance (tools/beam.py:68-105) runs on the device -- candidate walk, completed set, row
+ * compaction and a (parent, token) history per step in one single-block kernel -- and the whole max_seq_len + 1 step loop is
+ * ONE captured graph per (N, T, beam); the host copies one result block back and walks the best hypothesis through the
+ * history.  d2t_decode_beam is that loop with N = 1 (the same row kernels as d2t_decode_beam_batch: bit-identical).  Other
+ * decoders (d_model 512) and d2t_set_beam_shared_tile(1) keep the host-side loop with one round trip per step. */
 int d2t_decode_beam(d2t_ctx* ctx, const float* memory_dev, int32_t T, int32_t beam_size, int64_t* seq_out,
                     int32_t* len_out, float* score_out, d2t_stream stream);
 
