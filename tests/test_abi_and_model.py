@@ -204,3 +204,20 @@ def test_conv_precision_default_and_switches(monkeypatch):
     monkeypatch.setenv("D2T_CONV_PRECISION", "fp16x2")
     m = Model(synth.make_config("T2", max_seq_len=8))
     assert m.conv_precision == "fp16x2"
+
+
+def test_mixed_precision_and_kernel_choices_on_the_model(monkeypatch):
+    """Round 4: 'mixed' is a conv_precision like the others (opt-in, three units by default; D2T_CONV_PRECISION=mixed selects it),
+    the convolution kernel is 'pipelined16' (default) or 'classic' -- the A/B variants of rounds 1-3 are gone."""
+    from doc2tex_amd import Model, synth, _lib
+    monkeypatch.delenv("D2T_CONV_PRECISION", raising=False)
+    m = Model(synth.make_config("T2", max_seq_len=8))
+    assert m.mixed_units == 3 and m.conv_kernel == "pipelined16" and tuple(m.conv_fusion) == (True, True)
+    m.conv_precision = "mixed"
+    assert m.effective_conv_precision() == "mixed"
+    monkeypatch.setenv("D2T_CONV_PRECISION", "mixed")
+    assert Model(synth.make_config("T2", max_seq_len=8)).conv_precision == "mixed"
+    assert _lib.CONV_MIXED == 3
+    for sym in ("d2t_set_mixed_units", "d2t_set_conv_fusion"):
+        assert sym in _lib.SIGNATURES
+    assert "d2t_set_conv_winograd" not in _lib.SIGNATURES
