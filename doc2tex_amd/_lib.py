@@ -19,6 +19,7 @@ ATTN_KEYS_ALL_INIT_MEAN, ATTN_KEYS_NOCLS_INIT_CLS, ATTN_KEYS_ALL_INIT_FIRST = 0,
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 CONV_FP32, CONV_BF16X3, CONV_FP16X2, CONV_MIXED = 0, 1, 2, 3
 ATTN_CELL_LOCATION, ATTN_CELL_BAHDANAU = 0, 1
+VIT_POS_SINCOS_PREFIX, VIT_POS_LEARNED_INTERP, VIT_POS_LEARNED_PREFIX = 0, 1, 2
 
 
 class D2TConfig(C.Structure):
@@ -26,7 +27,7 @@ class D2TConfig(C.Structure):
         "encoder", "in_channels", "backbone_out", "vit_depth", "vit_heads", "vit_dim", "patch_h", "patch_w",
         "max_h", "max_w", "dec_dim", "dec_heads", "dec_layers", "dec_ff", "vocab", "max_seq_len",
         "decoder", "attn_hidden", "attn_kernel_size", "attn_kernel_dim", "attn_keys", "attn_enc_init",
-        "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb", "attn_cell", "attn_onehot")]
+        "attn_coverage", "bilstm_hidden", "batch_max_length", "gcb", "attn_cell", "attn_onehot", "vit_pos")]
 
 
 class D2TPrepConfig(C.Structure):  # include/d2t_prep.h d2t_prep_config

@@ -58,9 +58,16 @@ class SeqModelingBuilder(nn.Module):
                              else config["max_dimension"])  # vit_encoder.py:292-294
             ps = sp["patch_size"]
             ps = (ps, ps) if isinstance(ps, int) else tuple(ps)
-            self.SequenceModeling = P.ViTEncoderV3Params(
+            if sp.get("patching_style") != "2d":
+                raise NotImplementedError("patching_style '1d' (TRIGBaseEncoder) crashes in the reference: HybridEmbed1D has "
+                                          "no patch_size attribute for build_seq.py:63-66 to read")
+            # create_vit_modeling (vit_encoder.py:295-302): fix_embed -> ViTEncoderV3 (frozen sincos table); otherwise a
+            # learned table, read through bicubic interpolation (ViTEncoder) or -- interpolate_embed False -- a prefix slice
+            # (ViTEncoderV2)
+            self.SequenceModeling = P.ViTEncoderParams(
                 img_size=tuple(max_dimension), patch_size=ps, in_chans=sp["input_channel"], depth=sp["depth"],
-                embed_dim=sp["hidden_size"], num_heads=sp["num_heads"], hybrid_backbone=backbone)
+                embed_dim=sp["hidden_size"], num_heads=sp["num_heads"], hybrid_backbone=backbone,
+                fix_embed=bool(sp.get("fix_embed", False)))
         elif flow["Seq"] == "BiLSTM":  # build_seq.py:13-25
             hidden_size = config["SequenceModeling"]["params"]["hidden_size"]
             self.SequenceModeling = nn.Sequential(

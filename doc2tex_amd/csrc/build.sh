@@ -10,7 +10,7 @@ OPT="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-v
 OBJ=obj; LIB=libd2t.so
 if [ -n "$D2T_PROBES" ]; then OPT="$OPT -DD2T_PROBES"; OBJ=obj_probe; LIB=libd2t_probe.so; fi
 mkdir -p $OBJ
-SRCS="conv_mfma conv_bf16x3 conv_bf16x3p ops decode recurrent train_kernels train engine prep post"
+SRCS="conv_mfma conv_bf16x3 conv_bf16x3p ops decode recurrent train_kernels train engine prep post posembed"
 objs=""
 for f in $SRCS; do
   o=$OBJ/$f.o

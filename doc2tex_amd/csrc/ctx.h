@@ -132,6 +132,9 @@ struct d2t_ctx {
   const float* pos_embed = nullptr;  // [1+gh*gw][dim]
   int pos_rows = 0;
   float* cls_row = nullptr;  // cls_token + pos_embed[0]
+  int pos_GH = 0, pos_GW = 0;  // patch grid of max_dimension (the learned table's own grid)
+  struct PosTab { float* p = nullptr; bool valid = false; };
+  std::map<std::pair<int, int>, PosTab> pos_interp;  // D2T_VIT_POS_LEARNED_INTERP: the table resized to a crop's grid
   std::vector<VitBlock> vit;
   LNW vit_norm;
   const float* word_embed = nullptr;
@@ -284,3 +287,18 @@ int need(d2t_ctx* c, const std::string& k, const RawW** out, std::vector<int64_t
 int d2t_internal_pe2d(d2t_ctx* c, int h, int w, int C, hipStream_t s, const float** out);
 // engine.hip: launch_conv bracketed by HIP events while d2t_profile_enable is on (training GEMMs report through it too)
 hipError_t d2t_internal_conv_timed(d2t_ctx* c, const ConvP& p, hipStream_t s);
+
+// ViTEncoder.interpolating_pos_embedding (seq_modeling/vit_encoder.py:58-95): how a crop with patch grid gh x gw reads
+// the learned [1 + GH*GW][D] table.  interp == false: the table as it is (the grids agree, or -- :66-67 -- the token
+// counts agree and the padded feature map is square).  Otherwise F.interpolate's scale factors are (gh + 0.1) / GH and
+// (gw + 0.1) / GW, computed in double as Python does, and ATen maps coordinates with float(1 / scale_factor).
+struct PosGrid { bool interp; float sh, sw; };
+inline PosGrid pos_grid(const d2t_config& g, int GH, int GW, int gh, int gw) {
+  PosGrid r{false, 1.f, 1.f};
+  if (g.vit_pos != D2T_VIT_POS_LEARNED_INTERP || (gh == GH && gw == GW)) return r;  // HybridEmbed's flag, patchembed.py:140
+  if (gh * gw == GH * GW && gh * g.patch_h == gw * g.patch_w) return r;
+  r.interp = true;
+  r.sh = (float)(1.0 / (((double)gh + 0.1) / (double)GH));
+  r.sw = (float)(1.0 / (((double)gw + 0.1) / (double)GW));
+  return r;
+}

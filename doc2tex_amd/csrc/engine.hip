@@ -93,6 +93,7 @@ int get_ln(d2t_ctx* c, const std::string& k, LNW* out, int D) {
 void free_packed(d2t_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   c->owned.clear();
+  c->pos_interp.clear();  // resized copies of the previous position table (owned buffers)
   for (int i = 0; i < 4; ++i) c->layers[i].clear();
   c->vit.clear();
   c->dec.clear();
@@ -282,6 +283,29 @@ int run_backbone(d2t_ctx* c, hipStream_t s, const float* img, int B, int H, int 
            final_extra, sp && final_split && !final_out);
   if (err != hipSuccess) return fail(c, D2T_EHIP, "backbone launch: %s", hipGetErrorString(err));
   *out = x;
+  return D2T_OK;
+}
+
+// Position rows a crop with patch grid gh x gw adds to its tokens ([1 + gh*gw][D], row 0 = the cls row): the loaded table,
+// or -- ViTEncoder, D2T_VIT_POS_LEARNED_INTERP -- its bicubic resize (vit_encoder.py:58-95), built once per grid
+int pos_table_for(d2t_ctx* c, int gh, int gw, hipStream_t s, const float** out) {
+  const PosGrid pg = pos_grid(c->cfg, c->pos_GH, c->pos_GW, gh, gw);
+  if (!pg.interp) { *out = c->pos_embed; return D2T_OK; }
+  const int D = c->cfg.vit_dim;
+  d2t_ctx::PosTab& t = c->pos_interp[std::make_pair(gh, gw)];
+  if (!t.p) {
+    void* p;
+    if (int rc = dev_alloc(c, &p, (size_t)(gh * gw + 1) * D * 4)) return rc;
+    c->owned.push_back(p);
+    t.p = (float*)p;
+    t.valid = false;
+  }
+  if (!t.valid) {
+    HIPCHK(c, launch_copy(c->pos_embed, t.p, (size_t)D, s));  // class_pos_embedding is kept (:69,:93-95)
+    HIPCHK(c, launch_bicubic_table(c->pos_embed + D, t.p + D, c->pos_GH, c->pos_GW, gh, gw, D, pg.sh, pg.sw, s));
+    t.valid = true;
+  }
+  *out = t.p;
   return D2T_OK;
 }
 
@@ -607,6 +631,12 @@ int d2t_finalize_weights(d2t_ctx* c, d2t_stream stream) {
     if (pos->shape.size() != 3 || pos->shape[2] != D) return fail(c, D2T_EINVAL, "pos_embed must be [1,N,%d]", D);
     c->pos_embed = pos->p;
     c->pos_rows = (int)pos->shape[1];
+    if (g.vit_pos < D2T_VIT_POS_SINCOS_PREFIX || g.vit_pos > D2T_VIT_POS_LEARNED_PREFIX) return fail(c, D2T_EINVAL, "vit_pos %d", g.vit_pos);
+    if (d2t_encoder_shape(c, g.max_h, g.max_w, nullptr, nullptr, &c->pos_GH, &c->pos_GW, nullptr, nullptr))
+      return fail(c, D2T_EINVAL, "max_dimension %dx%d leaves no backbone output", g.max_h, g.max_w);
+    if (c->pos_rows != c->pos_GH * c->pos_GW + 1)
+      return fail(c, D2T_EINVAL, "pos_embed has %d rows, max_dimension %dx%d gives a %dx%d patch grid", c->pos_rows, g.max_h,
+                  g.max_w, c->pos_GH, c->pos_GW);
     void* p;
     if ((rc = dev_alloc(c, &p, (size_t)D * 4))) return rc;
     c->owned.push_back(p);
@@ -854,7 +884,8 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
   if (d2t_encoder_shape(c, H, W, &T, &dim, &gh, &gw, &pw, &ph))
     return fail(c, D2T_EINVAL, "unsupported crop %dx%d (backbone output would be empty)", H, W);
   const bool vit = g.encoder == D2T_ENC_HYBRID_VIT;
-  if (vit && T > c->pos_rows) return fail(c, D2T_EINVAL, "crop %dx%d exceeds max_dimension (pos_embed rows %d)", H, W, c->pos_rows);
+  if (vit && g.vit_pos != D2T_VIT_POS_LEARNED_INTERP && T > c->pos_rows)  // the prefix slice would run off the table
+    return fail(c, D2T_EINVAL, "crop %dx%d exceeds max_dimension (pos_embed rows %d)", H, W, c->pos_rows);
   if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
   // largest activation: conv0_2 output B*H*W*64 floats; ViT needs B*T*max(3*dim, hidden)
   size_t need_floats = (size_t)B * H * W * 64;
@@ -953,7 +984,9 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
     p.B = f.B; p.H = f.H; p.W = f.W; p.Cin = f.C; p.OH = gh; p.OW = gw; p.Cout = dim;
     p.KH = g.patch_h; p.KW = g.patch_w; p.SH = g.patch_h; p.SW = g.patch_w; p.PH = 0; p.PW = 0;
     p.M = B * gh * gw; p.K = p.KH * p.KW * f.C; p.act = ACT_NONE;
-    p.row_add = c->pos_embed; p.rows_per_img = gh * gw; p.img_stride = T; p.row_off = 1; p.row_add_off = 1;
+    const float* pos;
+    if ((rc = pos_table_for(c, gh, gw, s, &pos))) return rc;
+    p.row_add = pos; p.rows_per_img = gh * gw; p.img_stride = T; p.row_off = 1; p.row_add_off = 1;
     HIPCHK(c, conv_timed(c, p, s));
     HIPCHK(c, launch_fill_cls(c->cls_row, X, B, (long long)T * dim, dim, s));
   }

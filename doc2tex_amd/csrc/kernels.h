@@ -466,6 +466,14 @@ hipError_t launch_dilate(const float* src, float* dst, int B, int OH, int OW, in
 hipError_t launch_flip_oihw(const float* w, float* out, int Cout, int Cin, int KH, int KW, hipStream_t s);
 hipError_t launch_token_rows(const float* src, float* dst, int B, int n, int skip, int D, int scatter, hipStream_t s);
 hipError_t launch_sum_rows_strided(const float* x, float* out, int B, long long stride_rows, int row, int D, hipStream_t s);
+// posembed.hip -- ViTEncoder's learned table resized to a crop's patch grid (vit_encoder.py:58-95): [GH*GW][D] -> [gh*gw][D]
+// by ATen's bicubic rule with scale_h / scale_w = 1 / scale_factor; its transpose (gradient of the table); and the sum of a
+// [B][n] gradient over the batch
+hipError_t launch_bicubic_table(const float* src, float* dst, int GH, int GW, int gh, int gw, int D, float scale_h,
+                                float scale_w, hipStream_t s);
+hipError_t launch_bicubic_table_bwd(const float* ddst, float* dsrc, int GH, int GW, int gh, int gw, int D, float scale_h,
+                                    float scale_w, hipStream_t s);
+hipError_t launch_sum_over_batch(const float* x, float* out, int B, long long stride, long long n, hipStream_t s);
 hipError_t launch_stem_raw(const float* img, const float* w, float* z, int B, int H, int W, int Cout, hipStream_t s);
 hipError_t launch_stem_wgrad(const float* img, const float* dz, float* part, int B, int H, int W, int Cout, int chunk,
                              int nchunks, hipStream_t s);

@@ -690,7 +690,21 @@ struct Tr {  // builder / runner bound to one context and stream
     const RawW* pr;
     RC(need(c, p + "pos_embed", &pr));
     pos = pr->p;
-    if ((long long)pr->numel < (long long)(n + 1) * D) return fail(c, D2T_EINVAL, "pos_embed too small for %d tokens", n + 1);
+    // ViTEncoder (learned table, vit_encoder.py:58-95): a crop whose patch grid is not max_dimension's reads the table through a
+    // bicubic resize, rebuilt every step (the table is being trained)
+    int GH = 0, GW = 0;
+    if (d2t_encoder_shape(c, g.max_h, g.max_w, nullptr, nullptr, &GH, &GW, nullptr, nullptr) || (long long)pr->numel != (long long)(GH * GW + 1) * D)
+      return fail(c, D2T_EINVAL, "pos_embed does not match max_dimension's patch grid");
+    const PosGrid pg = pos_grid(g, GH, GW, gh, gw);
+    if (pg.interp) {
+      float* tbl;
+      RC(alloc(&tbl, (size_t)(n + 1) * D));
+      TCHK(launch_copy(pos, tbl, (size_t)D, s));
+      TCHK(launch_bicubic_table(pos + D, tbl + D, GH, GW, gh, gw, D, pg.sh, pg.sw, s));
+      pos = tbl;
+    } else if ((long long)pr->numel < (long long)(n + 1) * D) {
+      return fail(c, D2T_EINVAL, "pos_embed too small for %d tokens", n + 1);
+    }
     int x;
     RC(new_tensor((long long)f.B * (n + 1), D, &x));
     TCHK(launch_token_rows(st->t[patch].p, st->t[x].p, f.B, n, 1, D, 1, s));          // scatter, cls rows zero
@@ -701,6 +715,10 @@ struct Tr {  // builder / runner bound to one context and stream
     }
     Node tn;
     tn.kind = N_TOKENS; tn.in = patch; tn.out = x; tn.ntok = n; tn.wkey = p + "cls_token";
+    if (g.vit_pos != D2T_VIT_POS_SINCOS_PREFIX) {  // learned table: it receives a gradient (ViTEncoderV3's is frozen, :235-237)
+      tn.bkey = p + "pos_embed";
+      tn.KH = GH; tn.KW = GW; tn.SH = gh; tn.SW = gw;
+    }
     st->nodes.push_back(tn);
     const int rows_b = n + 1;
     for (int i = 0; i < g.vit_depth; ++i) {
@@ -1180,6 +1198,26 @@ struct Tr {  // builder / runner bound to one context and stream
     TCHK(launch_sum_rows_strided(y.grad, dcls, nb, n.ntok + 1, 0, D, s));
     RC(alloc(&dx, (size_t)x.rows * D));
     TCHK(launch_token_rows(y.grad, dx, nb, n.ntok, 1, D, 0, s));
+    if (!n.bkey.empty()) {
+      // d pos_embed: the table is broadcast over the batch, so its gradient is the sum of the token gradients over the batch --
+      // written to the first ntok + 1 rows (prefix slice / table as is) or, for a resized table, pulled back through the
+      // transpose of the bicubic resize; rows the crop did not read get zero
+      const int GH = n.KH, GW = n.KW, gh = n.SH, gw = n.SW;
+      const PosGrid pg = pos_grid(c->cfg, GH, GW, gh, gw);
+      float* dpos;
+      RC(grad_buf(n.bkey, &dpos));
+      const size_t rows = (size_t)n.ntok + 1, all = (size_t)GH * GW + 1;
+      if (!pg.interp) {
+        TCHK(launch_sum_over_batch(y.grad, dpos, nb, (long long)(rows * D), (long long)(rows * D), s));
+        if (all > rows) TCHK(hipMemsetAsync(dpos + rows * D, 0, (all - rows) * D * 4, s));
+      } else {
+        float* dt;
+        RC(alloc(&dt, rows * D));
+        TCHK(launch_sum_over_batch(y.grad, dt, nb, (long long)(rows * D), (long long)(rows * D), s));
+        TCHK(launch_copy(dt, dpos, (size_t)D, s));
+        TCHK(launch_bicubic_table_bwd(dt + D, dpos + D, GH, GW, gh, gw, D, pg.sh, pg.sw, s));
+      }
+    }
     return add_grad(n.in, dx);
   }
   int backward() {

@@ -26,8 +26,16 @@ def config_from_opt(opt):
         if bbp.get("name") != "resnet":
             raise NotImplementedError("ViT without the resnet hybrid backbone cannot run in the reference either "
                                       "(PatchEmbed returns a 3-tuple, SURVEY.md 3 notes)")
-        if not sp.get("fix_embed", False) or sp.get("patching_style") != "2d":
-            raise NotImplementedError("only fix_embed=True, patching_style='2d' (ViTEncoderV3) is accelerated")
+        if sp.get("patching_style") != "2d":
+            raise NotImplementedError("patching_style '1d' (TRIGBaseEncoder) crashes in the reference: HybridEmbed1D has no "
+                                      "patch_size attribute for build_seq.py:63-66 to read")
+        # create_vit_modeling, vit_encoder.py:295-302
+        if sp.get("fix_embed", False):
+            cfg.vit_pos = _lib.VIT_POS_SINCOS_PREFIX       # ViTEncoderV3
+        elif not sp.get("interpolate_embed", True):
+            cfg.vit_pos = _lib.VIT_POS_LEARNED_PREFIX      # ViTEncoderV2
+        else:
+            cfg.vit_pos = _lib.VIT_POS_LEARNED_INTERP      # ViTEncoder
         cfg.gcb = int(bool(bbp.get("gcb", False)))
         cfg.encoder = _lib.ENC_HYBRID_VIT
         cfg.in_channels = int(bbp["input_channel"])

@@ -180,18 +180,23 @@ class _VitBlockParams(_Holder):
         self.mlp = _VitMlpParams(dim, int(dim * mlp_ratio))
 
 
-class ViTEncoderV3Params(_Holder):
-    """ViTEncoderV3 (seq_modeling/vit_encoder.py:229-268) over VisionTransformer
-    (seq_modeling/vit/vision_transformer.py:132-228): fix_embed sincos table."""
+class ViTEncoderParams(_Holder):
+    """ViTEncoder / ViTEncoderV2 / ViTEncoderV3 (seq_modeling/vit_encoder.py:22-118, :207-226, :229-268) over
+    VisionTransformer (seq_modeling/vit/vision_transformer.py:132-228): the same parameter tree; `fix_embed` makes
+    pos_embed the frozen sincos table of V3, otherwise it is a learned table (trunc-normal, std 0.02, :44-50)."""
 
-    def __init__(self, img_size, patch_size, in_chans, depth, embed_dim, num_heads, hybrid_backbone):
+    def __init__(self, img_size, patch_size, in_chans, depth, embed_dim, num_heads, hybrid_backbone, fix_embed=True):
         super().__init__()
         self.num_features = self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.patch_embed = HybridEmbedParams(hybrid_backbone, img_size, patch_size, embed_dim)
         gh, gw = self.patch_embed.grid_size
-        self.pos_embed = nn.Parameter(sincos_2d_table(embed_dim, gh, gw), requires_grad=False)
+        if fix_embed:
+            self.pos_embed = nn.Parameter(sincos_2d_table(embed_dim, gh, gw), requires_grad=False)
+        else:
+            self.pos_embed = nn.Parameter(torch.zeros(1, gh * gw + 1, embed_dim))
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
         self.blocks = nn.ModuleList([_VitBlockParams(embed_dim) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.emb_height, self.emb_width = gh, gw

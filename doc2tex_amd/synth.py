@@ -126,6 +126,19 @@ _CONFIGS["T1G"] = copy.deepcopy(_CONFIGS["T1"])
 _CONFIGS["T1G"]["FeatureExtraction"]["params"]["gcb"] = True
 _CONFIGS["T2D"] = copy.deepcopy(_CONFIGS["T2"])  # training with dropout in the decoder layers
 _CONFIGS["T2D"]["Prediction"]["params"]["dropout"] = 0.1
+# The ViT encoders beside ViTEncoderV3 (create_vit_modeling, vit_encoder.py:295-302; in no shipped config): a LEARNED position
+# table, read through bicubic interpolation (ViTEncoder: T2V1, and T2V1P with a non-square patch) or as a prefix slice
+# (ViTEncoderV2: T2V2).  max_dimension [96, 128] -> patch grid 3 x 17.
+_CONFIGS["T2V1"] = copy.deepcopy(_CONFIGS["T2"])
+_CONFIGS["T2V1"]["SequenceModeling"]["params"]["fix_embed"] = False
+_CONFIGS["T2V1"]["max_dimension"] = [96, 128]
+_CONFIGS["T2V1"]["_crop"] = (48, 64)
+_CONFIGS["T2V2"] = copy.deepcopy(_CONFIGS["T2V1"])
+_CONFIGS["T2V2"]["SequenceModeling"]["params"]["interpolate_embed"] = False
+_CONFIGS["T2V1P"] = copy.deepcopy(_CONFIGS["T2V1"])  # patch 1 x 2, max grid 1 x 8: an 80 x 12 crop has the same token count
+_CONFIGS["T2V1P"]["SequenceModeling"]["params"]["patch_size"] = [1, 2]  # on a square feature map (vit_encoder.py:66-67)
+_CONFIGS["T2V1P"]["max_dimension"] = [32, 60]
+_CONFIGS["T2V1P"]["_crop"] = (32, 60)
 _CONFIGS["TS0"] = copy.deepcopy(_CONFIGS["S0"])  # tiny S0
 _CONFIGS["TS0"]["SequenceModeling"] = _vit_seq(depth=2)
 _CONFIGS["TS0"]["max_dimension"] = [48, 64]
@@ -196,9 +209,16 @@ def _fans(shape):
 _TABLES = ("pos_embed", "pos_enc.pe", "image_positional_encoder.pe")
 
 
-def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0):
+def learned_pos_embed(cfg):
+    """True when the configuration's ViT encoder trains its position table (ViTEncoder / ViTEncoderV2): `pos_embed` is then a
+    weight like any other and gets a seeded value; ViTEncoderV3's sincos table is kept as constructed."""
+    seq = cfg.get("SequenceModeling") or {}
+    return seq.get("name") == "ViT" and not seq["params"].get("fix_embed", False)
+
+
+def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0, learned_pos=False):
     """Seeded value for one state_dict entry, or None for constructed tables."""
-    if any(name.endswith(t) for t in _TABLES):
+    if any(name.endswith(t) for t in _TABLES) and not (learned_pos and name.endswith("pos_embed")):
         return None
     shape = tuple(shape)
     g = _rng(seed, name)
@@ -218,6 +238,8 @@ def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0):
         v = g.standard_normal(shape) * 0.1
     elif leaf == "cls_token":
         v = g.standard_normal(shape) * 0.02
+    elif leaf == "pos_embed":  # a trained table (learned_pos): as large as the patch tokens, so a wrong resize shows
+        v = g.standard_normal(shape) * 0.5
     elif "word_embed" in name or name.endswith("Prediction.embedding.weight"):
         v = g.standard_normal(shape)
         v[0] = 0.0  # padding_idx row
@@ -238,16 +260,17 @@ def synth_tensor(name, shape, dtype, seed=1234, end_bias=0.0):
     return torch.from_numpy(np.ascontiguousarray(v)).to(dtype)
 
 
-def synth_state_dict(template, seed=1234, end_bias=0.0):
+def synth_state_dict(template, seed=1234, end_bias=0.0, learned_pos=False):
     """Fill a state_dict-shaped mapping {name: tensor} with seeded values.
 
     `template` is any mapping with the reference's key names and shapes (the
     reference Model's or the engine Model's state_dict()).  Table entries
-    (sincos pos_embed, sinusoid pe) are passed through unchanged.
+    (sincos pos_embed, sinusoid pe) are passed through unchanged; `learned_pos` (= learned_pos_embed(cfg)) makes
+    pos_embed a seeded weight instead.
     """
     out = {}
     for name, t in template.items():
-        v = synth_tensor(name, t.shape, t.dtype, seed=seed, end_bias=end_bias)
+        v = synth_tensor(name, t.shape, t.dtype, seed=seed, end_bias=end_bias, learned_pos=learned_pos)
         out[name] = t.detach().clone() if v is None else v
     return out
 

@@ -84,6 +84,15 @@ enum {
 enum { D2T_ACT_NONE = 0, D2T_ACT_RELU = 1, D2T_ACT_GELU = 2 };
 
 enum { D2T_ATTN_CELL_LOCATION = 0, D2T_ATTN_CELL_BAHDANAU = 1 };
+/* How the ViT encoder's position table meets a crop whose patch grid differs from max_dimension's
+ * (create_vit_modeling, seq_modeling/vit_encoder.py:295-302):
+ *   SINCOS_PREFIX   fix_embed: True -> ViTEncoderV3 (:229-268): frozen sincos table, flat prefix slice pos_embed[:, :N+1]
+ *   LEARNED_INTERP  default -> ViTEncoder (:22-118): learned table, resized to the crop's grid by bicubic interpolation
+ *                   (F.interpolate, align_corners False, scale factors (gh + 0.1) / GH, (gw + 0.1) / GW, :58-95); the table
+ *                   itself when the grids agree (or the token counts agree and the padded feature map is square, :66-67)
+ *   LEARNED_PREFIX  interpolate_embed: False -> ViTEncoderV2 (:207-226): learned table, flat prefix slice
+ * The first and the last are the same arithmetic in inference; in training the learned tables receive gradients. */
+enum { D2T_VIT_POS_SINCOS_PREFIX = 0, D2T_VIT_POS_LEARNED_INTERP = 1, D2T_VIT_POS_LEARNED_PREFIX = 2 };
 
 typedef struct d2t_config {
   int32_t encoder;      /* D2T_ENC_*: Feat=ResNet+Seq=None  |  Seq=ViT (hybrid) */
@@ -111,6 +120,8 @@ typedef struct d2t_config {
                                (attention1D.py:71-118: keys "attn.i2h / attn.h2h / attn.score", no alignment memory) */
   int32_t attn_onehot;      /* 1 = embed_target False: the decoder input is the one-hot vector of the previous token
                                (seq2seq.py:72-78), rnn.weight_ih is [4H][H + num_class] and there is no embedding table */
+  /* appended in v4: the ViT encoder variants beside ViTEncoderV3 */
+  int32_t vit_pos;          /* D2T_VIT_POS_* */
 } d2t_config;
 
 /* ---- lifecycle ----------------------------------------------------------

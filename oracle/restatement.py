@@ -221,14 +221,46 @@ def _vit_block(x, sd, p, heads):
     return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
 
 
-def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None, bn_train=None, drop=None):
-    """ViTEncoderV3.forward, seq_modeling/vit_encoder.py:249-268."""
+def interpolated_pos_embed(pos, max_grid, size, patch):
+    """ViTEncoder.interpolating_pos_embedding, seq_modeling/vit_encoder.py:58-95: the learned [1, 1 + GH*GW, D] table resized
+    to the patch grid of a padded feature map of `size` (F.interpolate bicubic, align_corners False, scale factors
+    (gh + 0.1) / GH and (gw + 0.1) / GW); the table itself when the token counts agree and the feature map is square (:66-67)."""
+    GH, GW = max_grid
+    gh, gw = size["height"] // patch[0], size["width"] // patch[1]
+    if gh * gw == pos.shape[1] - 1 and size["height"] == size["width"]:
+        return pos
+    dim = pos.shape[-1]
+    h0, w0 = gh + 0.1, gw + 0.1
+    grid = F.interpolate(pos[:, 1:].reshape(1, GH, GW, dim).permute(0, 3, 1, 2), scale_factor=(h0 / GH, w0 / GW),
+                         mode="bicubic", align_corners=False)
+    assert int(h0) == grid.shape[-2] and int(w0) == grid.shape[-1]
+    return torch.cat((pos[:, 0].unsqueeze(0), grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+
+
+def vit_max_grid(max_dimension, patch):
+    """HybridEmbed.__init__ (patchembed.py:74-113): patch grid of the max_dimension crop (the reference measures the backbone's
+    output size with a dry run; resnet_out_hw is the same arithmetic)."""
+    fh, fw = resnet_out_hw(*max_dimension)
+    return -(-fh // patch[0]), -(-fw // patch[1])
+
+
+def vit_encoder_v3(img, sd, p, depth, heads, patch=(2, 2), faithful=True, taps=None, bn_train=None, drop=None, pos_mode="prefix",
+                   max_grid=None):
+    """ViTEncoderV3.forward / ViTEncoderV2.forward (seq_modeling/vit_encoder.py:249-268, :208-226; pos_mode "prefix") and
+    ViTEncoder.forward_features (:97-118; pos_mode "interp")."""
     x, pad_info, size = hybrid_embed(img, sd, p + "patch_embed.", patch, faithful, bn_train, drop)
     if taps is not None:
         taps["patch"] = x
     B, n, C = x.shape
     x = torch.cat((sd[p + "cls_token"].expand(B, -1, -1), x), dim=1)
-    x = x + sd[p + "pos_embed"][:, : n + 1]  # flat prefix slice, :260
+    if pos_mode == "interp":
+        GH, GW = max_grid
+        if size["height"] != GH * patch[0] or size["width"] != GW * patch[1]:  # HybridEmbed's flag, patchembed.py:140
+            x = x + interpolated_pos_embed(sd[p + "pos_embed"], max_grid, size, patch)  # :108-109
+        else:
+            x = x + sd[p + "pos_embed"]  # :110-111
+    else:
+        x = x + sd[p + "pos_embed"][:, : n + 1]  # flat prefix slice, :260 / :219
     for i in range(depth):
         x = _vit_block(x, sd, f"{p}blocks.{i}.", heads)
         if taps is not None:
@@ -650,8 +682,14 @@ def forward_encoder(cfg, sd, image, faithful=True, taps=None, bn_train=None, dro
     seq = cfg["SequenceModeling"]
     if seq["name"] == "ViT":
         sp = seq["params"]
+        # create_vit_modeling, vit_encoder.py:292-302
+        patch = tuple(sp["patch_size"])
+        interp = not sp.get("fix_embed", False) and sp.get("interpolate_embed", True)
+        max_dim = (cfg["imgH"], cfg["max_dimension"][1]) if cfg.get("imgH") else cfg["max_dimension"]
         x, pad_info, size = vit_encoder_v3(image, sd, "seqmodeler.SequenceModeling.", sp["depth"],
-                                           sp["num_heads"], tuple(sp["patch_size"]), faithful, taps, bn_train, drop)
+                                           sp["num_heads"], patch, faithful, taps, bn_train, drop,
+                                           pos_mode="interp" if interp else "prefix",
+                                           max_grid=vit_max_grid(max_dim, patch) if interp else None)
         shape = (size["height"] // sp["patch_size"][0], size["width"] // sp["patch_size"][1])
         return x, shape, pad_info
     if seq["name"] == "BiLSTM":
@@ -713,10 +751,14 @@ def ce_loss(logits, target):
 # ---------------------------------------------------------------------------
 # Training step (engine/training.py:76-164): module.train() forward + CE + backward
 # ---------------------------------------------------------------------------
-def is_trainable(key):
+def is_trainable(key, cfg=None):
     """state_dict keys that are nn.Parameters with requires_grad=True in the reference: everything except
-    BatchNorm buffers, the sinusoid tables and the frozen sincos pos_embed (vit_encoder.py:235-237)."""
+    BatchNorm buffers, the sinusoid tables and the frozen sincos pos_embed of ViTEncoderV3 (vit_encoder.py:235-237);
+    the pos_embed of ViTEncoder / ViTEncoderV2 (`cfg` without fix_embed) is a trained table (:44-50)."""
     tail = key.rsplit(".", 1)[-1]
+    if tail == "pos_embed" and cfg is not None:
+        seq = cfg.get("SequenceModeling") or {}
+        return seq.get("name") == "ViT" and not seq["params"].get("fix_embed", False)
     return tail not in ("running_mean", "running_var", "num_batches_tracked", "pe", "pos_embed")
 
 
@@ -741,7 +783,7 @@ def train_forward(cfg, sd, image, text_in, bn_train, drop=None, flags=None):
 def train_step_grads(cfg, sd, image, text, drop=None, flags=None):
     """forward_step + loss.backward() (engine/training.py:83-88,126,137): text [B,L+1] with [GO] first;
     the model sees text[:, :-1], the target is text[:, 1:].  Returns (loss, logits, {key: grad}, bn_train)."""
-    params = {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and is_trainable(k)) else v)
+    params = {k: (v.detach().clone().requires_grad_(True) if (v.is_floating_point() and is_trainable(k, cfg)) else v)
               for k, v in sd.items()}
     bn_train = {}
     logits = train_forward(cfg, params, image, text[:, :-1], bn_train, drop, flags)

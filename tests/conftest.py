@@ -37,15 +37,16 @@ def oracle_state_dict(cfg_name, manifest, max_seq_len, wseed=1234, end_bias=0.0)
     from oracle import restatement as R
 
     cfg = synth.make_config(cfg_name, max_seq_len=max_seq_len)
+    learned = synth.learned_pos_embed(cfg)  # ViTEncoder / ViTEncoderV2: pos_embed is a seeded weight, not the sincos table
     sd = {}
     for k, shape in manifest.items():
         if k.endswith("image_positional_encoder.pe"):
             continue  # 8 GB table in the reference; the oracle builds the crop it needs
         dt = torch.long if k.endswith("num_batches_tracked") else torch.float32
         eb = end_bias if k.endswith(("Prediction.proj.bias", "attention_cell.generator.bias")) else 0.0
-        key = (k, tuple(shape), dt, wseed, eb)
+        key = (k, tuple(shape), dt, wseed, eb, learned and k.endswith("pos_embed"))
         if key not in _SYNTH_CACHE:  # shared with engine_model: the same seeded tensor for the oracle and the engine
-            _SYNTH_CACHE[key] = synth.synth_tensor(k, shape, dt, seed=wseed, end_bias=eb)
+            _SYNTH_CACHE[key] = synth.synth_tensor(k, shape, dt, seed=wseed, end_bias=eb, learned_pos=learned)
         t = _SYNTH_CACHE[key]
         if t is None:
             if k.endswith("pos_embed"):
@@ -58,7 +59,7 @@ def oracle_state_dict(cfg_name, manifest, max_seq_len, wseed=1234, end_bias=0.0)
     return cfg, sd
 
 
-def _cached_synth_state_dict(tmpl, seed, end_bias):
+def _cached_synth_state_dict(tmpl, seed, end_bias, learned=False):
     """synth.synth_state_dict with the seeded tensors kept across tests (a tensor depends only on its key, shape, dtype, the
     seed and -- for the two biases that carry it -- end_bias): most of the ~200 engine models the GPU suite builds share a
     backbone, and generating 50 M Philox normals per model was a third of the suite's wall time.  The cached tensors are
@@ -67,9 +68,9 @@ def _cached_synth_state_dict(tmpl, seed, end_bias):
     out = {}
     for k, t in tmpl.items():
         eb = end_bias if k.endswith(("Prediction.proj.bias", "attention_cell.generator.bias")) else 0.0
-        key = (k, tuple(t.shape), t.dtype, seed, eb)
+        key = (k, tuple(t.shape), t.dtype, seed, eb, learned and k.endswith("pos_embed"))
         if key not in _SYNTH_CACHE:
-            _SYNTH_CACHE[key] = synth.synth_tensor(k, t.shape, t.dtype, seed=seed, end_bias=eb)
+            _SYNTH_CACHE[key] = synth.synth_tensor(k, t.shape, t.dtype, seed=seed, end_bias=eb, learned_pos=learned)
         v = _SYNTH_CACHE[key]
         out[k] = t.detach().clone() if v is None else v  # None: a constructed table (depends on more than its shape)
     return out
@@ -84,7 +85,7 @@ def engine_model(cfg_name, max_seq_len, wseed=1234, end_bias=0.0, beam_size=None
     tmpl = {k: v for k, v in m.state_dict().items() if not k.endswith("image_positional_encoder.pe")}
     for k in tmpl:
         assert tmpl[k].dtype in (torch.float32, torch.int64), k
-    sd = _cached_synth_state_dict(tmpl, wseed, end_bias)
+    sd = _cached_synth_state_dict(tmpl, wseed, end_bias, synth.learned_pos_embed(cfg))
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.endswith("image_positional_encoder.pe") for k in missing), (missing, unexpected)
     m.eval()

@@ -38,7 +38,7 @@ def test_config_struct_matches_header():
     assert ctypes.sizeof(_lib.D2TConfig) == 4 * len(names)
 
 
-@pytest.mark.parametrize("name", ["C2", "C1", "T2", "C0", "S0", "B0", "TB0", "TO0", "TL0"])
+@pytest.mark.parametrize("name", ["C2", "C1", "T2", "C0", "S0", "B0", "TB0", "TO0", "TL0", "T2V1", "T2V2", "T2V1P"])
 def test_state_dict_keys_and_shapes_match_reference_manifest(manifests, name):
     m = Model(synth.make_config(name))
     sd = m.state_dict()
@@ -58,6 +58,30 @@ def test_parameters_are_real_and_pos_embed_frozen():
     # optimizer construction / clip_grad_norm_ work on the tree
     torch.optim.AdamW([p for p in ps.values() if p.requires_grad], lr=1e-3)
     assert m.seqmodeler.SequenceModeling.patch_embed.grid_size == (1, 9)  # touched by load_checkpoint
+
+
+def test_vit_encoder_variants_follow_create_vit_modeling():
+    """create_vit_modeling (vit_encoder.py:295-302): fix_embed -> ViTEncoderV3 (frozen sincos table, prefix slice); otherwise a
+    learned table read through bicubic interpolation (ViTEncoder) unless interpolate_embed is False (ViTEncoderV2: prefix slice);
+    patching_style '1d' builds TRIGBaseEncoder, whose HybridEmbed1D has no patch_size for build_seq.py:63-66 -- rejected."""
+    from doc2tex_amd import _lib
+    from doc2tex_amd.engine import config_from_opt
+    for name, mode, learned in (("T2", _lib.VIT_POS_SINCOS_PREFIX, False), ("T2V1", _lib.VIT_POS_LEARNED_INTERP, True),
+                                ("T2V2", _lib.VIT_POS_LEARNED_PREFIX, True), ("T2V1P", _lib.VIT_POS_LEARNED_INTERP, True)):
+        cfg = synth.make_config(name)
+        m = Model(cfg)
+        assert config_from_opt(cfg).vit_pos == mode, name
+        pos = dict(m.named_parameters())["seqmodeler.SequenceModeling.pos_embed"]
+        assert pos.requires_grad == learned, name
+        assert synth.learned_pos_embed(cfg) == learned
+        if learned:  # trunc_normal_(std=0.02), vit_encoder.py:50
+            assert 0.015 < float(pos.std()) < 0.025
+    assert Model(synth.make_config("T2V1")).seqmodeler.SequenceModeling.patch_embed.grid_size == (3, 17)
+    assert Model(synth.make_config("T2V1P")).seqmodeler.SequenceModeling.patch_embed.grid_size == (1, 8)
+    cfg = synth.make_config("T2V1")
+    cfg["SequenceModeling"]["params"]["patching_style"] = "1d"
+    with pytest.raises(NotImplementedError, match="1d"):
+        Model(cfg)
 
 
 def test_load_state_dict_roundtrip_and_strict(manifests):

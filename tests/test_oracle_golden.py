@@ -17,7 +17,12 @@ GREEDY = ["t2_greedy", "t2_greedy_early", "t2_greedy_late", "t1_greedy", "c2_sma
           # re-checked by tools/make_golden.py at generation time and on the GPU box, not here
           "c4_greedy_128", "c4_greedy_96",
           # the other cells / inputs of the LSTM-attention head: Bahdanau, one-hot targets (seq2seq.py:31-53,72-78)
-          "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy"]
+          "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy",
+          # round 4: ViTEncoder (learned table through bicubic interpolation: the table's own grid, smaller, one direction only,
+          # larger than max_dimension; 1 x 2 patches: same token count on a square feature map, and interpolated) and
+          # ViTEncoderV2 (learned table, prefix slice) -- vit_encoder.py:22-118, :207-226
+          "v1_greedy_full", "v1_greedy_small", "v1_greedy_mid", "v1_greedy_narrow", "v1_greedy_big", "v1p_greedy_samecount",
+          "v1p_greedy_interp", "v2_greedy_small", "v2_greedy_full"]
 
 
 def _case(cases, kind, name):
@@ -149,7 +154,7 @@ def gc_drop_from_seed(seed):
 
 @pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step", "c3_train_step", "t2g_train_step",
                                   "t1g_train_step", "c0_train_step", "b0_train_step", "tb0_train_step",
-                                  "to0_train_step"])
+                                  "to0_train_step", "v1_train_step", "v1_train_step_full", "v2_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """module.train() step of the oracle (BN batch statistics, teacher forcing, CE, autograd) against the
     reference's loss, logits, gradient samples / norms and updated BatchNorm running statistics."""

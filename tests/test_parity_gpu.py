@@ -48,7 +48,12 @@ def _run_engine(c, B=None):
                                   # each bucket of SURVEY 8d, and configs[1] at its full 151 steps
                                   "c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full",
                                   # Bahdanau cell, one-hot targets (the remaining branches of Attention.__init__)
-                                  "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy"])
+                                  "b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy",
+                                  # ViTEncoder: learned position table through the bicubic resize kernel (the table's own
+                                  # grid / smaller / one direction / beyond max_dimension; 1 x 2 patches: same token count on
+                                  # a square feature map, and resized); ViTEncoderV2: learned table, prefix slice
+                                  "v1_greedy_full", "v1_greedy_small", "v1_greedy_mid", "v1_greedy_narrow", "v1_greedy_big",
+                                  "v1p_greedy_samecount", "v1p_greedy_interp", "v2_greedy_small", "v2_greedy_full"])
 def test_greedy_vs_reference_fixture(cases, name):
     c = _case(cases, "greedy", name)
     z = np.load(os.path.join(GOLD, name + ".npz"))

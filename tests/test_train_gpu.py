@@ -86,7 +86,7 @@ def _check_instance(m, ograds):
 
 
 @pytest.mark.parametrize("name", ["t2_train_step", "t1_train_step", "ts0_train_step", "c0_train_step", "b0_train_step",
-                                  "tb0_train_step", "to0_train_step"])
+                                  "tb0_train_step", "to0_train_step", "v1_train_step", "v1_train_step_full", "v2_train_step"])
 def test_train_step_matches_reference_fixture(cases, manifests, name):
     """Loss, logits, BatchNorm running statistics and gradient norms of the reference's own step (fixture):
     HybridViT + TFM (t2), ResNet + PositionalEncoding2D + TFM with d_model 512 (t1), and HybridViT + Attnv2 -- the
@@ -118,6 +118,17 @@ def test_train_step_matches_reference_fixture(cases, manifests, name):
         assert abs(float(params[k].grad.double().norm()) - norm) <= 3e-2 * max(norm, 1e-6), k
     if name == "t2_train_step":
         assert params["seqmodeler.SequenceModeling.pos_embed"].grad is None  # frozen (vit_encoder.py:235-237)
+    if name.startswith(("v1_", "v2_")):
+        # ViTEncoder / ViTEncoderV2 train their position table (vit_encoder.py:44-50): through the transpose of the bicubic
+        # resize (v1, 48x64 crops under the 96x128 table), directly (v1 full), through the prefix slice (v2: the rows past the
+        # crop's tokens receive exactly zero)
+        k = "seqmodeler.SequenceModeling.pos_embed"
+        g, og = params[k].grad.cpu(), ograds[k]
+        assert float((g - og).norm()) <= 1e-2 * float(og.norm()), float((g - og).norm()) / float(og.norm())
+        if name == "v2_train_step":
+            n = 1 + 1 * 9  # 48x64 crop: patch grid 1 x 9
+            assert float(og[:, n:].abs().max()) == 0.0 and float(g[:, n:].abs().max()) == 0.0
+            assert float(g[:, :n].abs().min()) > 0.0
     m.eval()  # the model still serves inference, now with the updated running statistics
     with torch.no_grad():
         go = (torch.zeros(c["B"], c["max_seq_len"] + 1, dtype=torch.long) if name.startswith(("ts0", "c0", "b0", "tb0", "to0"))

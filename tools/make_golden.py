@@ -72,6 +72,22 @@ GREEDY_CASES = [
     ("tb0_greedy", "TB0", 2, 48, 64, 12, 1234, 1082, 0.0, False),
     ("to0_greedy", "TO0", 2, 48, 64, 12, 1234, 1083, 0.0, False),
 ]
+# round 4 -- the ViT encoders beside ViTEncoderV3 (vit_encoder.py:22-118, :207-226): learned position table read through
+# bicubic interpolation (T2V1: max grid 3 x 17; crops whose grid is the table's own, smaller in both directions, smaller in
+# one, LARGER than max_dimension; T2V1P: 1 x 2 patches -- a crop with the table's token count on a square feature map takes
+# the table as is, :66-67, another is interpolated) or as a prefix slice (T2V2)
+VITPOS_GREEDY_CASES = [
+    ("v1_greedy_full", "T2V1", 2, 96, 128, 12, 1234, 1090, 0.0, False),
+    ("v1_greedy_small", "T2V1", 2, 48, 64, 12, 1234, 1091, 0.0, False),
+    ("v1_greedy_mid", "T2V1", 1, 64, 96, 12, 1234, 1092, 0.0, False),
+    ("v1_greedy_narrow", "T2V1", 1, 96, 64, 12, 1234, 1093, 0.0, False),
+    ("v1_greedy_big", "T2V1", 1, 128, 160, 12, 1234, 1094, 0.0, False),
+    ("v1p_greedy_samecount", "T2V1P", 2, 80, 12, 12, 1234, 1095, 0.0, False),
+    ("v1p_greedy_interp", "T2V1P", 1, 48, 64, 12, 1234, 1096, 0.0, False),
+    ("v2_greedy_small", "T2V2", 2, 48, 64, 12, 1234, 1097, 0.0, False),
+    ("v2_greedy_full", "T2V2", 1, 96, 128, 12, 1234, 1098, 0.0, False),
+]
+GREEDY_CASES += VITPOS_GREEDY_CASES
 A15_GREEDY = ("b0_greedy", "b0_greedy_early", "tb0_greedy", "to0_greedy")
 ROUND2_GREEDY = ("c4_greedy_160", "c4_greedy_128", "c4_greedy_96", "c1_greedy_full")
 BEAM_CASES = [
@@ -119,6 +135,11 @@ TRAIN_STEP_CASES = [("t2_train_step", "T2", 3, 48, 64, 24, 1234, 1030), ("t1_tra
                     # Bahdanau cell with one-hot targets and a zero initial state, coverage cell with one-hot targets
                     ("b0_train_step", "B0", 3, 32, 160, 24, 1234, 1037), ("tb0_train_step", "TB0", 3, 48, 64, 24, 1234, 1038),
                     ("to0_train_step", "TO0", 3, 48, 64, 24, 1234, 1039)]
+# round 4 -- training the learned position tables: through the bicubic resize (48x64 crops under a 96x128 table), with the
+# table read as it is (crop = max_dimension), and the prefix slice of ViTEncoderV2 (rows past the crop's tokens get zero)
+VITPOS_TRAIN_CASES = [("v1_train_step", "T2V1", 3, 48, 64, 24, 1234, 1100), ("v1_train_step_full", "T2V1", 2, 96, 128, 24, 1234, 1101),
+                      ("v2_train_step", "T2V2", 3, 48, 64, 24, 1234, 1102)]
+TRAIN_STEP_CASES += VITPOS_TRAIN_CASES
 LOGIT_STRIDE = {"c3_train_step": 8}  # store every 8th position of the [B, 151, V] logits (fixture size)
 GRAD_SAMPLES = 48
 GC_MASK_SEED = 99  # seeded keep masks of the GlobalContext blocks' dropout in the *g_train_step fixtures
@@ -135,8 +156,9 @@ def build_ref(cfg_name, max_seq_len, beam_size=None, wseed=1234, end_bias=0.0):
     tmpl = m.state_dict()
     # the C1 table is (512,2000,2000) fp32 = 8 GB: never copy it
     sd = {}
+    learned = synth.learned_pos_embed(cfg)  # ViTEncoder / ViTEncoderV2: pos_embed is a trained table, seeded like a weight
     for k, v in tmpl.items():
-        t = synth.synth_tensor(k, v.shape, v.dtype, seed=wseed, end_bias=end_bias)
+        t = synth.synth_tensor(k, v.shape, v.dtype, seed=wseed, end_bias=end_bias, learned_pos=learned)
         sd[k] = v if t is None else t
     m.load_state_dict(sd)
     m.eval()
@@ -160,7 +182,14 @@ def slim_sd(sd):
 
 def check_tables(cfg, sd, report):
     p = "seqmodeler.SequenceModeling."
-    if p + "pos_embed" in sd:
+    if p + "pos_embed" in sd and synth.learned_pos_embed(cfg):
+        sp = cfg["SequenceModeling"]["params"]
+        GH, GW = R.vit_max_grid(cfg["max_dimension"], tuple(sp["patch_size"]))
+        assert tuple(sd[p + "pos_embed"].shape) == (1, GH * GW + 1, sp["hidden_size"]), sd[p + "pos_embed"].shape
+        report["pos_embed_sum"] = float(sd[p + "pos_embed"].double().sum())
+        report["pos_embed_abs"] = float(sd[p + "pos_embed"].double().abs().sum())
+        report["max_grid"] = [GH, GW]
+    elif p + "pos_embed" in sd:
         gh, gw = R.resnet_out_hw(*cfg["max_dimension"])
         gh, gw = -(-gh // 2), -(-gw // 2)
         t = R.sincos_2d_table(sd[p + "pos_embed"].shape[-1], gh, gw)
@@ -508,6 +537,26 @@ def main():
             print("train_dropout", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], flush=True)
         for cn in ("T2D", "TS0D"):
             manifests[cn] = manifest(build_ref(cn, 24)[2])
+        with open(os.path.join(GOLD, "cases.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        with open(os.path.join(GOLD, "manifests.json"), "w") as f:
+            json.dump(manifests, f)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "vitpos":  # add / refresh only the ViTEncoder / ViTEncoderV2 fixtures (round 4)
+        with open(os.path.join(GOLD, "cases.json")) as f:
+            summary = json.load(f)
+        with open(os.path.join(GOLD, "manifests.json")) as f:
+            manifests = json.load(f)
+        for case in VITPOS_GREEDY_CASES:
+            rep, man, cname = run_greedy(case)
+            manifests[cname] = man
+            summary["greedy"] = [r for r in summary["greedy"] if r["case"] != rep["case"]] + [rep]
+            print("greedy", rep["case"], "steps", rep["steps"], "dmem", rep["diff_mem_folded"], "dlogit", rep["diff_logits_cached"],
+                  "gap", rep["min_top2_gap"], f'{rep["seconds"]}s', flush=True)
+        for case in VITPOS_TRAIN_CASES:
+            rep = run_train_step(case)
+            summary["train_step"] = [r for r in summary["train_step"] if r["case"] != rep["case"]] + [rep]
+            print("train_step", rep["case"], rep["loss"], rep["oracle_worst_rel_grad_diff"], f'{rep["seconds"]}s', flush=True)
         with open(os.path.join(GOLD, "cases.json"), "w") as f:
             json.dump(summary, f, indent=1)
         with open(os.path.join(GOLD, "manifests.json"), "w") as f:
