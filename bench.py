@@ -497,7 +497,9 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             others = ["bf16x3"] if precision in ("fp16x2", "mixed") else (["mixed", "fp16x2"] if name in ("C2", "C4") else [])
             what = {"bf16x3": "split-bf16 arithmetic (three bf16 MFMAs per product): the default",
                     "fp16x2": "the backbone's feature maps as fp16 records and its convolutions as x16 * w_lo + x16 * w_hi (two MFMAs "
-                              "per product instead of three) in EVERY split-record layer: 5x margin to the logits bar (opt-in)",
+                              "per product instead of three) in EVERY split-record layer: 5x margin to the logits bar (opt-in; it is "
+                              "also what a forward under the caller's torch.autocast runs -- the reference's --amp, api/infer.py:120-124, "
+                              "whose own fp16 path sits 3e-3 from its fp32 logits on this config)",
                     "mixed": f"split-bf16 with the two-MFMA fp16 arithmetic in the first {model.mixed_units} of the backbone's eight plain "
                              "512->512 units only, fp16 hi|lo records between them (opt-in; >= 10x margin to the logits bar on this "
                              "config: DESIGN.md section 3)"}

@@ -194,6 +194,13 @@ class Model(nn.Module):
         #             grows with the square root of the number of such layers;
         #   'fp32'    exact fp32 matrix-core arithmetic.
         # D2T_CONV_PRECISION=auto|bf16x3|fp16x2|mixed|fp32 overrides the default; 'auto' is 'bf16x3'.
+        # The reference's --amp (api/infer.py:120-124,157-161; engine/inferencing.py:68-72,149-153) wraps the model call in
+        # torch.autocast: its convolutions and linears then run on fp16 operands and return fp16 (measured on the reference
+        # itself, CPU autocast(float16): max |dlogit| 3e-3 on C2, 7e-3 on T2 against its own fp32 path).  A forward of an
+        # eval()-mode HybridViT stack that the caller runs under torch.autocast("cuda") therefore takes `amp_conv_precision`
+        # ('fp16x2': 2e-4 on C2, 17x closer to fp32 than the reference's AMP path; None: autocast changes nothing) -- outputs
+        # stay fp32.  An explicit conv_precision / D2T_CONV_PRECISION always wins, and training steps keep their arithmetic.
+        self.amp_conv_precision = "fp16x2"
         prec = os.environ.get("D2T_CONV_PRECISION", "auto")
         self._precision_auto = prec == "auto"
         if prec == "auto":
@@ -321,8 +328,23 @@ class Model(nn.Module):
         self._conv_precision = mode
         self._precision_auto = False
 
+    def _under_amp(self):
+        """True when the caller's torch.autocast("cuda") asks for reduced precision and this model may follow it."""
+        if not (self._precision_auto and self.amp_conv_precision) or self.training or self.stages["Seq"] != "ViT":
+            return False
+        import torch
+        try:
+            return bool(torch.is_autocast_enabled("cuda"))
+        except TypeError:  # older signature: no device argument, CUDA implied
+            return bool(torch.is_autocast_enabled())
+
     def effective_conv_precision(self):
-        """The arithmetic the next forward runs in (an 'auto' fp16x2 steps back to bf16x3 for other convolution kernels)."""
+        """The arithmetic the next forward runs in (an 'auto' fp16x2 steps back to bf16x3 for other convolution kernels;
+        under the caller's torch.autocast an 'auto' model takes amp_conv_precision)."""
+        if self._under_amp() and self.conv_kernel == "pipelined16":
+            if self.amp_conv_precision not in ("fp16x2", "mixed", "bf16x3"):
+                raise ValueError(f"amp_conv_precision must be 'fp16x2', 'mixed', 'bf16x3' or None, not {self.amp_conv_precision!r}")
+            return self.amp_conv_precision
         if self._precision_auto and self._conv_precision in ("fp16x2", "mixed") and self.conv_kernel != "pipelined16":
             return "bf16x3"
         return self._conv_precision

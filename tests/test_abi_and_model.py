@@ -245,3 +245,12 @@ def test_mixed_precision_and_kernel_choices_on_the_model(monkeypatch):
     for sym in ("d2t_set_mixed_units", "d2t_set_conv_fusion"):
         assert sym in _lib.SIGNATURES
     assert "d2t_set_conv_winograd" not in _lib.SIGNATURES
+
+
+def test_amp_arithmetic_is_declared_and_inert_without_a_gpu(monkeypatch):
+    """`amp_conv_precision` (what a forward under the caller's torch.autocast("cuda") runs in, the reference's --amp) defaults
+    to fp16x2; without CUDA autocast nothing changes."""
+    monkeypatch.delenv("D2T_CONV_PRECISION", raising=False)
+    m = Model(synth.make_config("T2")).eval()
+    assert m.amp_conv_precision == "fp16x2"
+    assert not m._under_amp() and m.effective_conv_precision() == "bf16x3"

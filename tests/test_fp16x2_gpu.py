@@ -177,3 +177,46 @@ def test_mixed_precision_is_shard_invariant(cases):
         p, l, _ = m(img, text, is_train=False)
         parts = [m(img[i:i + n], text[i:i + n], is_train=False) for i, n in ((0, 1), (1, 2), (3, 3))]
     assert torch.equal(p, torch.cat([q[0] for q in parts])) and torch.equal(l, torch.cat([q[1] for q in parts]))
+
+
+def test_forward_under_the_callers_autocast_takes_the_amp_arithmetic(cases, monkeypatch):
+    """The reference's --amp wraps the model call in torch.autocast (api/infer.py:120-124, engine/inferencing.py:68-72): its
+    convolutions then run on fp16 operands (its own fp16-autocast path is 3e-3 .. 7e-3 away from its fp32 logits, measured on
+    the reference).  An eval-mode HybridViT model with the default ('auto') arithmetic follows the caller's autocast into
+    `amp_conv_precision` = fp16x2 -- bit-identical to asking for fp16x2, tokens of the fixture exact, logits within the 1e-3 bar,
+    outputs still fp32 -- and returns to split-bf16 outside it.  An explicit conv_precision, amp_conv_precision = None, a
+    training-mode model and the ResNet-only stack (whose fp16x2 error is of the reference's AMP size) do not follow."""
+    monkeypatch.delenv("D2T_CONV_PRECISION", raising=False)
+    c = _case(cases, "greedy", "c2_small_crop")
+    z = np.load(os.path.join(GOLD, "c2_small_crop.npz"))
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"]).cuda()
+    text = torch.full((c["B"], 1), R.GO, dtype=torch.long, device="cuda")
+    _, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    assert m.amp_conv_precision == "fp16x2" and m.effective_conv_precision() == "bf16x3"
+    with torch.no_grad():
+        p0, l0, _ = m(img, text, is_train=False)
+        with torch.autocast("cuda"):
+            assert m.effective_conv_precision() == "fp16x2"
+            p1, l1, _ = m(img, text, is_train=False)
+        assert m.effective_conv_precision() == "bf16x3"
+        p2, l2, _ = m(img, text, is_train=False)
+    assert l1.dtype == torch.float32
+    assert torch.equal(l0, l2) and not torch.equal(l0, l1)
+    _, mf = _model(c)  # explicit fp16x2
+    with torch.no_grad():
+        pf, lf, _ = mf(img, text, is_train=False)
+    assert torch.equal(l1, lf) and torch.equal(p1, pf)
+    assert np.array_equal(p1.cpu().numpy(), z["tokens"])
+    steps = z["logit_steps"].tolist()
+    assert float(np.abs(l1[:, steps].cpu().numpy() - z["logits_sample"]).max()) <= LOGIT_TOL
+    with torch.autocast("cuda"):
+        m.amp_conv_precision = None
+        assert m.effective_conv_precision() == "bf16x3"
+        m.amp_conv_precision = "fp16x2"
+        m.train()
+        assert m.effective_conv_precision() == "bf16x3"
+        m.eval()
+        m.conv_precision = "bf16x3"  # explicit: autocast does not override it
+        assert m.effective_conv_precision() == "bf16x3"
+        _, t1 = engine_model("T1", 12)
+        assert t1.effective_conv_precision() == "bf16x3"

@@ -586,3 +586,40 @@ def test_weights_follow_the_optimizer_between_steps(cases):
     rc = eng.lib.d2t_reload_weights(eng.ctx, 1, (C.c_char_p * 1)(b"no.such.tensor"), (C.c_void_p * 1)(bad.data_ptr()),
                                     (C.c_int64 * 1)(7), _lib.stream_of(bad))
     assert rc != 0
+
+
+def test_training_step_under_autocast_and_grad_scaler(cases):
+    """train_one_step with use_amp (engine/training.py:118-136): forward_step inside torch.autocast, scaler.scale(loss).backward(),
+    scaler.unscale_, clip_grad_norm_, scaler.step.  The engine's step keeps its own arithmetic under the caller's autocast (fp32
+    logits out, fp32 gradients in every parameter), the scaled backward is the plain one times a power of two -- after
+    unscale_ the gradients are the plain step's -- and the scaler finds them finite and lets the optimizer step."""
+    c = _case(cases, "train_step", "t2_train_step")
+    _, m = _train_model(c["config"], c["max_seq_len"], c["wseed"], precision="bf16x3")
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    text = train_step_labels(c)
+    loss0, _ = _step(m, img, text)
+    plain = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12)
+    m.train()
+    m.zero_grad()
+    with torch.autocast("cuda"):
+        assert m.effective_conv_precision() == "bf16x3"  # training steps do not follow the autocast (Model.amp_conv_precision)
+        _, preds, _ = m(img.cuda(), text[:, :-1].cuda())
+        assert preds.dtype == torch.float32
+        cost = torch.nn.functional.cross_entropy(preds.view(-1, preds.shape[-1]), text[:, 1:].cuda().contiguous().view(-1),
+                                                 ignore_index=0, reduction="none")
+    loss = cost.mean()
+    assert abs(float(loss.detach()) - float(loss0)) <= 1e-6 * max(1.0, abs(float(loss0)))
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    for k, p in m.named_parameters():
+        if k in plain:
+            assert p.grad.dtype == torch.float32
+            assert float((p.grad - plain[k]).abs().max()) <= 1e-6 * max(1e-12, float(plain[k].abs().max())), k
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+    before = {k: p.detach().clone() for k, p in m.named_parameters() if p.requires_grad}
+    scaler.step(opt)
+    scaler.update()
+    assert scaler.get_scale() == 2.0 ** 12  # no inf / nan found: the step was taken, the scale kept
+    assert any(not torch.equal(p.detach(), before[k]) for k, p in m.named_parameters() if k in before)
