@@ -55,6 +55,19 @@ __device__ __forceinline__ void wait_vm() {
   // s_waitcnt simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; leave expcnt / lgkmcnt untouched (max)
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
+#ifdef D2T_PROBES
+// probe builds: thread 0 of block 0 (a compute wave that is not staggered) adds the time between consecutive marks of a tile
+// (s_memrealtime, 10 ns ticks) to d2t_conv_phase[k]; [15] counts tiles.  tools/probe/conv_phases.py
+__device__ unsigned long long d2t_conv_phase[16];
+#define CONV_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&d2t_conv_phase[k], now_ - cphase_t_); cphase_t_ = now_; } } while (0)
+#define CONV_PHASE_INIT() unsigned long long cphase_t_ = __builtin_amdgcn_s_memrealtime()
+#define CONV_PHASE_TILE() do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&d2t_conv_phase[15], 1ull); } while (0)
+#else
+#define CONV_PHASE(k) do { } while (0)
+#define CONV_PHASE_INIT() do { } while (0)
+#define CONV_PHASE_TILE() do { } while (0)
+#endif
 }  // namespace
 
 // Second phase of the wide epilogue (conv_common.h conv_epilogue_wide), run by EVERY thread of the block, loader waves
@@ -368,9 +381,12 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
   const int G = gridDim.x, xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7;
   const int slot = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
 
+  CONV_PHASE_INIT();
   for (int tile = slot; tile < ntiles; tile += G) {
     const int m0 = p.m_base + (tile / nt) * BM;
     const int n0 = (tile % nt) * BN;
+    CONV_PHASE(0);  // previous tile's last barrier .. here (loop overhead; the first tile: kernel entry)
+    CONV_PHASE_TILE();
     if (loader) {  // (the compute waves below run the same barrier sequence)
       Issuer dma;
       dma.setup(p, m0, n0, wave - NW, lane);
@@ -457,6 +473,7 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
     if (!late) {
       for (int kt = 0; kt < KT; ++kt) {
         __builtin_amdgcn_s_barrier();  // stage kt (and kt + 1) complete for everyone; nobody reads the stages before
+        if (kt == 0) CONV_PHASE(1);  // setup + the first two stages' LDS-DMA landed (pipeline fill)
         const unsigned char* ah = smem + cur * STAGE;
         // all sixteen fragment reads of the K-step go out before the first MFMA (the SIMD partner's carried MFMAs cover
         // their latency); left to itself the compiler interleaves them in three groups, each with its own wait
@@ -495,8 +512,10 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
       for (int kt = 1; kt < KT; ++kt) step(H1{}, kt);
       mma(H1{}, gah, gal, gbh, gbl);
     }
+    CONV_PHASE(2);  // the K loop of this wave
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with the last stages: the staging area becomes the epilogue's fp32 tile
+    CONV_PHASE(3);  // waiting for the other waves (staggered partners finish half a K-step later)
     // C/D map of v_mfma_f32_16x16x32: col = lane & 15 -> n, row = 4 * (lane >> 4) + reg -> m
     if (wide_epilogue_ok(p)) {  // block-uniform
       float* tile_f = reinterpret_cast<float*>(smem);
@@ -512,14 +531,17 @@ __device__ __forceinline__ void conv_bf16x3p16_body(const ConvP& p, unsigned cha
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      CONV_PHASE(4);  // accumulators to the LDS tile + barrier
       if (p.pool2) epilogue_rows_pool<BM, BN, NT>(p, smem, m0, n0, tid);
       else epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid);
+      CONV_PHASE(5);  // this thread's rows: LDS reads, bias / residual / activation / split, stores issued
     } else {
       __builtin_amdgcn_s_barrier();
       conv_epilogue16<MI, NJ>(p, acc, m0 + wm * WTM, n0 + wn * WTN, r, q);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the tile is staging memory again (next tile's LDS-DMA)
+    CONV_PHASE(6);  // waiting for the slowest thread's epilogue
   }
 }
 
@@ -635,4 +657,17 @@ hipError_t launch_conv_bf16x3p(const ConvP& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef D2T_PROBES
+}  // namespace d2t
+extern "C" int d2t_debug_conv_phases(unsigned long long* out, int reset) {  // probe builds: read (and clear) d2t_conv_phase
+  hipDeviceSynchronize();
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(d2t::d2t_conv_phase), 16 * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d2t::d2t_conv_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace d2t {
+#endif
 }  // namespace d2t

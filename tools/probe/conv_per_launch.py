@@ -27,7 +27,7 @@ with torch.no_grad():
 recs = eng.profile_read(65536)
 per = len(recs) // reps
 assert per * reps == len(recs), (len(recs), reps)
-print(f"{per} GEMM launches per forward, {reps} forwards")
+print(f"{per} GEMM launches per forward, {reps} forwards, {sum(r[3] for r in recs) / reps:.3f} ms of GEMM launches per forward")
 print(f"{'#':>3} {'M':>8} {'N':>5} {'K':>5} {'avg ms':>8} {'min ms':>8} {'tiles/256':>9} {'us/round':>8}")
 for i in range(per):
     M, N, K = recs[i][:3]
