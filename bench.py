@@ -472,7 +472,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
     #   fp32            -- the exact-fp32 arithmetic mode (--precision fp32), fewer steps
     secondary = {}
     if not early and secondary_runs:
-        e2, _, _ = timed(steps, warmup, with_transfers=True)
+        e2, _, o2 = timed(steps, warmup, with_transfers=True)
         # SURVEY 8d quotes the metric with the H2D of the batch and the D2H of the ids inside the region; the task's bench contract
         # asks for `value` with inputs resident in HBM.  Both are in the line: `value` = resident, this = SURVEY 8d's definition.
         secondary["incl_transfers"] = {
@@ -480,11 +480,12 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
             "metric_definition": "SURVEY.md 8d (PCIe-inclusive): the rate a caller holding host buffers sees; `value` is the "
                                  "HBM-resident rate the bench contract asks for",
             "what": f"as `value`, plus per step the H2D copy of the batch ({host_img.numel() * 4 / 1e6:.1f} MB from pinned host "
-                    "memory, on a copy stream) and, before the region ends, the D2H copy of every batch's token ids"}
+                    "memory, on a copy stream) and, before the region ends, the D2H copy of every batch's token ids",
+            "_out": (o2[0], o2[1])}  # (its last batch is checked against the oracle like the headline's: main())
         if precision in ("bf16x3", "fp16x2", "mixed"):
             k3 = max(4, steps // 4)
             model.conv_precision = "fp32"
-            e3, r3, _ = timed(k3, 2)
+            e3, r3, o3 = timed(k3, 2)
             model.conv_precision = precision
             if rank == 0:
                 secondary["fp32"] = {
@@ -492,7 +493,7 @@ def serving_bench(args, name, rank, world, dev, dist, secondary_runs=True, steps
                     "steps": k3, "dtype": "f32",
                     "what": "same workload and serving configuration with exact fp32 arithmetic on the fp32-input MFMA "
                             "(v_mfma_f32_32x32x2_f32) everywhere",
-                    "roofline": roofline_of(r3, "fp32", k3)}
+                    "roofline": roofline_of(r3, "fp32", k3), "_out": (o3[0], o3[1])}
             # the other 16-bit arithmetics beside the headline's, each with its own roofline and its own parity
             others = ["bf16x3"] if precision in ("fp16x2", "mixed") else (["mixed", "fp16x2"] if name in ("C2", "C4") else [])
             what = {"bf16x3": "split-bf16 arithmetic (three bf16 MFMAs per product): the default",
