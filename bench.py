@@ -698,8 +698,10 @@ def beam_bench(dev, n=128, beam=5, per_sample=8):
             m(img[i:i + 1], go, is_train=False, is_test=True)
         torch.cuda.synchronize(dev)
         ds = time.perf_counter() - t1
-    # the same batch with the [s] bias raised (as the early-exit fixtures: +1.8): with the seeded weights some samples then
-    # complete hypotheses at once and others never do, so the completed-hypothesis bookkeeping runs inside a timed region
+    # the same batch with the [s] bias raised (as the early-exit fixtures: +1.8): with the seeded weights [s] then enters the top
+    # five at the first step -- one hypothesis per sample completes there and wins on score / length, the other four rows run on
+    # (the synthetic logits hardly depend on the crop: up to +1.75 nothing completes, from +1.8 this happens for every sample),
+    # so the completed-hypothesis bookkeeping and the shrinking row set run inside a timed region
     m2 = Model(synth.make_config("C4", device=str(dev), beam_size=beam))
     m2.load_state_dict(synth.synth_state_dict({k: v for k, v in m2.state_dict().items()}, end_bias=1.8), strict=False)
     m2 = m2.to(dev).eval()
