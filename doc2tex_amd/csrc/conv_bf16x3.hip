@@ -509,7 +509,10 @@ hipError_t launch_conv_bf16x3(const ConvP& p, hipStream_t s) {
     }
     return hipGetLastError();
   }
-  static const int variant = D2T_PROBE_ENV_STR("D2T_BF16X3_WAVES") ? D2T_PROBE_ENV("D2T_BF16X3_WAVES") : 4;
+  // fp32 rows in (the ViT encoder's linears, M = B * 261: one to two rounds of 128 x 128 tiles): eight waves per tile measured
+  // 15-20 % faster there than four (round 4, tools/probe/conv_per_launch.py: 229 -> 194 us per ViT block); same products in the
+  // same order per output element, so the two are bit-identical
+  static const int variant = D2T_PROBE_ENV_STR("D2T_BF16X3_WAVES") ? D2T_PROBE_ENV("D2T_BF16X3_WAVES") : 8;
   if (p.Cout <= 64) {
     hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2, true>), dim3(mt * ((p.Cout + 63) / 64)), dim3(256), 0, s, p);
   } else if (variant == 4) {
