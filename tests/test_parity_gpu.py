@@ -700,3 +700,28 @@ def test_other_attention_cells_vs_oracle_other_seeds(manifests):
             assert seq[0].tolist() == oseq[0].tolist(), (cname, iseed, eb)
             assert abs(float(score) - oscore) <= 1e-3
             assert both[0][0][0].tolist() == seq[0].tolist() and abs(float(both[0][1]) - float(score)) <= 1e-5
+
+
+def test_resized_position_table_follows_the_weights(cases, manifests):
+    """ViTEncoder (vit_encoder.py:58-95): the engine keeps one bicubic resize of the learned position table per patch grid.
+    When the table changes (an optimizer step, load_state_dict) the resized copies must be rebuilt: encoder memory of a 48x64
+    crop (grid 1 x 9 under the 3 x 17 table) before and after the table is edited in place, each against the oracle."""
+    c = _case(cases, "greedy", "v1_greedy_small")
+    cfg, m = engine_model(c["config"], c["max_seq_len"], c["wseed"], c["end_bias"])
+    ocfg, sd = oracle_state_dict(c["config"], manifests[c["config"]], c["max_seq_len"], c["wseed"], c["end_bias"])
+    img = synth.synth_images(c["B"], c["H"], c["W"], seed=c["iseed"])
+    key = "seqmodeler.SequenceModeling.pos_embed"
+    tol = MEM_TOL[m.effective_conv_precision()]
+    with torch.no_grad():
+        mem0, _, _ = m.forward_encoder(img.cuda())
+        o0, _, _ = R.forward_encoder(ocfg, sd, img, faithful=False)
+        assert float((mem0.cpu() - o0).abs().max()) / max(1.0, float(o0.abs().max())) <= tol
+        g = torch.Generator().manual_seed(5)
+        delta = torch.randn(sd[key].shape, generator=g) * 0.3
+        dict(m.named_parameters())[key].add_(delta.cuda())  # in place: the version counter tells the engine
+        sd2 = dict(sd)
+        sd2[key] = sd[key] + delta
+        mem1, _, _ = m.forward_encoder(img.cuda())
+        o1, _, _ = R.forward_encoder(ocfg, sd2, img, faithful=False)
+    assert float((o1 - o0).abs().max()) > 1e-2  # the edit shows
+    assert float((mem1.cpu() - o1).abs().max()) / max(1.0, float(o1.abs().max())) <= tol
