@@ -7,6 +7,7 @@ bench.py's `incl_transfers` leg, one ingredient at a time:
   d  c + holding every step's token tensor and the D2H at the end  (= bench.py's leg)
   e  c with the H2D issued one step EARLIER (copy for step i+1 enqueued before forward i)
   p  a with the engine's per-launch HIP-event profiling on (what bench.py's headline leg runs with)
+  c1 the copy alone beside the loop (nothing waits for it)      c2  c1 + the forward waits for its copy
 usage: python tools/probe/transfers_ab.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -69,6 +70,17 @@ def run(mode):
             out = fwd(img)
         elif mode == "b":
             out = fwd(bufs[k])
+        elif mode == "c1":  # the copy alone beside the loop: nothing waits for it, the forward reads the resident batch
+            with torch.cuda.stream(cs):
+                bufs[k].copy_(host, non_blocking=True)
+            out = fwd(img)
+        elif mode == "c2":  # + the forward waits for its copy (no buffer hand-back)
+            with torch.cuda.stream(cs):
+                bufs[k].copy_(host, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            main.wait_event(ev)
+            out = fwd(bufs[k])
         elif mode in ("c", "d"):
             ev = h2d(k)
             main.wait_event(ev)
@@ -106,5 +118,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 print(f"H2D alone: {dt * 1e3:.3f} ms per {host.numel() * 4 / 1e6:.1f} MB = {host.numel() * 4 / dt / 1e9:.1f} GB/s", flush=True)
 prime()
-for mode in ("a", "p", "c", "d", "a", "p", "c", "d"):
+for mode in ("a", "c1", "c2", "c", "a", "c1", "c2", "c"):
     run(mode)
