@@ -725,3 +725,39 @@ def test_resized_position_table_follows_the_weights(cases, manifests):
         o1, _, _ = R.forward_encoder(ocfg, sd2, img, faithful=False)
     assert float((o1 - o0).abs().max()) > 1e-2  # the edit shows
     assert float((mem1.cpu() - o1).abs().max()) / max(1.0, float(o1.abs().max())) <= tol
+
+
+def test_smallest_crop_and_crops_the_model_cannot_take(manifests):
+    """Edges of the crop range on the headline stack (HybridViT + TFM-6, max_dimension [128, 512]): the smallest crop the
+    reference's min_dimension [32, 32] lets through (backbone output 1 x 9 -> a 1 x 5 patch grid, six memory tokens) against the
+    oracle; a crop beyond max_dimension, for which ViTEncoderV3's prefix slice `pos_embed[:, :N+1]` is shorter than the token
+    sequence -- the reference raises a RuntimeError on the addition (vit_encoder.py:260), the engine raises one naming the limit;
+    and a crop the backbone reduces to nothing (the reference's convolution raises a RuntimeError there too)."""
+    L = 6
+    cfg, m = engine_model("C2", L)
+    ocfg, sd = oracle_state_dict("C2", manifests["C2"], L)
+    img = synth.synth_images(2, 32, 32, seed=4711)
+    text = torch.full((2, 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        omem, oshape, opad = R.forward_encoder(ocfg, sd, img, faithful=False)
+        opreds, ologits, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=False)
+        mem, shape, pad = m.forward_encoder(img.cuda())
+        preds, logits, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=False)
+    assert tuple(mem.shape) == tuple(omem.shape) == (2, 6, 256)
+    assert tuple(shape) == tuple(oshape) == (1, 5) and tuple(pad) == tuple(opad)
+    assert float((mem.cpu() - omem).abs().max()) / max(1.0, float(omem.abs().max())) <= MEM_TOL[m.effective_conv_precision()]
+    assert torch.equal(preds.cpu(), opreds)
+    assert float((logits.cpu() - ologits).abs().max()) <= LOGIT_TOL
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="max_dimension"):
+            m.forward_encoder(synth.synth_images(1, 160, 640, seed=1).cuda())
+        with pytest.raises(RuntimeError, match="crop"):
+            m.forward_encoder(synth.synth_images(1, 8, 8, seed=1).cuda())
+        with pytest.raises(RuntimeError):  # the oracle (torch ops, like the reference) cannot take them either
+            R.forward_encoder(ocfg, sd, synth.synth_images(1, 160, 640, seed=1), faithful=False)
+        with pytest.raises(RuntimeError):
+            R.forward_encoder(ocfg, sd, synth.synth_images(1, 8, 8, seed=1), faithful=False)
+    # the engine is still usable after the refused calls
+    with torch.no_grad():
+        mem2, _, _ = m.forward_encoder(img.cuda())
+    assert torch.equal(mem2, mem)
