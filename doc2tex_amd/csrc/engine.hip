@@ -872,6 +872,11 @@ int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_
   return D2T_OK;
 }
 
+// Longest encoder memory a decode can attend over.  The absorbed cross-attention of the d_model-256 TFM decoder streams the
+// memory rows in 16-key tiles with a running softmax -- any length (4096 here: the shipped max_dimension [800, 800] gives
+// 2526 tokens); the projected-K/V kernels (d_model 512) and the LSTM-attention heads keep per-row score arrays of 512 entries.
+static int memory_cap(const d2t_ctx* c) { return (c->cfg.decoder == D2T_DEC_TFM && c->dec_absorbed) ? 4096 : 512; }
+
 int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, float* memory, d2t_stream stream) {
   DevGuard dg_(c);
   if (!c || !image || !memory || B < 1) return fail(c, D2T_EINVAL, "bad argument");
@@ -886,7 +891,7 @@ int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, 
   const bool vit = g.encoder == D2T_ENC_HYBRID_VIT;
   if (vit && g.vit_pos != D2T_VIT_POS_LEARNED_INTERP && T > c->pos_rows)  // the prefix slice would run off the table
     return fail(c, D2T_EINVAL, "crop %dx%d exceeds max_dimension (pos_embed rows %d)", H, W, c->pos_rows);
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   // largest activation: conv0_2 output B*H*W*64 floats; ViT needs B*T*max(3*dim, hidden)
   size_t need_floats = (size_t)B * H * W * 64;
   if (vit) {
@@ -1334,7 +1339,7 @@ int d2t_decode_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T, con
   if (!c || !memory || !start_tokens || !tokens || !logits || !steps_out || B < 1 || T < 1)
     return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
   if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
   if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
@@ -1718,7 +1723,7 @@ int d2t_decode_greedy_async(d2t_ctx* c, const float* memory, int32_t B, int32_t 
   DevGuard dg_(c);
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
   if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
   if (int rc = check_dev_ptr(c, logits, "logits")) return rc;
@@ -1731,7 +1736,7 @@ int d2t_decode_greedy_submit(d2t_ctx* c, const float* memory, int32_t B, int32_t
   DevGuard dg_(c);
   if (!c || !memory || !start_tokens || !tokens || !logits || B < 1 || T < 1) return fail(c, D2T_EINVAL, "bad argument");
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "context was not created with the TFM decoder");
   if (rows_per_batch < 0 || (rows_per_batch > 0 && B % rows_per_batch)) return fail(c, D2T_EINVAL, "rows_per_batch must divide the row count");
   if (int rc = check_dev_ptr(c, memory, "memory")) return rc;
@@ -1991,7 +1996,7 @@ int d2t_decode_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t beam_siz
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "beam search is implemented for the TFM decoder only");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = beam_size;
   const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;
@@ -2120,7 +2125,7 @@ int d2t_decode_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32_t T,
   if (!c->finalized) return fail(c, D2T_ESTATE, "weights not finalized");
   if (beam_size < 1 || beam_size > 16) return fail(c, D2T_EINVAL, "beam_size must be in [1,16]");
   if (c->cfg.decoder != D2T_DEC_TFM) return fail(c, D2T_ESTATE, "beam search is implemented for the TFM decoder only");
-  if (T > 512) return fail(c, D2T_EINVAL, "memory length %d > 512 unsupported", T);
+  if (T > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d > %d unsupported", T, memory_cap(c));
   const d2t_config& g = c->cfg;
   const int S = g.max_seq_len + 1, V = g.vocab, d = g.dec_dim, cap = N * beam_size;
   const int heads = g.dec_heads, hd = d / heads, Lmax = g.max_seq_len + 2;

@@ -342,35 +342,27 @@ __global__ __launch_bounds__(512) void vit_attention_kernel(const float* __restr
 // accumulator holds a row in one register across 32 lanes, so the row maximum is a 5-step lane reduction), rescale,
 // P = exp(S - max) staged through a per-wave LDS tile to turn accumulator layout into the A-operand layout, O += P V by
 // 16 more MFMAs.  K rows are padded to 33 floats (conflict-free B-operand reads), V rows are read lane-contiguous.
-// head_dim = 32, N <= 512.
+// head_dim = 32.  Up to 512 tokens the block holds the head's whole K / V in LDS (one chunk; grid = images x heads).  Longer
+// sequences (crops beyond about 180 x 720: the shipped configurations allow up to 448 x 960 = 1695 tokens) take the same
+// loop in CHUNKS of `kct` key tiles staged one after the other -- the running maximum / sum / O carry over, the keys are
+// visited in the same order -- and the queries are split over `qchunks` blocks of up to 16 waves per (image, head).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ y,
-                                                                  int N, int heads, int tiles) {
+                                                                  int N, int heads, int tiles, int kct, int qchunks) {
   // Round 3: the score product is taken TRANSPOSED (S^T = K Q^T: rows = keys, columns = this wave's 32 queries), so a lane
   // holds, for ONE query (its column), 16 of the tile's 32 keys in its accumulator registers -- and that is already the
   // A-operand layout of the second product when MFMA step kk is made to mean "key (kk & 3) + 8 (kk >> 2) + 4 h" (the V rows are
   // simply read in that order).  No LDS tile for P (113 -> 75 KB: two blocks per CU), the row maximum is 16 in-register
   // maxima and one lane exchange instead of sixteen 5-step lane reductions, and the exps are 16 per lane as before.
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int Np = tiles * 32;
+  const int Np = kct * 32;                 // keys per staged chunk
   float* Ks = sm;                          // [Np][33]
   float* Vs = Ks + (size_t)Np * 33;        // [Np][32]
-  const int b = blockIdx.x / heads, hh = blockIdx.x % heads, C = heads * 32;
+  const int bh = blockIdx.x / qchunks, qc = blockIdx.x % qchunks;
+  const int b = bh / heads, hh = bh % heads, C = heads * 32;
   const float* base = qkv + (size_t)b * N * 3 * C;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nthreads = blockDim.x;
-  for (int i = tid; i < Np * 8; i += nthreads) {  // 8 float4 per key row; rows >= N are zero
-    const int j = i >> 3, c = (i & 7) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (j < N) {
-      kv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + C + hh * 32 + c);
-      vv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + 2 * C + hh * 32 + c);
-    }
-    float* kd = Ks + j * 33 + c;
-    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
-    *reinterpret_cast<float4*>(Vs + j * 32 + c) = vv;
-  }
-  __syncthreads();
-  const int r = lane & 31, h = lane >> 5, q0 = wave * 32;
+  const int r = lane & 31, h = lane >> 5, q0 = (qc * 16 + wave) * 32;
   // B operand of S^T: lane (k = h, column = query r) supplies scale * Q[q0 + r][2 kk + h]
   float qb[16];
   {
@@ -384,12 +376,28 @@ __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* _
 #pragma unroll
   for (int e = 0; e < 16; ++e) o[e] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;  // of query q0 + r (both lane halves hold the same values)
-  for (int t = 0; t < tiles; ++t) {
+  for (int t0 = 0; t0 < tiles; t0 += kct) {
+  if (t0) __syncthreads();  // everyone is done with the previous chunk
+  for (int i = tid; i < Np * 8; i += nthreads) {  // 8 float4 per key row; rows >= N are zero
+    const int jl = i >> 3, j = t0 * 32 + jl, c = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (j < N) {
+      kv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + C + hh * 32 + c);
+      vv = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * C + 2 * C + hh * 32 + c);
+    }
+    float* kd = Ks + jl * 33 + c;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(Vs + jl * 32 + c) = vv;
+  }
+  __syncthreads();
+  const int tend = t0 + kct < tiles ? t0 + kct : tiles;
+  for (int t = t0; t < tend; ++t) {
+    const int tl = t - t0;  // tile index inside the staged chunk
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
     // A operand: lane (row = key r of the tile, k = h) supplies K[t*32 + r][2 kk + h]
-    const float* ka = Ks + (size_t)(t * 32 + r) * 33 + h;
+    const float* ka = Ks + (size_t)(tl * 32 + r) * 33 + h;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * kk], qb[kk], sacc, 0, 0, 0);
     // register e of this lane: key t*32 + (e & 3) + 8 (e >> 2) + 4 h, query q0 + r
@@ -415,10 +423,11 @@ __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* _
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] *= __shfl(corr, (e & 3) + 8 * (e >> 2) + 4 * h, 64);
     // O += P V_t with MFMA step kk <-> key (kk & 3) + 8 (kk >> 2) + 4 h: A[query r][k = h] = pe[kk], B[k = h][d = r] = V[that key][r]
-    const float* vb = Vs + (size_t)(t * 32 + 4 * h) * 32 + r;
+    const float* vb = Vs + (size_t)(tl * 32 + 4 * h) * 32 + r;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(pe[kk], vb[(size_t)((kk & 3) + 8 * (kk >> 2)) * 32], o, 0, 0, 0);
+  }
   }
   lrun += __shfl_xor(lrun, 32, 64);  // each half summed its own 16 keys per tile
 #pragma unroll
@@ -432,9 +441,12 @@ __global__ __launch_bounds__(1024) void vit_attention_mfma_kernel(const float* _
 
 hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int heads, hipStream_t s) {
   static const bool valu = D2T_PROBE_ENV_STR("D2T_VIT_ATTN_VALU") != nullptr;
-  if (!valu && N <= 512) {
+  if (!valu) {
     const int tiles = (N + 31) / 32;
-    const size_t lds2 = ((size_t)tiles * 32 * 33 + (size_t)tiles * 32 * 32) * sizeof(float);
+    // up to 512 tokens: the whole head in one chunk, one block per (image, head) -- the launch of rounds 2-3, unchanged;
+    // beyond: 256-key chunks (66 KB: two blocks per CU) and the queries in blocks of sixteen waves
+    const int kct = tiles <= 16 ? tiles : 8, qchunks = (tiles + 15) / 16, waves = tiles < 16 ? tiles : 16;
+    const size_t lds2 = ((size_t)kct * 32 * 33 + (size_t)kct * 32 * 32) * sizeof(float);
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attention_mfma_kernel),
@@ -443,7 +455,8 @@ hipError_t launch_vit_attention(const float* qkv, float* y, int B, int N, int he
       attr2 = true;
     }
     if (lds2 <= 160 * 1024) {
-      hipLaunchKernelGGL(vit_attention_mfma_kernel, dim3(B * heads), dim3(tiles * 64), lds2, s, qkv, y, N, heads, tiles);
+      hipLaunchKernelGGL(vit_attention_mfma_kernel, dim3(B * heads * qchunks), dim3(waves * 64), lds2, s, qkv, y, N, heads, tiles,
+                         kct, qchunks);
       return hipGetLastError();
     }
   }

@@ -761,3 +761,59 @@ def test_smallest_crop_and_crops_the_model_cannot_take(manifests):
     with torch.no_grad():
         mem2, _, _ = m.forward_encoder(img.cuda())
     assert torch.equal(mem2, mem)
+
+
+@pytest.mark.parametrize("H,W,B,L", [(192, 768, 2, 6), (448, 960, 1, 4)])
+def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
+    """The shipped configurations allow crops up to 448 x 960 (config/test.yaml:3: 14 x 121 patches = 1695 memory tokens) and
+    800 x 800; up to round 3 the engine stopped at 512 tokens (the ViT attention kernel held a head's whole K / V in LDS).  The
+    HybridViT + TFM stack on such crops against the oracle: 192 x 768 (583 tokens: two query blocks, three key chunks per head)
+    and 448 x 960 itself -- encoder memory, greedy tokens and logits.  The stacks whose decode keeps 512-entry score rows
+    (LSTM-attention heads, d_model 512) still refuse with an error that names the limit."""
+    from doc2tex_amd import Model
+    cfg = synth.make_config("C2", device="cuda", max_seq_len=L)
+    cfg["max_dimension"] = [H, W]
+    m = Model(cfg)
+    tmpl = {k: v for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(tmpl), strict=False)
+    m = m.cuda().eval()
+    ocfg, sd = oracle_state_dict("C2", manifests["C2"], L)
+    ocfg["max_dimension"] = [H, W]
+    gh, gw = R.vit_max_grid([H, W], (2, 2))
+    sd = dict(sd)
+    sd["seqmodeler.SequenceModeling.pos_embed"] = R.sincos_2d_table(256, gh, gw)
+    assert torch.equal(sd["seqmodeler.SequenceModeling.pos_embed"], m.state_dict()["seqmodeler.SequenceModeling.pos_embed"].cpu())
+    img = synth.synth_images(B, H, W, seed=900 + H)
+    text = torch.full((B, 1), R.GO, dtype=torch.long)
+    with torch.no_grad():
+        omem, oshape, opad = R.forward_encoder(ocfg, sd, img, faithful=False)
+        opreds, ologits, _ = R.forward(ocfg, sd, img, text, is_train=False, is_test=False)
+        mem, shape, pad = m.forward_encoder(img.cuda())
+        preds, logits, _ = m(img.cuda(), text.cuda(), is_train=False, is_test=False)
+    assert tuple(mem.shape) == tuple(omem.shape) == (B, gh * gw + 1, 256) and mem.shape[1] > 512
+    assert tuple(shape) == tuple(oshape) and tuple(pad) == tuple(opad)
+    assert float((mem.cpu() - omem).abs().max()) / max(1.0, float(omem.abs().max())) <= MEM_TOL[m.effective_conv_precision()]
+    assert torch.equal(preds.cpu(), opreds)
+    assert float((logits.cpu() - ologits).abs().max()) <= LOGIT_TOL
+    if H == 192:
+        # beam search over the same long memory (one sample per call, tfm.py:146-148) against the oracle's
+        bcfg = synth.make_config("C2", device="cuda", max_seq_len=L, beam_size=3)
+        bcfg["max_dimension"] = [H, W]
+        mb = Model(bcfg)
+        mb.load_state_dict(synth.synth_state_dict({k: v for k, v in mb.state_dict().items()}, end_bias=1.8), strict=False)
+        mb = mb.cuda().eval()
+        osd = dict(oracle_state_dict("C2", manifests["C2"], L, end_bias=1.8)[1])
+        osd["seqmodeler.SequenceModeling.pos_embed"] = sd["seqmodeler.SequenceModeling.pos_embed"]
+        ob = dict(ocfg)
+        ob["beam_size"] = 3
+        with torch.no_grad():
+            seq, score, _ = mb(img[:1].cuda(), text[:1].cuda(), is_train=False)
+            oseq, oscore, _ = R.forward(ob, osd, img[:1], text[:1], is_train=False)
+        assert seq.tolist() == oseq.tolist() and abs(float(score) - float(oscore)) <= 1e-3
+        scfg = synth.make_config("S0", device="cuda", max_seq_len=L)  # HybridViT + Attnv2: 512-entry alignment rows
+        scfg["max_dimension"] = [H, W]
+        ms = Model(scfg)
+        ms.load_state_dict(synth.synth_state_dict({k: v for k, v in ms.state_dict().items()}), strict=False)
+        ms = ms.cuda().eval()
+        with torch.no_grad(), pytest.raises(RuntimeError, match="512"):
+            ms(img.cuda(), torch.zeros(B, L + 1, dtype=torch.long, device="cuda"), is_train=False)
