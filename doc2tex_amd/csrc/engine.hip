@@ -875,7 +875,10 @@ int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_
 // Longest encoder memory a decode can attend over.  The absorbed cross-attention of the d_model-256 TFM decoder streams the
 // memory rows in 16-key tiles with a running softmax -- any length (4096 here: the shipped max_dimension [800, 800] gives
 // 2526 tokens); the projected-K/V kernels (d_model 512) and the LSTM-attention heads keep per-row score arrays of 512 entries.
-static int memory_cap(const d2t_ctx* c) { return (c->cfg.decoder == D2T_DEC_TFM && c->dec_absorbed) ? 4096 : 512; }
+static int memory_cap(const d2t_ctx* c) {
+  if (c->cfg.decoder == D2T_DEC_ATTN) return 4096;  // two alignment rows of the memory's length in LDS (recurrent.hip AD_MAXT)
+  return c->dec_absorbed ? 4096 : 512;
+}
 
 int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, float* memory, d2t_stream stream) {
   DevGuard dg_(c);
@@ -1355,7 +1358,7 @@ int d2t_decode_attn_greedy(d2t_ctx* c, const float* memory, int32_t B, int32_t T
   if (g.decoder != D2T_DEC_ATTN) return fail(c, D2T_ESTATE, "context was not created with the Attn decoder");
   const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab;
   const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
-  if (T - key_off < 1 || T - key_off > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  if (T - key_off < 1 || T - key_off > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   // workspace: key_proj(memory) [B*T][H] | end_step [B]
@@ -1413,7 +1416,7 @@ int d2t_decode_attn_beam(d2t_ctx* c, const float* memory, int32_t T, int32_t bea
   const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = beam_size;
   const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
   const int Tk = T - key_off;
-  if (Tk < 1 || Tk > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  if (Tk < 1 || Tk > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure(c, &c->dws, &c->dws_cap, ((size_t)T * Hh + 16) * 4))) return rc;
@@ -1561,7 +1564,7 @@ int d2t_decode_attn_beam_batch(d2t_ctx* c, const float* memory, int32_t N, int32
   const int Hh = g.attn_hidden, S = g.batch_max_length + 1, V = g.vocab, cap = N * beam_size;
   const int key_off = g.attn_keys == D2T_ATTN_KEYS_NOCLS_INIT_CLS ? 1 : 0;
   const int Tk = T - key_off;
-  if (Tk < 1 || Tk > 512) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
+  if (Tk < 1 || Tk > memory_cap(c)) return fail(c, D2T_EINVAL, "memory length %d unsupported", T);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure(c, &c->dws, &c->dws_cap, ((size_t)N * T * Hh + 16) * 4))) return rc;

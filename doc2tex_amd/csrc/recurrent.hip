@@ -117,9 +117,10 @@ hipError_t launch_bilstm(const float* g, const float* whh_t, float* out, int B, 
 
 // ---------------------------------------------------------------------------
 // LSTM-attention greedy decoder: one block (1024 threads) per batch row runs every step.
-// D = E = H = 256, V <= 1024, Tk <= 512.
+// D = E = H = 256, V <= 1024, Tk <= 4096 keys (two alignment rows of that length in LDS: 32 of the block's 58 KB; the
+// shipped max_dimension [800, 800] gives 2525).  The backward kernel of the training step keeps six such rows and stays at 512.
 // ---------------------------------------------------------------------------
-constexpr int AD_MAXT = 512;
+constexpr int AD_MAXT = 4096, AD_MAXT_TRAIN = 512;
 
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   constexpr int H = 256;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
 __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTrainBwdP p) {
   constexpr int H = 256;
   __shared__ float dh_s[H], dc_s[H], dgate_s[4 * H], dctx_s[H], dhprev_s[H], hq_s[H], dhq_s[H];
-  __shared__ float alpha_s[AD_MAXT], mem_s[AD_MAXT + 16], dal_s[AD_MAXT], de_s[AD_MAXT], dcov_s[AD_MAXT], dmem_s[AD_MAXT + 16];
+  __shared__ float alpha_s[AD_MAXT_TRAIN], mem_s[AD_MAXT_TRAIN + 16], dal_s[AD_MAXT_TRAIN], de_s[AD_MAXT_TRAIN], dcov_s[AD_MAXT_TRAIN], dmem_s[AD_MAXT_TRAIN + 16];
   __shared__ __attribute__((aligned(16))) float part_s[16][H];
   __shared__ float dl_s[1024], red_s[32];
   __shared__ __attribute__((aligned(16))) float wloc_s[11 * H];  // [tap][n]
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(1024) void attn_train_lstm_bwd_kernel(const AttnTra
   float* dkp = p.dkp + ((size_t)b * p.T + p.key_off) * H;
   for (int i = tid; i < p.taps * H; i += 1024) wloc_s[i] = p.wloc[(i % H) * p.taps + i / H];
   if (tid < H) { dh_s[tid] = 0.f; dc_s[tid] = 0.f; }
-  for (int i = tid; i < AD_MAXT; i += 1024) { dcov_s[i] = 0.f; mem_s[i] = 0.f; dmem_s[i] = 0.f; }
-  if (tid < 16) { mem_s[AD_MAXT + tid] = 0.f; dmem_s[AD_MAXT + tid] = 0.f; }
+  for (int i = tid; i < AD_MAXT_TRAIN; i += 1024) { dcov_s[i] = 0.f; mem_s[i] = 0.f; dmem_s[i] = 0.f; }
+  if (tid < 16) { mem_s[AD_MAXT_TRAIN + tid] = 0.f; dmem_s[AD_MAXT_TRAIN + tid] = 0.f; }
   __syncthreads();
   // memory after the last step = sum of all alignments (coverage) / the last alignment (location-aware)
   for (int t = 0; t < p.S; ++t)
@@ -629,7 +630,7 @@ hipError_t launch_attn_train_lstm_bwd(const AttnTrainBwdP& p_in, hipStream_t s) 
   AttnTrainBwdP p = p_in;
   static const int probe = D2T_PROBE_ENV("D2T_LSTM_BWD_PROBE");
   p.probe = probe;
-  if (p.H != 256 || p.D != 256 || p.E != 256 || p.V > 1024 || p.T - p.key_off > AD_MAXT || p.T - p.key_off < 1 || p.taps > 11)
+  if (p.H != 256 || p.D != 256 || p.E != 256 || p.V > 1024 || p.T - p.key_off > AD_MAXT_TRAIN || p.T - p.key_off < 1 || p.taps > 11)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(attn_train_lstm_bwd_kernel, dim3(p.B), dim3(1024), 0, s, p);
   return hipGetLastError();

@@ -810,10 +810,29 @@ def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
             seq, score, _ = mb(img[:1].cuda(), text[:1].cuda(), is_train=False)
             oseq, oscore, _ = R.forward(ob, osd, img[:1], text[:1], is_train=False)
         assert seq.tolist() == oseq.tolist() and abs(float(score) - float(oscore)) <= 1e-3
-        scfg = synth.make_config("S0", device="cuda", max_seq_len=L)  # HybridViT + Attnv2: 512-entry alignment rows
+        # HybridViT + Attnv2 (the shipped stack): the LSTM-attention decoder keeps two alignment rows of the memory's length in
+        # LDS, 4096 entries since round 4 -- 582 keys against the oracle
+        scfg = synth.make_config("S0", device="cuda", max_seq_len=L)
         scfg["max_dimension"] = [H, W]
         ms = Model(scfg)
         ms.load_state_dict(synth.synth_state_dict({k: v for k, v in ms.state_dict().items()}), strict=False)
         ms = ms.cuda().eval()
+        socfg, ssd = oracle_state_dict("S0", manifests["S0"], L)
+        socfg["max_dimension"] = [H, W]
+        ssd = dict(ssd)
+        ssd["seqmodeler.SequenceModeling.pos_embed"] = sd["seqmodeler.SequenceModeling.pos_embed"]
+        ztext = torch.zeros(B, L + 1, dtype=torch.long)
+        with torch.no_grad():
+            sp, sl, _ = ms(img.cuda(), ztext.cuda(), is_train=False)
+            osp, osl, _ = R.forward(socfg, ssd, img, ztext, is_train=False, is_test=False)
+        assert torch.equal(sp.cpu(), osp)
+        assert float((sl.cpu() - osl).abs().max()) <= LOGIT_TOL
+        # the d_model-512 decoder (ResNet + None + TFM-2) keeps 512-entry score rows: a 128 x 512 crop (7 x 129 = 903 keys) is
+        # refused with an error that names the limit
+        c1 = synth.make_config("C1", device="cuda", max_seq_len=L)
+        m1 = Model(c1)
+        m1.load_state_dict(synth.synth_state_dict({k: v for k, v in m1.state_dict().items()
+                                                   if not k.endswith("image_positional_encoder.pe")}), strict=False)
+        m1 = m1.cuda().eval()
         with torch.no_grad(), pytest.raises(RuntimeError, match="512"):
-            ms(img.cuda(), torch.zeros(B, L + 1, dtype=torch.long, device="cuda"), is_train=False)
+            m1(synth.synth_images(1, 128, 512, seed=3).cuda(), text[:1].cuda(), is_train=False)
