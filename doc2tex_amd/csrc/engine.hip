@@ -872,13 +872,11 @@ int d2t_encoder_shape(const d2t_ctx* c, int32_t H, int32_t W, int32_t* T, int32_
   return D2T_OK;
 }
 
-// Longest encoder memory a decode can attend over.  The absorbed cross-attention of the d_model-256 TFM decoder streams the
-// memory rows in 16-key tiles with a running softmax -- any length (4096 here: the shipped max_dimension [800, 800] gives
-// 2526 tokens); the projected-K/V kernels (d_model 512) and the LSTM-attention heads keep per-row score arrays of 512 entries.
-static int memory_cap(const d2t_ctx* c) {
-  if (c->cfg.decoder == D2T_DEC_ATTN) return 4096;  // two alignment rows of the memory's length in LDS (recurrent.hip AD_MAXT)
-  return c->dec_absorbed ? 4096 : 512;
-}
+// Longest encoder memory a decode can attend over: 4096 tokens (the shipped max_dimension [800, 800] gives 2526).  The TFM row
+// kernels walk the keys with a running softmax -- the absorbed form (d_model 256) in 16-key tiles, the projected-K/V form
+// (d_model 512) in groups per lane -- and the LSTM-attention decode kernel keeps two alignment rows of that length in LDS
+// (recurrent.hip AD_MAXT).
+static int memory_cap(const d2t_ctx*) { return 4096; }
 
 int d2t_encode(d2t_ctx* c, const float* image, int32_t B, int32_t H, int32_t W, float* memory, d2t_stream stream) {
   DevGuard dg_(c);

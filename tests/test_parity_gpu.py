@@ -827,12 +827,18 @@ def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
             osp, osl, _ = R.forward(socfg, ssd, img, ztext, is_train=False, is_test=False)
         assert torch.equal(sp.cpu(), osp)
         assert float((sl.cpu() - osl).abs().max()) <= LOGIT_TOL
-        # the d_model-512 decoder (ResNet + None + TFM-2) keeps 512-entry score rows: a 128 x 512 crop (7 x 129 = 903 keys) is
-        # refused with an error that names the limit
+        # the d_model-512 decoder (ResNet + None + TFM-2, projected K / V): a 128 x 512 crop is 7 x 129 = 903 keys
         c1 = synth.make_config("C1", device="cuda", max_seq_len=L)
         m1 = Model(c1)
         m1.load_state_dict(synth.synth_state_dict({k: v for k, v in m1.state_dict().items()
                                                    if not k.endswith("image_positional_encoder.pe")}), strict=False)
         m1 = m1.cuda().eval()
-        with torch.no_grad(), pytest.raises(RuntimeError, match="512"):
-            m1(synth.synth_images(1, 128, 512, seed=3).cuda(), text[:1].cuda(), is_train=False)
+        o1cfg, o1sd = oracle_state_dict("C1", manifests["C1"], L)
+        img1 = synth.synth_images(1, 128, 512, seed=3)
+        with torch.no_grad():
+            p1, l1, _ = m1(img1.cuda(), text[:1].cuda(), is_train=False)
+            op1, ol1, _ = R.forward(o1cfg, o1sd, img1, text[:1], is_train=False, is_test=False)
+            mem1, _, _ = m1.forward_encoder(img1.cuda())
+        assert mem1.shape[1] == 903
+        assert torch.equal(p1.cpu(), op1)
+        assert float((l1.cpu() - ol1).abs().max()) <= LOGIT_TOL
