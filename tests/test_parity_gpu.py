@@ -842,3 +842,30 @@ def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
         assert mem1.shape[1] == 903
         assert torch.equal(p1.cpu(), op1)
         assert float((l1.cpu() - ol1).abs().max()) <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("end_bias", [0.3, 0.0])
+def test_shipped_test_yaml_geometry(manifests, end_bias):
+    """config/test.yaml as shipped: HybridViT + Attnv2 (coverage LSTM head), max_dimension [448, 960] (1695 memory tokens),
+    batch_max_length 500, beam_size 5 -- one 448 x 960 crop through Model.forward against the oracle's beam search: the same
+    sequence and score, with the [s] bias raised (hypotheses complete after a few steps) and as seeded (all 501 steps run)."""
+    from doc2tex_amd import Model
+    H, W, L, beam = 448, 960, 500, 5
+    cfg = synth.make_config("S0", device="cuda", max_seq_len=L, beam_size=beam)
+    cfg["max_dimension"] = [H, W]
+    m = Model(cfg)
+    m.load_state_dict(synth.synth_state_dict({k: v for k, v in m.state_dict().items()}, end_bias=end_bias), strict=False)
+    m = m.cuda().eval()
+    ocfg, sd = oracle_state_dict("S0", manifests["S0"], L, end_bias=end_bias)
+    ocfg["max_dimension"] = [H, W]
+    ocfg["beam_size"] = beam
+    sd = dict(sd)
+    sd["seqmodeler.SequenceModeling.pos_embed"] = R.sincos_2d_table(256, *R.vit_max_grid([H, W], (2, 2)))
+    img = synth.synth_images(1, H, W, seed=77)
+    text = torch.zeros(1, L + 1, dtype=torch.long)
+    with torch.no_grad():
+        seq, score, _ = m(img.cuda(), text.cuda(), is_train=False)
+        oseq, oscore, _ = R.forward(ocfg, sd, img, text, is_train=False)
+    assert seq.tolist() == oseq.tolist()
+    assert (seq.shape[1] == L + 1) == (end_bias == 0.0)
+    assert abs(float(score) - float(oscore)) <= _score_tol(m, seq.shape[1])
