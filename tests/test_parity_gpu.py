@@ -763,12 +763,12 @@ def test_smallest_crop_and_crops_the_model_cannot_take(manifests):
     assert torch.equal(mem2, mem)
 
 
-@pytest.mark.parametrize("H,W,B,L", [(192, 768, 2, 6), (448, 960, 1, 4)])
+@pytest.mark.parametrize("H,W,B,L", [(192, 768, 2, 6), (448, 960, 1, 4), (800, 800, 1, 3)])
 def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
     """The shipped configurations allow crops up to 448 x 960 (config/test.yaml:3: 14 x 121 patches = 1695 memory tokens) and
     800 x 800; up to round 3 the engine stopped at 512 tokens (the ViT attention kernel held a head's whole K / V in LDS).  The
     HybridViT + TFM stack on such crops against the oracle: 192 x 768 (583 tokens: two query blocks, three key chunks per head)
-    and 448 x 960 itself -- encoder memory, greedy tokens and logits.  The stacks whose decode keeps 512-entry score rows
+    448 x 960 itself, and 800 x 800 (config/train.yaml:3: 2526 tokens) -- encoder memory, greedy tokens and logits.  The stacks whose decode keeps 512-entry score rows
     (LSTM-attention heads, d_model 512) still refuse with an error that names the limit."""
     from doc2tex_amd import Model
     cfg = synth.make_config("C2", device="cuda", max_seq_len=L)
