@@ -768,8 +768,9 @@ def test_crops_beyond_512_memory_tokens(manifests, H, W, B, L):
     """The shipped configurations allow crops up to 448 x 960 (config/test.yaml:3: 14 x 121 patches = 1695 memory tokens) and
     800 x 800; up to round 3 the engine stopped at 512 tokens (the ViT attention kernel held a head's whole K / V in LDS).  The
     HybridViT + TFM stack on such crops against the oracle: 192 x 768 (583 tokens: two query blocks, three key chunks per head)
-    448 x 960 itself, and 800 x 800 (config/train.yaml:3: 2526 tokens) -- encoder memory, greedy tokens and logits.  The stacks whose decode keeps 512-entry score rows
-    (LSTM-attention heads, d_model 512) still refuse with an error that names the limit."""
+    448 x 960 itself, and 800 x 800 (config/train.yaml:3: 2526 tokens) -- encoder memory, greedy tokens and logits.  At
+    192 x 768 also: TFM beam search, the shipped HybridViT + Attnv2 stack (the LSTM head's alignment rows: 4096 entries now) and
+    the d_model-512 decoder over 903 keys (ResNet + TFM-2 on a 128 x 512 crop)."""
     from doc2tex_amd import Model
     cfg = synth.make_config("C2", device="cuda", max_seq_len=L)
     cfg["max_dimension"] = [H, W]
