@@ -118,9 +118,9 @@ hipError_t launch_bilstm(const float* g, const float* whh_t, float* out, int B, 
 // ---------------------------------------------------------------------------
 // LSTM-attention greedy decoder: one block (1024 threads) per batch row runs every step.
 // D = E = H = 256, V <= 1024, Tk <= 4096 keys (two alignment rows of that length in LDS: 32 of the block's 58 KB; the
-// shipped max_dimension [800, 800] gives 2525).  The backward kernel of the training step keeps six such rows and stays at 512.
+// shipped max_dimension [800, 800] gives 2525).  The backward kernel of the training step keeps six such rows (96 of its 134 KB).
 // ---------------------------------------------------------------------------
-constexpr int AD_MAXT = 4096, AD_MAXT_TRAIN = 512;
+constexpr int AD_MAXT = 4096, AD_MAXT_TRAIN = 4096;
 
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecP p) {
   constexpr int H = 256;

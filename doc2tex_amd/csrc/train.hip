@@ -681,8 +681,8 @@ struct Tr {  // builder / runner bound to one context and stream
     const d2t_config& g = c->cfg;
     const TT f = st->t[feat];
     const int D = g.vit_dim, gh = (f.H + g.patch_h - 1) / g.patch_h, gw = (f.W + g.patch_w - 1) / g.patch_w, n = gh * gw;
-    // (the training attention kernels hold a head's whole K / V in LDS; inference has the chunked kernel, ops.hip)
-    if (n + 1 > 512) return fail(c, D2T_EINVAL, "training step: memory length %d > 512 unsupported", n + 1);
+    // (memories beyond about 600 tokens: the training attention kernels read K / V from global memory, train_kernels.hip GKV)
+    if (n + 1 > 4096) return fail(c, D2T_EINVAL, "training step: memory length %d > 4096 unsupported", n + 1);
     int patch;
     // zero padding right / bottom = out-of-image taps of the strided convolution
     RC(conv_bn(feat, p + "patch_embed.proj", "", D, g.patch_h, g.patch_w, g.patch_h, g.patch_w, 0, 0, false, -1, &patch, gh, gw));

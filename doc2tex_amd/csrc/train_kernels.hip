@@ -1085,20 +1085,34 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* mean, con
 // (keytok[b][j] == pad_id masked) -- nn.MultiheadAttention's additive -inf masks (tfm.py:74-91).
 // probs [B][heads][Lq][Lk] is written for the backward pass.
 // ---------------------------------------------------------------------------
-template <int HD>
+// GKV (memories too long for a head's K and V to sit in LDS: crops beyond about 600 tokens, the shipped max_dimension [800, 800]
+// gives 2526): the same loops read K / V rows from global memory (L2) -- slow, and the same sums in the same order.
+template <int HD, bool GKV = false>
 __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;                          // [Lk][HD+1]
-  float* Vs = Ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD]
-  float* Ps = Vs + (size_t)p.Lk * HD;        // [waves][Lk]
   const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
-  for (int i = tid; i < p.Lk * HD; i += NT) {
-    const int j = i / HD, c = i % HD;
-    Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
-    Vs[j * HD + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+  const float* Ks;  // key j, channel c at Ks[j * KLD + c]
+  const float* Vs;
+  float* Ps;        // [waves][Lk]
+  int KLD, VLD;
+  if (GKV) {
+    Ks = p.k + (size_t)b * p.Lk * p.ldk + hh * HD; KLD = p.ldk;
+    Vs = p.v + (size_t)b * p.Lk * p.ldv + hh * HD; VLD = p.ldv;
+    Ps = sm;
+  } else {
+    float* ks = sm;                              // [Lk][HD+1]
+    float* vs = ks + (size_t)p.Lk * (HD + 1);    // [Lk][HD]
+    Ps = vs + (size_t)p.Lk * HD;
+    for (int i = tid; i < p.Lk * HD; i += NT) {
+      const int j = i / HD, c = i % HD;
+      ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
+      vs[j * HD + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+    }
+    __syncthreads();
+    Ks = ks; KLD = HD + 1;
+    Vs = vs; VLD = HD;
   }
-  __syncthreads();
   const float scale = rsqrtf((float)HD);
   float* P = Ps + (size_t)wave * p.Lk;
   for (int i = wave; i < p.Lq; i += NW) {
@@ -1114,7 +1128,7 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainP p
       if (ok) {
         a = 0.f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) a = fmaf(q[c], Ks[j * (HD + 1) + c], a);
+        for (int c = 0; c < HD; ++c) a = fmaf(q[c], Ks[(size_t)j * KLD + c], a);
         a *= scale;
       }
       P[j] = a;
@@ -1141,7 +1155,7 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainP p
     const int c = lane % HD, ph = lane / HD;
     float o = 0.f;
 #pragma unroll 8
-    for (int j = ph; j < p.Lk; j += PH) o = fmaf(P[j], Vs[j * HD + c], o);
+    for (int j = ph; j < p.Lk; j += PH) o = fmaf(P[j], Vs[(size_t)j * VLD + c], o);
     if (PH == 2) o += __shfl_xor(o, 32, 64);
     if (lane < HD) p.o[((size_t)b * p.Lq + i) * p.ldo + hh * HD + c] = o;
   }
@@ -1158,11 +1172,29 @@ static int attn_waves(size_t base_bytes, int Lk) {
     if (base_bytes + (size_t)nw * Lk * 4 <= 160 * 1024) return nw;
   return 4;
 }
+// waves of the global-K/V forms: as many per-wave rows of Lk floats as fit (a multiple of four, at most sixteen)
+static int attn_waves_gkv(int Lk) {
+  int nw = (int)((size_t)160 * 1024 / ((size_t)Lk * 4)) & ~3;
+  return nw > 16 ? 16 : nw;
+}
 hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s) {
   const size_t base = ((size_t)p.Lk * (p.hd + 1) + (size_t)p.Lk * p.hd) * 4;
+  hipError_t e;
+  if (base + (size_t)4 * p.Lk * 4 > 160 * 1024) {  // K and V of a head do not fit in LDS beside four score rows
+    const int nwg = attn_waves_gkv(p.Lk);
+    if (nwg < 4 || (p.hd != 32 && p.hd != 64)) return hipErrorInvalidValue;
+    const size_t ldsg = (size_t)nwg * p.Lk * 4;
+    if (p.hd == 32) {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<32, true>), ldsg)) != hipSuccess) return e;
+      hipLaunchKernelGGL((attn_train_fwd_kernel<32, true>), dim3(p.B * p.heads), dim3(nwg * 64), ldsg, s, p);
+    } else {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<64, true>), ldsg)) != hipSuccess) return e;
+      hipLaunchKernelGGL((attn_train_fwd_kernel<64, true>), dim3(p.B * p.heads), dim3(nwg * 64), ldsg, s, p);
+    }
+    return hipGetLastError();
+  }
   const int nw = attn_waves(base, p.Lk);
   const size_t lds = base + (size_t)nw * p.Lk * 4;
-  hipError_t e;
   if (p.hd == 32) {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_fwd_kernel<32>), lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(attn_train_fwd_kernel<32>, dim3(p.B * p.heads), dim3(nw * 64), lds, s, p);
@@ -1178,25 +1210,38 @@ hipError_t launch_attn_train_fwd(const AttnTrainP& p, hipStream_t s) {
 // Backward: dV = P^T dO;  dP = dO V^T;  dS = P * (dP - rowsum(dP * P));  dQ = scale * dS K;  dK = scale * dS^T Q.
 // One block per (batch, head); dS overwrites the saved probabilities in place (phase 2), phases separated by
 // block barriers.  p.o carries dO; p.dq / p.dk / p.dv use the q / k / v strides.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p) {
+// (GKV: K / V rows from global memory, as in the forward kernel; any multiple of 64 threads)
+template <int HD, bool GKV = false>
+__global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Ks = sm;                            // [Lk][HD+1]
-  float* Vs = Ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD+1]
-  float* Ds = Vs + (size_t)p.Lk * (HD + 1);  // [4 waves][Lk]: the dS row a wave is working on
   const int b = blockIdx.x / p.heads, hh = blockIdx.x % p.heads;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < p.Lk * HD; i += 256) {
-    const int j = i / HD, c = i % HD;
-    Ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
-    Vs[j * (HD + 1) + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
+  const float* Ks;  // key j, channel c at Ks[j * KLD + c]
+  const float* Vs;
+  float* Ds;        // [waves][Lk]: the dS row a wave is working on
+  int KLD, VLD;
+  if (GKV) {
+    Ks = p.k + (size_t)b * p.Lk * p.ldk + hh * HD; KLD = p.ldk;
+    Vs = p.v + (size_t)b * p.Lk * p.ldv + hh * HD; VLD = p.ldv;
+    Ds = sm;
+  } else {
+    float* ks = sm;                            // [Lk][HD+1]
+    float* vs = ks + (size_t)p.Lk * (HD + 1);  // [Lk][HD+1]
+    Ds = vs + (size_t)p.Lk * (HD + 1);
+    for (int i = tid; i < p.Lk * HD; i += NT) {
+      const int j = i / HD, c = i % HD;
+      ks[j * (HD + 1) + c] = p.k[((size_t)b * p.Lk + j) * p.ldk + hh * HD + c];
+      vs[j * (HD + 1) + c] = p.v[((size_t)b * p.Lk + j) * p.ldv + hh * HD + c];
+    }
+    Ks = ks; KLD = HD + 1;
+    Vs = vs; VLD = HD + 1;
   }
   float* probs = p.probs + ((size_t)b * p.heads + hh) * p.Lq * p.Lk;
   constexpr int PH = 64 / HD;
   const int c = lane % HD, ph = lane / HD;
   const uint8_t* dmask = p.dropmask ? p.dropmask + ((size_t)b * p.heads + hh) * p.Lq * p.Lk : nullptr;
   // phase 1: dV[j][c] = sum_i (P o D)[i][j] * dO[i][c]   (wave per key; D = dropout keep mask * scale)
-  for (int j = wave; j < p.Lk; j += 4) {
+  for (int j = wave; j < p.Lk; j += NW) {
     float a = 0.f;
 #pragma unroll 8
     for (int i = ph; i < p.Lq; i += PH) {
@@ -1210,7 +1255,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
   __syncthreads();
   const float scale = rsqrtf((float)HD);
   // phase 2: per query row: dS, dQ (wave per query)
-  for (int i = wave; i < p.Lq; i += 4) {
+  for (int i = wave; i < p.Lq; i += NW) {
     const float* dop = p.o + ((size_t)b * p.Lq + i) * p.ldo + hh * HD;
     float d_o[HD];
 #pragma unroll
@@ -1221,7 +1266,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
     for (int j = lane; j < p.Lk; j += 64) {
       float dp = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[(size_t)j * VLD + cc], dp);
       if (mrow) dp *= mrow[j] ? p.dropscale : 0.f;
       dsum = fmaf(dp, prow[j], dsum);
     }
@@ -1229,7 +1274,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
     for (int j = lane; j < p.Lk; j += 64) {
       float dp = 0.f;
 #pragma unroll
-      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[j * (HD + 1) + cc], dp);
+      for (int cc = 0; cc < HD; ++cc) dp = fmaf(d_o[cc], Vs[(size_t)j * VLD + cc], dp);
       if (mrow) dp *= mrow[j] ? p.dropscale : 0.f;
       const float ds = prow[j] * (dp - dsum);
       prow[j] = ds;  // read again by phase 3 (after the block barrier)
@@ -1237,13 +1282,13 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(const AttnTrainP p)
     }
     float a = 0.f;
 #pragma unroll 8
-    for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[j * (HD + 1) + c], a);
+    for (int j = ph; j < p.Lk; j += PH) a = fmaf(Ds[wave * p.Lk + j], Ks[(size_t)j * KLD + c], a);
     if (PH == 2) a += __shfl_xor(a, 32, 64);
     if (lane < HD) p.dq[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c] = a * scale;
   }
   __syncthreads();
   // phase 3: dK[j][c] = scale * sum_i dS[i][j] * Q[i][c]   (wave per key)
-  for (int j = wave; j < p.Lk; j += 4) {
+  for (int j = wave; j < p.Lk; j += NW) {
     float a = 0.f;
 #pragma unroll 8
     for (int i = ph; i < p.Lq; i += PH) a = fmaf(probs[(size_t)i * p.Lk + j], p.q[((size_t)b * p.Lq + i) * p.ldq + hh * HD + c], a);
@@ -1354,14 +1399,26 @@ hipError_t launch_attn_train_bwd(const AttnTrainP& p_in, hipStream_t s) {
     }
     return hipGetLastError();
   }
+  if (p.hd != 32 && p.hd != 64) return hipErrorInvalidValue;
+  if (lds > 160 * 1024) {  // K and V of a head do not fit in LDS: rows from global memory
+    const int nwg = attn_waves_gkv(p.Lk);
+    if (nwg < 4) return hipErrorInvalidValue;
+    const size_t ldsg = (size_t)nwg * p.Lk * 4;
+    if (p.hd == 32) {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<32, true>), ldsg)) != hipSuccess) return e;
+      hipLaunchKernelGGL((attn_train_bwd_kernel<32, true>), dim3(p.B * p.heads), dim3(nwg * 64), ldsg, s, p);
+    } else {
+      if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<64, true>), ldsg)) != hipSuccess) return e;
+      hipLaunchKernelGGL((attn_train_bwd_kernel<64, true>), dim3(p.B * p.heads), dim3(nwg * 64), ldsg, s, p);
+    }
+    return hipGetLastError();
+  }
   if (p.hd == 32) {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<32>), lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(attn_train_bwd_kernel<32>, dim3(p.B * p.heads), dim3(256), lds, s, p);
-  } else if (p.hd == 64) {
+  } else {
     if ((e = attn_lds(reinterpret_cast<const void*>(attn_train_bwd_kernel<64>), lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(attn_train_bwd_kernel<64>, dim3(p.B * p.heads), dim3(256), lds, s, p);
-  } else {
-    return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

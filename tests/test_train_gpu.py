@@ -623,3 +623,37 @@ def test_training_step_under_autocast_and_grad_scaler(cases):
     scaler.update()
     assert scaler.get_scale() == 2.0 ** 12  # no inf / nan found: the step was taken, the scale kept
     assert any(not torch.equal(p.detach(), before[k]) for k, p in m.named_parameters() if k in before)
+
+
+@pytest.mark.parametrize("cname", ["T2", "TS0"])
+def test_training_step_over_a_memory_beyond_512_tokens(manifests, cname):
+    """The shipped training configuration allows crops up to 800 x 800 (config/train.yaml:3: 2526 memory tokens).  Beyond about 600
+    tokens a head's K and V no longer fit in LDS beside the score rows: the training attention kernels then read K / V rows from
+    global memory (train_kernels.hip GKV: the same sums in the same order, slower), and the LSTM head's backward keeps its six
+    alignment rows at 4096 entries.  A 192 x 768 crop (583 tokens) through the whole step -- loss, logits and every gradient
+    against the oracle's autograd -- on the HybridViT + TFM stack (ViT self-attention and decoder cross-attention over 583 keys)
+    and on HybridViT + Attnv2 (582 keys in the LSTM head)."""
+    H, W, B, L = 192, 768, 2, 8
+    from doc2tex_amd import Model
+    cfg = synth.make_config(cname, device="cuda", max_seq_len=L)
+    cfg["max_dimension"] = [H, W]
+    m = Model(cfg)
+    m.load_state_dict(synth.synth_state_dict({k: v for k, v in m.state_dict().items()}), strict=False)
+    m = m.cuda()
+    m.conv_precision = "fp32"
+    ocfg, sd = oracle_state_dict(cname, manifests[cname], L)
+    ocfg["max_dimension"] = [H, W]
+    sd = dict(sd)
+    sd["seqmodeler.SequenceModeling.pos_embed"] = R.sincos_2d_table(256, *R.vit_max_grid([H, W], (2, 2)))
+    img = synth.synth_images(B, H, W, seed=1234)
+    g = torch.Generator().manual_seed(7)
+    text = torch.zeros(B, L + 2, dtype=torch.long)
+    attn = cfg["Prediction"]["name"] != "TFM"
+    text[:, 0] = 0 if attn else 1                                   # [GO]
+    text[:, 1:L] = torch.randint(4, 400, (B, L - 1), generator=g)
+    text[:, L] = 1 if attn else 2                                   # [s]; the last column stays PAD / [GO]-index padding
+    oloss, ologits, ograds, obn = R.train_step_grads(ocfg, sd, img, text)
+    loss, preds = _step(m, img, text)
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    assert float((preds.cpu() - ologits).abs().max()) <= 1e-3
+    _check_instance(m, ograds)
